@@ -1,0 +1,167 @@
+/*
+ * kinetica_hip.h - C ABI of libkinetica_hip.so, the MI355X (gfx950) implementation of
+ * Kinetica.jl's kinetic-ODE solve path (src/solving in the reference).
+ *
+ * The reference has no FFI on this path (pure Julia multiple dispatch), so this
+ * header DEFINES the boundary a `ccall` shim binds. Every entry
+ * point cites the reference code it stands in for (paths relative to the reference
+ * repository root). Conventions:
+ *   - all entry points are extern "C", return an int status (KIN_OK == 0) and never throw;
+ *   - plain pointers and sizes only; the caller owns every host buffer, the library
+ *     never keeps a host pointer after a call returns;
+ *   - Float64 / Int64 everywhere, as the reference (init_network(fType=Float64,
+ *     iType=Int64), src/exploration/network.jl:491);
+ *   - `index_base` is 1 when called from Julia (1-based species ids,
+ *     src/exploration/network.jl:55-56) and 0 from C / Python;
+ *   - one host thread per handle; handles are independent (one per GPU / stream);
+ *   - a handle owns device memory; kin_network_destroy(NULL) is a no-op.
+ * There is no CPU fallback: without a HIP device every compute call returns
+ * KIN_ERR_DEVICE.
+ */
+#ifndef KINETICA_HIP_H
+#define KINETICA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (error convention of SURVEY 8(b)) ------------------------------ */
+enum {
+  KIN_OK = 0,
+  KIN_ERR_INVALID_ARG = 1,   /* ArgumentError in the reference (params.jl:77-104, calculator.jl:200-204) */
+  KIN_ERR_UNSUPPORTED = 2,   /* molecularity > 2 on one side (network.jl:275-279) */
+  KIN_ERR_DEVICE = 3,        /* HIP runtime error / no device */
+  KIN_ERR_SOLVE_FAILED = 4,  /* ErrorException("ODE solution failed.") (solve_utils.jl:405-411) */
+  KIN_ERR_CAPACITY = 5,      /* caller-provided output buffer too small */
+  KIN_ERR_STATE = 6          /* call order violated (e.g. rates never set) */
+};
+
+/* ---- integrator return codes, 1:1 with SciMLBase.ReturnCode as consumed by
+ *      successful_retcode (solve_utils.jl:391) and stored in the solution (methods.jl:862) */
+enum {
+  KIN_RETCODE_SUCCESS = 0,
+  KIN_RETCODE_MAXITERS = 1,
+  KIN_RETCODE_DTLESSTHANMIN = 2,
+  KIN_RETCODE_UNSTABLE = 3
+};
+
+typedef struct kin_network kin_network; /* opaque */
+
+/* ---- A1: CRN topology ------------------------------------------------------------- */
+/* Replaces the four ragged vectors of RxData the solve reads (id_reacs, stoic_reacs,
+ * id_prods, stoic_prods; src/exploration/network.jl:193-203) in flat CSR-like form:
+ * reaction r consumes reac_idx[reac_ptr[r]..reac_ptr[r+1]) with stoichiometries reac_sto,
+ * and likewise for products. ptr arrays are always 0-based offsets; idx uses index_base.
+ * Rate law and ODEs are those of make_rs (src/solving/solve_utils.jl:318-334) with
+ * combinatoric_ratelaws=false. */
+int kin_network_create(int64_t n_species, int64_t n_reactions,
+                       const int64_t* reac_ptr, const int64_t* reac_idx, const int64_t* reac_sto,
+                       const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
+                       int index_base, kin_network** out);
+int kin_network_destroy(kin_network* h);
+int kin_network_sizes(const kin_network* h, int64_t* n_species, int64_t* n_reactions);
+/* Last error text of this handle (or of the failed create when h == NULL). */
+const char* kin_last_error(const kin_network* h);
+
+/* ---- A6: rate constants ------------------------------------------------------------ */
+/* DummyKineticCalculator / any external calculator: hand over k[R] directly
+ * (calculator.jl:127-152 produces such a vector). */
+int kin_set_rates(kin_network* h, const double* k);
+int kin_get_rates(kin_network* h, double* k_out);
+/* PrecalculatedArrheniusCalculator parameters (calculator.jl:164-198). k_max = NaN means
+ * `k_max = nothing`; t_mult = tconvert(t_unit, "s") (calculator.jl:196, utils.jl:21-30). */
+int kin_set_arrhenius(kin_network* h, const double* Ea, const double* A, double k_max, double t_mult);
+/* k = calculator(; T) (calculator.jl:223-232) evaluated on the device; becomes the
+ * handle's current rate vector; k_out (host, R doubles) may be NULL. */
+int kin_rates_at(kin_network* h, double T, double* k_out);
+/* Network-free form of the same functor, used by the host for get_max_rates /
+ * apply_low_k_cutoff! (solve_utils.jl:19-54, 213-245) before a handle exists. */
+int kin_arrhenius_eval(const double* Ea, const double* A, int64_t n, double k_max, double t_mult,
+                       double T, double* k_out);
+/* A8: calculate_discrete_rates (solve_utils.jl:91-109): table[s][r] = calculator(T[s])[r],
+ * S x R doubles, row-major; generated on the device. out_table (host) may be NULL, in which
+ * case the table only stays resident on the device for kin_solve. */
+int kin_rate_table(kin_network* h, const double* T, int64_t n_stops, double* out_table);
+
+/* ---- A2: mass-action right-hand side ------------------------------------------------ */
+/* du = f(u; k) for the current rates: the generated f! of ODEProblem (methods.jl:157). */
+int kin_rhs(kin_network* h, const double* u, double* du);
+/* B states at once, host buffers in the reference's layout u[b][N], du[b][N] (sol.u is a
+ * Vector of Vectors); k is per state k[b][R] or NULL (current rates for every state). */
+int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k, double* du);
+/* The same sweep on device-resident buffers (no PCIe): species-major, state-contiguous
+ * layouts u[N][ldb], k[R][ldb] (or NULL), du[N][ldb]; ldb >= B and ldb % 8 == 0.
+ * `stream` is a hipStream_t (NULL = the handle's stream); the call only enqueues. */
+int kin_rhs_batched_dev(kin_network* h, int64_t B, int64_t ldb, const double* d_u, const double* d_k,
+                        double* d_du, void* stream);
+/* Workspace the batched sweep needs for B states (the handle grows it on demand). */
+int kin_rhs_batched_reserve(kin_network* h, int64_t B);
+
+/* ---- A3: analytic sparse Jacobian ---------------------------------------------------- */
+/* Replaces ODEProblem(...; jac=true, sparse=true) (methods.jl:157-158): pattern (CSR,
+ * sorted columns, diagonal always present) and values for the current rates. The reference
+ * stores SparseMatrixCSC; CSR of J is CSC of transpose(J), the shim picks what it needs. */
+int kin_jac_nnz(kin_network* h, int64_t* nnz);
+int kin_jac_pattern(kin_network* h, int64_t* rowptr, int64_t* colidx, int index_base);
+int kin_jac_values(kin_network* h, const double* u, double* vals);
+
+/* ---- A12: ODESimulationParams (src/solving/params.jl:3-27, defaults :55-75) ---------- */
+typedef struct kin_params {
+  double tspan0, tspan1;     /* tspan */
+  double abstol;             /* 1e-10 */
+  double reltol;             /* 1e-8  */
+  int32_t adaptive_tols;     /* true  */
+  int32_t update_tols;       /* false */
+  int32_t solve_chunks;      /* true  */
+  int32_t ban_negatives;     /* false: isoutofdomain = any(u < 0) (methods.jl:169-171) */
+  double solve_chunkstep;    /* 1e-3  */
+  int64_t maxiters;          /* 100000 */
+  double save_interval;      /* < 0 means `nothing` */
+  /* `solver`, `jac`, `sparse`, `progress`, `u0`, `low_k_*`, `allow_short_u0` are consumed
+   * by the host layer (the integrator is always the library's BDF with the analytic
+   * sparse Jacobian). */
+} kin_params;
+
+typedef struct kin_stats {
+  int64_t n_steps, n_rejected, n_rhs, n_jac, n_factor, n_linsolve, n_newton_fail;
+  int64_t n_chunks, n_restarts, n_retries;
+  double final_abstol, final_reltol; /* what update_tols writes back (solve_utils.jl:397-401) */
+  double wall_seconds;
+  int64_t lu_dense_dim, lu_sparse_rows, lu_rounds, lu_nnz;
+} kin_stats;
+
+/* ---- A4/A5/A9/A10: the solve --------------------------------------------------------- */
+/* Integrates du/dt = f(u; k) over params->tspan from u0 with the library's variable-order
+ * BDF (orders 1-5, modified Newton, analytic sparse Jacobian, on-device sparse LU), standing
+ * in for init/solve!/reinit! of the user-supplied stiff solver (methods.jl:174, 241, 260,
+ * 779, 819; solve_utils.jl:389) including:
+ *   - chunkwise local-time solving and output stitching (methods.jl:185-303, 717-865),
+ *   - complete-timespan solving (methods.jl:132-183, 655-714) when solve_chunks == 0,
+ *   - discrete rate-constant updates at `tstops` (solve_utils.jl:435-509): k is held
+ *     piecewise constant and switched at every tstop; rates come from k_table[s][R] (host,
+ *     any calculator) or, when k_table == NULL, from the Arrhenius parameters at T_stops[s];
+ *     n_stops == 0 means static rates (StaticODESolve),
+ *   - the tolerance-tightening retry loop adaptive_solve! (solve_utils.jl:376-424).
+ * Results stay in the handle; fetch them with kin_solution_size / kin_solution_copy.
+ * Returns KIN_ERR_SOLVE_FAILED (with *retcode set) when adaptive_solve! would throw. */
+int kin_solve(kin_network* h, const kin_params* params, const double* u0,
+              const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops,
+              int64_t* n_saved, int32_t* retcode, kin_stats* stats);
+int kin_solution_size(const kin_network* h, int64_t* n_saved, int64_t* n_species);
+/* out_t[n_saved], out_u[n_saved][N] (sol.t / sol.u of ODESolveOutput, analysis/io.jl:3-11). */
+int kin_solution_copy(const kin_network* h, double* out_t, double* out_u);
+/* N2: max over saved times of each species (what identify_next_seeds reads,
+ * src/exploration/explore_utils.jl:344-351), reduced on the device. */
+int kin_solution_max(const kin_network* h, double* out_umax);
+
+/* ---- device / build information ------------------------------------------------------- */
+int kin_device_count(int* n);
+int kin_set_device(int device);
+const char* kin_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KINETICA_HIP_H */

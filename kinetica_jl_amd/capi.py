@@ -1,0 +1,255 @@
+"""ctypes binding of libkinetica_hip.so (C ABI: include/kinetica_hip.h).
+
+This is the Python twin of the Julia `ccall` shim shown in INTEGRATION.md. There is no CPU
+fallback: a missing library or a missing HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkinetica_hip.so")
+
+KIN_OK, KIN_ERR_INVALID_ARG, KIN_ERR_UNSUPPORTED, KIN_ERR_DEVICE, KIN_ERR_SOLVE_FAILED, KIN_ERR_CAPACITY, KIN_ERR_STATE = range(7)
+RETCODE_NAMES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable"}
+
+# every symbol include/kinetica_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "kin_network_create", "kin_network_destroy", "kin_network_sizes", "kin_last_error",
+    "kin_set_rates", "kin_get_rates", "kin_set_arrhenius", "kin_rates_at", "kin_arrhenius_eval",
+    "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev", "kin_rhs_batched_reserve",
+    "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solution_size",
+    "kin_solution_copy", "kin_solution_max", "kin_device_count", "kin_set_device", "kin_version",
+]
+
+
+class KinParams(ctypes.Structure):
+    """kin_params: mirror of ODESimulationParams (src/solving/params.jl:3-27)."""
+    _fields_ = [("tspan0", c_double), ("tspan1", c_double), ("abstol", c_double), ("reltol", c_double),
+                ("adaptive_tols", c_int32), ("update_tols", c_int32), ("solve_chunks", c_int32),
+                ("ban_negatives", c_int32), ("solve_chunkstep", c_double), ("maxiters", c_int64),
+                ("save_interval", c_double)]
+
+
+class KinStats(ctypes.Structure):
+    _fields_ = [(n, c_int64) for n in ("n_steps", "n_rejected", "n_rhs", "n_jac", "n_factor", "n_linsolve",
+                                        "n_newton_fail", "n_chunks", "n_restarts", "n_retries")] + \
+               [("final_abstol", c_double), ("final_reltol", c_double), ("wall_seconds", c_double)] + \
+               [(n, c_int64) for n in ("lu_dense_dim", "lu_sparse_rows", "lu_rounds", "lu_nnz")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class KineticaHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[kin status {code}] {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libkinetica_hip.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is mandatory, there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        P64, PD = POINTER(c_int64), POINTER(c_double)
+        L.kin_version.restype = c_char_p
+        L.kin_last_error.restype = c_char_p
+        L.kin_last_error.argtypes = [c_void_p]
+        L.kin_network_create.argtypes = [c_int64, c_int64, P64, P64, P64, P64, P64, P64, c_int, POINTER(c_void_p)]
+        L.kin_network_destroy.argtypes = [c_void_p]
+        L.kin_network_sizes.argtypes = [c_void_p, P64, P64]
+        L.kin_set_rates.argtypes = [c_void_p, PD]
+        L.kin_get_rates.argtypes = [c_void_p, PD]
+        L.kin_set_arrhenius.argtypes = [c_void_p, PD, PD, c_double, c_double]
+        L.kin_rates_at.argtypes = [c_void_p, c_double, PD]
+        L.kin_arrhenius_eval.argtypes = [PD, PD, c_int64, c_double, c_double, c_double, PD]
+        L.kin_rate_table.argtypes = [c_void_p, PD, c_int64, PD]
+        L.kin_rhs.argtypes = [c_void_p, PD, PD]
+        L.kin_rhs_batched.argtypes = [c_void_p, c_int64, PD, PD, PD]
+        L.kin_rhs_batched_dev.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.kin_rhs_batched_reserve.argtypes = [c_void_p, c_int64]
+        L.kin_jac_nnz.argtypes = [c_void_p, P64]
+        L.kin_jac_pattern.argtypes = [c_void_p, P64, P64, c_int]
+        L.kin_jac_values.argtypes = [c_void_p, PD, PD]
+        L.kin_solve.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64, P64, POINTER(c_int32),
+                                POINTER(KinStats)]
+        L.kin_solution_size.argtypes = [c_void_p, P64, P64]
+        L.kin_solution_copy.argtypes = [c_void_p, PD, PD]
+        L.kin_solution_max.argtypes = [c_void_p, PD]
+        L.kin_device_count.argtypes = [POINTER(c_int)]
+        L.kin_set_device.argtypes = [c_int]
+        _lib = L
+    return _lib
+
+
+def _pd(a):
+    return None if a is None else a.ctypes.data_as(POINTER(c_double))
+
+
+def _p64(a):
+    return a.ctypes.data_as(POINTER(c_int64))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = c_int(0)
+    lib().kin_device_count(ctypes.byref(n))
+    return n.value
+
+
+def arrhenius_eval(Ea, A, T, k_max=None, t_mult=1.0):
+    """calculator(; T) on the device without a network handle."""
+    Ea, A = _f64(Ea), _f64(A)
+    out = np.empty(len(Ea))
+    st = lib().kin_arrhenius_eval(_pd(Ea), _pd(A), len(Ea), float("nan") if k_max is None else k_max, t_mult, T, _pd(out))
+    if st != KIN_OK:
+        raise KineticaHipError(st, lib().kin_last_error(None).decode())
+    return out
+
+
+class HipNetwork:
+    """Owning wrapper of a kin_network handle."""
+
+    def __init__(self, n_species, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto, index_base=0):
+        arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto)]
+        self._h = c_void_p()
+        st = lib().kin_network_create(int(n_species), len(arrs[0]) - 1, *[_p64(a) for a in arrs], index_base,
+                                      ctypes.byref(self._h))
+        if st != KIN_OK:
+            raise KineticaHipError(st, lib().kin_last_error(None).decode())
+        self.n = int(n_species)
+        self.nr = len(arrs[0]) - 1
+
+    @classmethod
+    def from_flat(cls, net):
+        return cls(net.n_species, net.reac_ptr, net.reac_idx, net.reac_sto, net.prod_ptr, net.prod_idx, net.prod_sto)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kin_network_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, st):
+        if st != KIN_OK:
+            raise KineticaHipError(st, lib().kin_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    # --- rates -------------------------------------------------------------------------
+    def set_rates(self, k):
+        k = _f64(k)
+        assert len(k) == self.nr
+        self._chk(lib().kin_set_rates(self._h, _pd(k)))
+
+    def get_rates(self):
+        out = np.empty(self.nr)
+        self._chk(lib().kin_get_rates(self._h, _pd(out)))
+        return out
+
+    def set_arrhenius(self, Ea, A, k_max=None, t_mult=1.0):
+        Ea, A = _f64(Ea), _f64(A)
+        assert len(Ea) == self.nr and len(A) == self.nr
+        self._chk(lib().kin_set_arrhenius(self._h, _pd(Ea), _pd(A), float("nan") if k_max is None else k_max, t_mult))
+
+    def rates_at(self, T):
+        out = np.empty(self.nr)
+        self._chk(lib().kin_rates_at(self._h, float(T), _pd(out)))
+        return out
+
+    def rate_table(self, T_stops, fetch=True):
+        T_stops = _f64(T_stops)
+        out = np.empty((len(T_stops), self.nr)) if fetch else None
+        self._chk(lib().kin_rate_table(self._h, _pd(T_stops), len(T_stops), _pd(out)))
+        return out
+
+    # --- RHS / Jacobian ------------------------------------------------------------------
+    def rhs(self, u):
+        u = _f64(u)
+        assert len(u) == self.n
+        du = np.empty(self.n)
+        self._chk(lib().kin_rhs(self._h, _pd(u), _pd(du)))
+        return du
+
+    def rhs_batched(self, u, k=None):
+        u = _f64(u)
+        B = u.shape[0]
+        assert u.shape == (B, self.n)
+        if k is not None:
+            k = _f64(k)
+            assert k.shape == (B, self.nr)
+        du = np.empty((B, self.n))
+        self._chk(lib().kin_rhs_batched(self._h, B, _pd(u), _pd(k), _pd(du)))
+        return du
+
+    def rhs_batched_reserve(self, B):
+        self._chk(lib().kin_rhs_batched_reserve(self._h, int(B)))
+
+    def rhs_batched_dev(self, B, ldb, d_u, d_k, d_du, stream=0):
+        """Device pointers (ints), state-contiguous layouts; only enqueues."""
+        self._chk(lib().kin_rhs_batched_dev(self._h, int(B), int(ldb), c_void_p(d_u), c_void_p(d_k) if d_k else None,
+                                            c_void_p(d_du), c_void_p(stream) if stream else None))
+
+    def jac_pattern(self, index_base=0):
+        nnz = c_int64(0)
+        self._chk(lib().kin_jac_nnz(self._h, ctypes.byref(nnz)))
+        rowptr = np.empty(self.n + 1, np.int64)
+        col = np.empty(nnz.value, np.int64)
+        self._chk(lib().kin_jac_pattern(self._h, _p64(rowptr), _p64(col), index_base))
+        return rowptr, col
+
+    def jac_values(self, u):
+        u = _f64(u)
+        nnz = c_int64(0)
+        self._chk(lib().kin_jac_nnz(self._h, ctypes.byref(nnz)))
+        vals = np.empty(nnz.value)
+        self._chk(lib().kin_jac_values(self._h, _pd(u), _pd(vals)))
+        return vals
+
+    # --- solve -----------------------------------------------------------------------------
+    def solve(self, params: KinParams, u0, tstops=None, T_stops=None, k_table=None):
+        """kin_solve + kin_solution_copy. Returns (t[M], u[M][N], retcode, stats dict)."""
+        u0 = _f64(u0)
+        assert len(u0) == self.n
+        n_stops = 0
+        if tstops is not None:
+            tstops = _f64(tstops)
+            n_stops = len(tstops)
+            if T_stops is not None:
+                T_stops = _f64(T_stops)
+                assert len(T_stops) == n_stops
+            if k_table is not None:
+                k_table = _f64(k_table)
+                assert k_table.shape == (n_stops, self.nr)
+        n_saved, rc, stats = c_int64(0), c_int32(0), KinStats()
+        st = lib().kin_solve(self._h, ctypes.byref(params), _pd(u0), _pd(tstops), _pd(T_stops), _pd(k_table), n_stops,
+                             ctypes.byref(n_saved), ctypes.byref(rc), ctypes.byref(stats))
+        if st not in (KIN_OK, KIN_ERR_SOLVE_FAILED):
+            self._chk(st)
+        t = np.empty(n_saved.value)
+        u = np.empty((n_saved.value, self.n))
+        if n_saved.value:
+            self._chk(lib().kin_solution_copy(self._h, _pd(t), _pd(u)))
+        return t, u, rc.value, stats.as_dict(), st
+
+    def solution_max(self):
+        out = np.empty(self.n)
+        self._chk(lib().kin_solution_max(self._h, _pd(out)))
+        return out

@@ -1,0 +1,326 @@
+// extern "C" boundary of libkinetica_hip.so (declarations + reference citations:
+// include/kinetica_hip.h). Every entry point converts exceptions into status codes.
+#include "../../include/kinetica_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "handle.hpp"
+#include "solver.hpp"
+
+using namespace kin;
+
+static thread_local std::string g_create_err;
+
+void kin_network::rhs_dev(const double* d_u, double* d_du) {
+  launch_rates(host.R, k.p, d_u, x0.p, x1.p, rate.p, stream);
+  launch_segsum(rhs_plan.view(), SEG_COEF_SET, rate.p, d_du, SegExtra{}, stream);
+}
+
+void kin_network::jac_dev(const double* d_u, double* d_vals) {
+  launch_drates(host.R, k.p, d_u, x0.p, x1.p, dr.p, stream);
+  launch_segsum(jac_plan.view(), SEG_COEF_SET, dr.p, d_vals, SegExtra{}, stream);
+}
+
+void kin_network::ensure_batched(int64_t ldb) {
+  if (ldb <= b_cap) return;
+  b_rate.alloc((size_t)host.R * ldb);
+  b_cap = ldb;
+}
+
+#define KIN_TRY(h) try {
+#define KIN_CATCH(h)                                                        \
+  }                                                                         \
+  catch (const KinError& e) {                                               \
+    if (h) (h)->err = e.what(); else g_create_err = e.what();               \
+    return e.code;                                                          \
+  }                                                                         \
+  catch (const std::exception& e) {                                         \
+    if (h) (h)->err = e.what(); else g_create_err = e.what();               \
+    return KIN_ERR_DEVICE;                                                  \
+  }                                                                         \
+  return KIN_OK;
+
+static void require(bool c, int code, const char* msg) {
+  if (!c) throw KinError(code, msg);
+}
+
+extern "C" {
+
+const char* kin_version(void) { return "kinetica-hip 0.1 (gfx950)"; }
+
+int kin_device_count(int* n) {
+  if (!n) return KIN_ERR_INVALID_ARG;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) { *n = 0; return KIN_ERR_DEVICE; }
+  *n = c;
+  return KIN_OK;
+}
+
+int kin_set_device(int device) { return hipSetDevice(device) == hipSuccess ? KIN_OK : KIN_ERR_DEVICE; }
+
+const char* kin_last_error(const kin_network* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr, const int64_t* reac_idx,
+                       const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx,
+                       const int64_t* prod_sto, int index_base, kin_network** out) {
+  kin_network* h = nullptr;
+  if (!out) { g_create_err = "out is null"; return KIN_ERR_INVALID_ARG; }
+  *out = nullptr;
+  try {
+    NetworkHost H = compile_network(n_species, n_reactions, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx,
+                                    prod_sto, index_base);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+      throw KinError(ERR_DEVICE, "no HIP device available (libkinetica_hip has no CPU fallback)");
+    h = new kin_network();
+    h->host = std::move(H);
+    KIN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const NetworkHost& N = h->host;
+    hipStream_t s = h->stream;
+    h->x0.upload(N.x0, s); h->x1.upload(N.x1, s);
+    h->sp_ptr.upload(N.sp_ptr, s); h->sp_rxn.upload(N.sp_rxn, s); h->sp_coef.upload(N.sp_coef, s);
+    // rows of the batched gather, longest first
+    std::vector<int32_t> order(N.N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+      return N.sp_ptr[a + 1] - N.sp_ptr[a] > N.sp_ptr[b + 1] - N.sp_ptr[b];
+    });
+    h->row_order.upload(order, s);
+    h->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);
+    h->jac_plan.upload(build_seg_plan(N.nnz(), N.jc_ptr.data(), nullptr, N.jc_src.data(), nullptr, N.jc_coef.data(), false), s);
+    h->k.alloc(N.R); h->rate.alloc(N.R); h->dr.alloc(2 * N.R + 2);
+    h->u.alloc(N.N); h->du.alloc(N.N); h->jvals.alloc(N.nnz());
+    KIN_HIP(hipStreamSynchronize(s));
+    *out = h;
+  } catch (const KinError& e) {
+    g_create_err = e.what();
+    delete h;
+    return e.code;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    delete h;
+    return KIN_ERR_DEVICE;
+  }
+  return KIN_OK;
+}
+
+int kin_network_destroy(kin_network* h) {
+  delete h;
+  return KIN_OK;
+}
+
+int kin_network_sizes(const kin_network* h, int64_t* n_species, int64_t* n_reactions) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  if (n_species) *n_species = h->host.N;
+  if (n_reactions) *n_reactions = h->host.R;
+  return KIN_OK;
+}
+
+int kin_set_rates(kin_network* h, const double* k) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(k != nullptr, ERR_INVALID_ARG, "k is null");
+  h->k.upload(k, h->host.R, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  h->has_rates = true;
+  KIN_CATCH(h)
+}
+
+int kin_get_rates(kin_network* h, double* k_out) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(k_out != nullptr, ERR_INVALID_ARG, "k_out is null");
+  require(h->has_rates, ERR_STATE, "rates were never set");
+  h->k.download(k_out, h->host.R, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_set_arrhenius(kin_network* h, const double* Ea, const double* A, double k_max, double t_mult) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(Ea && A, ERR_INVALID_ARG, "Ea / A is null");
+  h->Ea.upload(Ea, h->host.R, h->stream);
+  h->A.upload(A, h->host.R, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  h->has_kmax = !std::isnan(k_max);
+  h->k_max = h->has_kmax ? k_max : 1.0;
+  h->t_mult = t_mult;
+  h->has_arrhenius = true;
+  KIN_CATCH(h)
+}
+
+int kin_rates_at(kin_network* h, double T, double* k_out) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(h->has_arrhenius, ERR_STATE, "Arrhenius parameters were never set");
+  launch_arrhenius(h->host.R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, T, h->k.p, h->stream);
+  if (k_out) h->k.download(k_out, h->host.R, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  h->has_rates = true;
+  KIN_CATCH(h)
+}
+
+int kin_arrhenius_eval(const double* Ea, const double* A, int64_t n, double k_max, double t_mult, double T,
+                       double* k_out) {
+  kin_network* h = nullptr;
+  KIN_TRY(h)
+  require(Ea && A && k_out && n >= 0, ERR_INVALID_ARG, "bad arguments");
+  DevBuf<double> dEa, dA, dk;
+  dEa.upload(Ea, n); dA.upload(A, n); dk.alloc(n);
+  const bool has = !std::isnan(k_max);
+  launch_arrhenius(n, dEa.p, dA.p, has, has ? k_max : 1.0, t_mult, T, dk.p, nullptr);
+  dk.download(k_out, n);
+  KIN_HIP(hipStreamSynchronize(nullptr));
+  KIN_CATCH(h)
+}
+
+int kin_rate_table(kin_network* h, const double* T, int64_t n_stops, double* out_table) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(h->has_arrhenius, ERR_STATE, "Arrhenius parameters were never set");
+  require(T != nullptr && n_stops >= 0, ERR_INVALID_ARG, "bad arguments");
+  h->T_stops.upload(T, n_stops, h->stream);
+  h->table.alloc((size_t)n_stops * h->host.R);
+  launch_rate_table(h->host.R, n_stops, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, h->T_stops.p, h->table.p, h->stream);
+  h->table_rows = n_stops;
+  if (out_table) h->table.download(out_table, (size_t)n_stops * h->host.R, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_rhs(kin_network* h, const double* u, double* du) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(u && du, ERR_INVALID_ARG, "u / du is null");
+  require(h->has_rates, ERR_STATE, "rates were never set");
+  h->u.upload(u, h->host.N, h->stream);
+  h->rhs_dev(h->u.p, h->du.p);
+  h->du.download(du, h->host.N, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_rhs_batched_reserve(kin_network* h, int64_t B) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(B > 0, ERR_INVALID_ARG, "B must be positive");
+  h->ensure_batched(ceil_div(B, 8) * 8);
+  KIN_CATCH(h)
+}
+
+int kin_rhs_batched_dev(kin_network* h, int64_t B, int64_t ldb, const double* d_u, const double* d_k, double* d_du,
+                        void* stream) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(B > 0 && ldb >= B && ldb % 8 == 0, ERR_INVALID_ARG, "need B > 0, ldb >= B, ldb % 8 == 0");
+  require(d_u && d_du, ERR_INVALID_ARG, "null device buffer");
+  require(d_k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
+  require(ldb <= h->b_cap, ERR_STATE, "call kin_rhs_batched_reserve(B) first (no allocation inside the sweep)");
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  launch_rates_batched(h->host.R, B, ldb, d_k, h->k.p, d_u, h->x0.p, h->x1.p, h->b_rate.p, s);
+  launch_gather_batched(h->host.N, B, ldb, h->sp_ptr.p, h->sp_rxn.p, h->sp_coef.p, h->row_order.p, h->b_rate.p, d_du, s);
+  KIN_CATCH(h)
+}
+
+int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k, double* du) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(B > 0 && u && du, ERR_INVALID_ARG, "bad arguments");
+  require(k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
+  const int64_t N = h->host.N, R = h->host.R, ldb = ceil_div(B, 8) * 8;
+  hipStream_t s = h->stream;
+  h->ensure_batched(ldb);
+  h->b_u.alloc((size_t)N * ldb); h->b_du.alloc((size_t)N * ldb);
+  h->b_stage.alloc((size_t)B * std::max(N, R));
+  // host layout [b][N] -> device layout [N][ldb]
+  KIN_HIP(hipMemsetAsync(h->b_u.p, 0, (size_t)N * ldb * sizeof(double), s));
+  h->b_stage.upload(u, (size_t)B * N, s);
+  launch_transpose(B, N, h->b_stage.p, N, h->b_u.p, ldb, s);
+  const double* dk = nullptr;
+  if (k) {
+    h->b_k.alloc((size_t)R * ldb);
+    KIN_HIP(hipMemsetAsync(h->b_k.p, 0, (size_t)R * ldb * sizeof(double), s));
+    KIN_HIP(hipStreamSynchronize(s));  // b_stage is reused
+    h->b_stage.upload(k, (size_t)B * R, s);
+    launch_transpose(B, R, h->b_stage.p, R, h->b_k.p, ldb, s);
+    dk = h->b_k.p;
+  }
+  launch_rates_batched(R, B, ldb, dk, h->k.p, h->b_u.p, h->x0.p, h->x1.p, h->b_rate.p, s);
+  launch_gather_batched(N, B, ldb, h->sp_ptr.p, h->sp_rxn.p, h->sp_coef.p, h->row_order.p, h->b_rate.p, h->b_du.p, s);
+  launch_transpose(N, B, h->b_du.p, ldb, h->b_stage.p, N, s);
+  h->b_stage.download(du, (size_t)B * N, s);
+  KIN_HIP(hipStreamSynchronize(s));
+  KIN_CATCH(h)
+}
+
+int kin_jac_nnz(kin_network* h, int64_t* nnz) {
+  if (!h || !nnz) return KIN_ERR_INVALID_ARG;
+  *nnz = h->host.nnz();
+  return KIN_OK;
+}
+
+int kin_jac_pattern(kin_network* h, int64_t* rowptr, int64_t* colidx, int index_base) {
+  if (!h || !rowptr || !colidx) return KIN_ERR_INVALID_ARG;
+  const NetworkHost& N = h->host;
+  for (int64_t i = 0; i <= N.N; i++) rowptr[i] = N.j_ptr[i] + index_base;
+  for (int64_t e = 0; e < N.nnz(); e++) colidx[e] = N.j_col[e] + index_base;
+  return KIN_OK;
+}
+
+int kin_jac_values(kin_network* h, const double* u, double* vals) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(u && vals, ERR_INVALID_ARG, "u / vals is null");
+  require(h->has_rates, ERR_STATE, "rates were never set");
+  h->u.upload(u, h->host.N, h->stream);
+  h->jac_dev(h->u.p, h->jvals.p);
+  h->jvals.download(vals, h->host.nnz(), h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_solve(kin_network* h, const kin_params* params, const double* u0, const double* tstops,
+              const double* T_stops, const double* k_table, int64_t n_stops, int64_t* n_saved, int32_t* retcode,
+              kin_stats* stats) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(params && u0, ERR_INVALID_ARG, "params / u0 is null");
+  int rc = solve_entry(h, *params, u0, tstops, T_stops, k_table, n_stops, stats);
+  if (n_saved) *n_saved = h->n_saved;
+  if (retcode) *retcode = rc;
+  if (rc != KIN_RETCODE_SUCCESS) throw KinError(ERR_SOLVE_FAILED, "ODE solution failed.");
+  KIN_CATCH(h)
+}
+
+int kin_solution_size(const kin_network* h, int64_t* n_saved, int64_t* n_species) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  if (n_saved) *n_saved = h->n_saved;
+  if (n_species) *n_species = h->host.N;
+  return KIN_OK;
+}
+
+int kin_solution_copy(const kin_network* hc, double* out_t, double* out_u) {
+  kin_network* h = const_cast<kin_network*>(hc);
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(out_t && out_u, ERR_INVALID_ARG, "null output buffer");
+  std::copy(h->sol_t.begin(), h->sol_t.begin() + h->n_saved, out_t);
+  h->d_sol_u.download(out_u, (size_t)h->n_saved * h->host.N, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_solution_max(const kin_network* hc, double* out_umax) {
+  kin_network* h = const_cast<kin_network*>(hc);
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(out_umax != nullptr, ERR_INVALID_ARG, "null output buffer");
+  require(h->n_saved > 0, ERR_STATE, "no solution stored");
+  solution_max(h, out_umax);
+  KIN_CATCH(h)
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// The object behind the opaque kin_network handle of include/kinetica_hip.h.
+#pragma once
+#include <memory>
+#include <string>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "network.hpp"
+
+namespace kin { struct Solver; }
+
+struct kin_network {
+  kin::NetworkHost host;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // reaction tables
+  kin::DevBuf<int32_t> x0, x1, sp_ptr, sp_rxn, row_order;
+  kin::DevBuf<float> sp_coef;
+  kin::SegPlanDev rhs_plan, jac_plan;
+
+  // rate constants / calculator
+  kin::DevBuf<double> k, Ea, A, table, T_stops;
+  bool has_rates = false, has_arrhenius = false, has_kmax = false;
+  double k_max = 0.0, t_mult = 1.0;
+  int64_t table_rows = 0;
+
+  // single-state work vectors
+  kin::DevBuf<double> u, du, rate, dr, jvals;
+
+  // batched sweep workspace
+  kin::DevBuf<double> b_rate, b_u, b_k, b_du, b_stage;
+  int64_t b_cap = 0;
+
+  // solver + stored solution (solver.cpp)
+  std::unique_ptr<kin::Solver> solver;
+  std::vector<double> sol_t, sol_u;
+  kin::DevBuf<double> d_sol_u;   // saved states on the device, [n_saved][N]
+  int64_t n_saved = 0;
+
+  kin_network();
+  ~kin_network();
+  void rhs_dev(const double* d_u, double* d_du);        // du = f(u) with current k
+  void jac_dev(const double* d_u, double* d_vals);      // CSR values with current k
+  void ensure_batched(int64_t ldb);
+};

@@ -1,0 +1,57 @@
+// Device-side tables and kernel launchers of libkinetica_hip (gfx950 only).
+#pragma once
+#include "common.hpp"
+#include "network.hpp"
+
+namespace kin {
+
+// raw-pointer view of a SegPlan, passed to kernels by value
+struct SegPlanView {
+  const int32_t* grp_off; const int32_t* grp_dst;
+  const int32_t* ell_a; const int32_t* ell_b; const float* ell_c;
+  const int32_t* seg_beg; const int32_t* seg_end; const int32_t* seg_dst;
+  const int32_t* long_a; const int32_t* long_b; const float* long_c;
+  const int32_t* fix_dst; const int32_t* fix_ptr;
+  double* partials;
+  int32_t G, S, F;
+};
+
+struct SegPlanDev {
+  DevBuf<int32_t> grp_off, grp_dst, ell_a, ell_b, seg_beg, seg_end, seg_dst, long_a, long_b, fix_dst, fix_ptr;
+  DevBuf<float> ell_c, long_c;
+  DevBuf<double> partials;
+  int32_t G = 0, S = 0, F = 0;
+  void upload(const SegPlanHost& h, hipStream_t s);
+  SegPlanView view() const;
+};
+
+// what an entry contributes and how the row sum is combined with the output
+enum SegOp : int {
+  SEG_COEF_SET = 0,   // out[dst]  = sum c * src[a]
+  SEG_PROD_SUB = 1,   // out[dst] -= sum src[a] * src[b]                 (Schur update of the sparse LU)
+  SEG_COEF_BDF = 2,   // out[dst]  = cscal * (sum c * src[a]) - psi[dst] - d[dst]   (Newton residual of a BDF step)
+};
+struct SegExtra {  // extra operands of SEG_COEF_BDF
+  const double* psi = nullptr; const double* d = nullptr; const double* cscal = nullptr;
+};
+
+void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* out, const SegExtra& ex, hipStream_t s);
+
+// per-reaction rate and operand derivatives (single state)
+void launch_rates(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s);
+void launch_drates(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* dr, hipStream_t s);
+
+// Arrhenius (k_max < 0 or NaN handled by has_kmax flag)
+void launch_arrhenius(int64_t n, const double* Ea, const double* A, int has_kmax, double k_max, double t_mult, double T, double* k, hipStream_t s);
+void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const double* A, int has_kmax, double k_max,
+                       double t_mult, const double* T, double* table, hipStream_t s);
+
+// batched sweep, state-contiguous layouts (see kin_rhs_batched_dev)
+void launch_rates_batched(int64_t R, int64_t B, int64_t ldb, const double* k_rb, const double* k_r, const double* u,
+                          const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s);
+void launch_gather_batched(int64_t N, int64_t B, int64_t ldb, const int32_t* sp_ptr, const int32_t* sp_rxn,
+                           const float* sp_coef, const int32_t* row_order, const double* rate, double* du, hipStream_t s);
+// out[c][r] = in[r][c] for a rows x cols row-major matrix (ld = leading dims)
+void launch_transpose(int64_t rows, int64_t cols, const double* in, int64_t ld_in, double* out, int64_t ld_out, hipStream_t s);
+
+}  // namespace kin

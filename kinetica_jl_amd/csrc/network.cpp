@@ -1,0 +1,171 @@
+#include "network.hpp"
+
+#include <algorithm>
+#include <map>
+#include <numeric>
+#include <string>
+
+namespace kin {
+
+SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
+                           const int32_t* b, const float* c, bool skip_empty) {
+  SegPlanHost P;
+  std::vector<int32_t> shorts, longs;
+  for (int64_t i = 0; i < n_rows; i++) {
+    int32_t len = ptr[i + 1] - ptr[i];
+    if (len == 0 && skip_empty) continue;
+    (len <= SegPlanHost::SHORT_MAX ? shorts : longs).push_back((int32_t)i);
+  }
+  // ELL groups: sort short rows by length so each 64-row group is padded to a near-uniform width.
+  std::stable_sort(shorts.begin(), shorts.end(),
+                   [&](int32_t x, int32_t y) { return ptr[x + 1] - ptr[x] < ptr[y + 1] - ptr[y]; });
+  P.grp_off.push_back(0);
+  for (size_t g0 = 0; g0 < shorts.size(); g0 += 64) {
+    size_t g1 = std::min(shorts.size(), g0 + 64);
+    int32_t width = 0;
+    for (size_t q = g0; q < g1; q++) width = std::max(width, ptr[shorts[q] + 1] - ptr[shorts[q]]);
+    size_t base = P.ell_a.size();
+    P.ell_a.resize(base + (size_t)width * 64, 0);
+    if (b) P.ell_b.resize(base + (size_t)width * 64, 0);
+    P.ell_c.resize(base + (size_t)width * 64, 0.0f);
+    for (int lane = 0; lane < 64; lane++) {
+      size_t q = g0 + lane;
+      if (q >= g1) { P.grp_dst.push_back(-1); continue; }
+      int32_t row = shorts[q];
+      P.grp_dst.push_back(dst ? dst[row] : row);
+      for (int32_t e = ptr[row], col = 0; e < ptr[row + 1]; e++, col++) {
+        size_t pos = base + (size_t)col * 64 + lane;
+        P.ell_a[pos] = a[e];
+        if (b) P.ell_b[pos] = b[e];
+        P.ell_c[pos] = c ? c[e] : 1.0f;
+      }
+    }
+    P.grp_off.push_back(P.grp_off.back() + width);
+  }
+  // long rows -> segments
+  P.fix_ptr.push_back(0);
+  for (int32_t row : longs) {
+    int32_t len = ptr[row + 1] - ptr[row];
+    int32_t nseg = (int32_t)ceil_div(len, SegPlanHost::SEG_LEN);
+    int32_t out = dst ? dst[row] : row;
+    for (int32_t s = 0; s < nseg; s++) {
+      int32_t e0 = ptr[row] + s * SegPlanHost::SEG_LEN;
+      int32_t e1 = std::min(ptr[row + 1], e0 + SegPlanHost::SEG_LEN);
+      P.seg_beg.push_back((int32_t)P.long_a.size());
+      for (int32_t e = e0; e < e1; e++) {
+        P.long_a.push_back(a[e]);
+        if (b) P.long_b.push_back(b[e]);
+        P.long_c.push_back(c ? c[e] : 1.0f);
+      }
+      P.seg_end.push_back((int32_t)P.long_a.size());
+      P.seg_dst.push_back(nseg == 1 ? out : -(P.n_partials++) - 1);
+    }
+    if (nseg > 1) {
+      P.fix_dst.push_back(out);
+      P.fix_ptr.push_back(P.n_partials);
+    }
+  }
+  return P;
+}
+
+static void fail(int code, const std::string& m) { throw KinError(code, m); }
+
+NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const int64_t* reac_idx,
+                            const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx,
+                            const int64_t* prod_sto, int index_base) {
+  if (N <= 0 || R < 0) fail(ERR_INVALID_ARG, "n_species must be > 0 and n_reactions >= 0");
+  if (N > (1ll << 30) || R > (1ll << 28)) fail(ERR_UNSUPPORTED, "network too large for int32 device indices");
+  if (!reac_ptr || !prod_ptr || (R > 0 && (!reac_idx || !reac_sto || !prod_idx || !prod_sto)))
+    fail(ERR_INVALID_ARG, "null topology array");
+  if (index_base != 0 && index_base != 1) fail(ERR_INVALID_ARG, "index_base must be 0 or 1");
+  NetworkHost H;
+  H.N = N; H.R = R;
+  H.x0.assign(R, -1); H.x1.assign(R, -1);
+  H.slot_sp.assign(4 * R, -1); H.slot_co.assign(R, 0);
+
+  struct Ent { int32_t rxn; float coef; };
+  std::vector<std::vector<Ent>> by_species(N);
+  // Jacobian contributions keyed by (row, col)
+  struct JC { int32_t row, col, src; float coef; };
+  std::vector<JC> jcs;
+  jcs.reserve((size_t)R * 8);
+
+  for (int64_t r = 0; r < R; r++) {
+    int64_t a0 = reac_ptr[r], a1 = reac_ptr[r + 1], b0 = prod_ptr[r], b1 = prod_ptr[r + 1];
+    if (a1 < a0 || b1 < b0) fail(ERR_INVALID_ARG, "ptr arrays must be non-decreasing");
+    // rate operands, expanded by stoichiometry; the reference enforces molecularity <= 2
+    // per side (src/exploration/network.jl:275-279)
+    int32_t ops[2]; int nops = 0;
+    std::map<int32_t, int> net;  // species -> net stoichiometric coefficient
+    for (int64_t p = a0; p < a1; p++) {
+      int64_t s = reac_idx[p] - index_base, st = reac_sto[p];
+      if (s < 0 || s >= N) fail(ERR_INVALID_ARG, "reactant species index out of range in reaction " + std::to_string(r));
+      if (st < 1) fail(ERR_INVALID_ARG, "reactant stoichiometry must be >= 1");
+      for (int64_t q = 0; q < st; q++) {
+        if (nops >= 2) fail(ERR_UNSUPPORTED, "reaction " + std::to_string(r) + ": more than 2 reactant molecules (max_molecularity = 2)");
+        ops[nops++] = (int32_t)s;
+      }
+      net[(int32_t)s] -= (int)st;
+    }
+    if (nops == 0) fail(ERR_UNSUPPORTED, "reaction " + std::to_string(r) + " has no reactants");
+    for (int64_t p = b0; p < b1; p++) {
+      int64_t s = prod_idx[p] - index_base, st = prod_sto[p];
+      if (s < 0 || s >= N) fail(ERR_INVALID_ARG, "product species index out of range in reaction " + std::to_string(r));
+      if (st < 1 || st > 100) fail(ERR_INVALID_ARG, "product stoichiometry out of range");
+      net[(int32_t)s] += (int)st;
+    }
+    H.x0[r] = ops[0];
+    H.x1[r] = nops == 2 ? ops[1] : -1;
+    // update slots
+    int ns = 0; uint32_t packed = 0;
+    for (auto& kv : net) {
+      if (kv.second == 0) continue;  // e.g. an inert collider on both sides: multiplies the rate only
+      if (ns >= 4) fail(ERR_UNSUPPORTED, "reaction " + std::to_string(r) + ": more than 4 distinct species");
+      if (kv.second < -127 || kv.second > 127) fail(ERR_UNSUPPORTED, "net stoichiometry out of int8 range");
+      H.slot_sp[4 * r + ns] = kv.first;
+      packed |= (uint32_t)(uint8_t)(int8_t)kv.second << (8 * ns);
+      by_species[kv.first].push_back({(int32_t)r, (float)kv.second});
+      ns++;
+    }
+    H.slot_co[r] = (int32_t)packed;
+    // Jacobian columns = distinct rate operands; drate index src = 2*r + w
+    int ncols = (nops == 2 && ops[0] != ops[1]) ? 2 : 1;
+    for (int w = 0; w < ncols; w++)
+      for (auto& kv : net)
+        if (kv.second != 0) jcs.push_back({kv.first, ops[w], (int32_t)(2 * r + w), (float)kv.second});
+  }
+
+  // species-major CSR
+  H.sp_ptr.assign(N + 1, 0);
+  for (int64_t i = 0; i < N; i++) H.sp_ptr[i + 1] = H.sp_ptr[i] + (int32_t)by_species[i].size();
+  H.sp_rxn.reserve(H.sp_ptr[N]); H.sp_coef.reserve(H.sp_ptr[N]);
+  for (int64_t i = 0; i < N; i++)
+    for (auto& e : by_species[i]) { H.sp_rxn.push_back(e.rxn); H.sp_coef.push_back(e.coef); }
+
+  // Jacobian pattern: sort contributions by (row, col, src); add the diagonal
+  for (int64_t i = 0; i < N; i++) jcs.push_back({(int32_t)i, (int32_t)i, -1, 0.0f});
+  std::sort(jcs.begin(), jcs.end(), [](const JC& p, const JC& q) {
+    if (p.row != q.row) return p.row < q.row;
+    if (p.col != q.col) return p.col < q.col;
+    return p.src < q.src;
+  });
+  H.j_ptr.assign(N + 1, 0);
+  H.j_diag.assign(N, -1);
+  H.jc_ptr.push_back(0);
+  for (size_t q = 0; q < jcs.size();) {
+    size_t q2 = q;
+    while (q2 < jcs.size() && jcs[q2].row == jcs[q].row && jcs[q2].col == jcs[q].col) q2++;
+    int32_t e = (int32_t)H.j_col.size();
+    H.j_col.push_back(jcs[q].col);
+    H.j_ptr[jcs[q].row + 1]++;
+    if (jcs[q].row == jcs[q].col) H.j_diag[jcs[q].row] = e;
+    for (size_t t = q; t < q2; t++)
+      if (jcs[t].src >= 0) { H.jc_src.push_back(jcs[t].src); H.jc_coef.push_back(jcs[t].coef); }
+    H.jc_ptr.push_back((int32_t)H.jc_src.size());
+    q = q2;
+  }
+  for (int64_t i = 0; i < N; i++) H.j_ptr[i + 1] += H.j_ptr[i];
+  return H;
+}
+
+}  // namespace kin

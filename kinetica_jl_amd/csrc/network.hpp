@@ -1,0 +1,70 @@
+// Host-side "network compiler": turns RxData's ragged stoichiometry (reference
+// src/exploration/network.jl:193-203) into the fixed-width, data-driven tables the device
+// kernels stream. Nothing here is generated per network beyond index tables - there is no
+// symbolic build (the reference's Catalyst -> ModelingToolkit codegen, methods.jl:140-158,
+// is replaced by table lookups).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "common.hpp"
+
+namespace kin {
+
+// Deterministic load-balanced gather-sum plan: out[dst(row)] = sum over the row's entries.
+// Short rows are packed 64 to a wavefront in a transposed (ELL) layout so that lane reads are
+// coalesced; long rows are cut into segments of <= SEG_LEN entries, one wavefront each; rows
+// with several segments are finished by a fix-up pass that adds the partial sums in a fixed
+// order (bitwise reproducible, no atomics).
+struct SegPlanHost {
+  static constexpr int SHORT_MAX = 32;   // rows up to this many entries go to the ELL groups
+  static constexpr int SEG_LEN = 1024;   // entries per long-row segment (16 per lane)
+  // ELL groups
+  std::vector<int32_t> grp_off;  // G+1: first ELL column of each group
+  std::vector<int32_t> grp_dst;  // G*64: output index per lane (-1 = idle lane)
+  std::vector<int32_t> ell_a, ell_b;
+  std::vector<float> ell_c;      // 0.0f marks padding
+  // long-row segments (payload copied contiguously)
+  std::vector<int32_t> seg_beg, seg_end;  // S
+  std::vector<int32_t> seg_dst;           // S: >=0 output index (single-segment row), <0: -(partial slot)-1
+  std::vector<int32_t> long_a, long_b;
+  std::vector<float> long_c;
+  // fix-up for multi-segment rows
+  std::vector<int32_t> fix_dst;           // F output index
+  std::vector<int32_t> fix_ptr;           // F+1 ranges of partial slots
+  int32_t n_partials = 0;
+  int32_t n_groups() const { return (int32_t)grp_off.size() - 1; }
+  int32_t n_segs() const { return (int32_t)seg_beg.size(); }
+  int32_t n_fix() const { return (int32_t)fix_dst.size(); }
+};
+
+// Build a plan from CSR rows. `dst[row]` is the output index of a row; rows with no entries
+// are still scheduled (they produce 0) unless skip_empty. `b` and `c` may be null.
+SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
+                           const int32_t* b, const float* c, bool skip_empty);
+
+struct NetworkHost {
+  int64_t N = 0, R = 0;
+  // per reaction: rate operands, rate = k * u[x0] * (x1 >= 0 ? u[x1] : 1)   (2A: x0 == x1)
+  std::vector<int32_t> x0, x1;
+  // per reaction: up to 4 update slots (distinct species with non-zero net stoichiometry)
+  std::vector<int32_t> slot_sp;   // 4*R, species id or -1
+  std::vector<int32_t> slot_co;   // R, four signed bytes packed
+  // species-major CSR: du[i] = sum_e sp_coef[e] * rate[sp_rxn[e]]
+  std::vector<int32_t> sp_ptr, sp_rxn;
+  std::vector<float> sp_coef;
+  // Jacobian: CSR pattern (sorted columns, diagonal present) and, per stored entry, the list of
+  // contributions coef * drate[src], src = 2*r + w (w-th operand derivative of reaction r)
+  std::vector<int32_t> j_ptr, j_col, j_diag;  // j_diag[i] = position of (i,i)
+  std::vector<int32_t> jc_ptr, jc_src;
+  std::vector<float> jc_coef;
+  int64_t nnz() const { return (int64_t)j_col.size(); }
+};
+
+// Validates and compiles the flat ragged arrays (see kin_network_create in kinetica_hip.h).
+// Throws KinError(ERR_INVALID_ARG | ERR_UNSUPPORTED).
+NetworkHost compile_network(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr,
+                            const int64_t* reac_idx, const int64_t* reac_sto, const int64_t* prod_ptr,
+                            const int64_t* prod_idx, const int64_t* prod_sto, int index_base);
+
+}  // namespace kin

@@ -1,0 +1,15 @@
+// BDF integrator + chunk/tstop driver behind kin_solve (solver.cpp, lu.cpp, solver_kernels.hip).
+#pragma once
+#include "../../include/kinetica_hip.h"
+#include "handle.hpp"
+
+namespace kin {
+
+// Runs the whole solve (chunk loop, discrete rate updates, retry loop); stores the solution in
+// the handle; returns the final KIN_RETCODE_*.
+int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops,
+                const double* T_stops, const double* k_table, int64_t n_stops, kin_stats* stats);
+// max over saved times per species, reduced on the device
+void solution_max(kin_network* h, double* out_umax);
+
+}  // namespace kin
