@@ -10,30 +10,33 @@ namespace kin {
 // plan upload
 // ------------------------------------------------------------------------------------------
 void SegPlanDev::upload(const SegPlanHost& h, hipStream_t s) {
-  grp_off.upload(h.grp_off, s); grp_dst.upload(h.grp_dst, s);
+  grp_off.upload(h.grp_off, s); grp_dst.upload(h.grp_dst, s); grp_aux.upload(h.grp_aux, s);
   ell_a.upload(h.ell_a, s); ell_b.upload(h.ell_b, s); ell_c.upload(h.ell_c, s);
-  seg_beg.upload(h.seg_beg, s); seg_end.upload(h.seg_end, s); seg_dst.upload(h.seg_dst, s);
+  seg_beg.upload(h.seg_beg, s); seg_end.upload(h.seg_end, s); seg_dst.upload(h.seg_dst, s); seg_aux.upload(h.seg_aux, s);
   long_a.upload(h.long_a, s); long_b.upload(h.long_b, s); long_c.upload(h.long_c, s);
-  fix_dst.upload(h.fix_dst, s); fix_ptr.upload(h.fix_ptr, s);
+  fix_dst.upload(h.fix_dst, s); fix_aux.upload(h.fix_aux, s); fix_ptr.upload(h.fix_ptr, s);
   partials.alloc((size_t)h.n_partials + 1);
   G = h.n_groups(); S = h.n_segs(); F = h.n_fix();
   KIN_HIP(hipStreamSynchronize(s));  // host vectors may die after this call
 }
 
 SegPlanView SegPlanDev::view() const {
-  return SegPlanView{grp_off.p, grp_dst.p, ell_a.p, ell_b.p, ell_c.p, seg_beg.p, seg_end.p, seg_dst.p,
-                     long_a.p, long_b.p, long_c.p, fix_dst.p, fix_ptr.p, partials.p, G, S, F};
+  return SegPlanView{grp_off.p, grp_dst.p, grp_aux.p, ell_a.p, ell_b.p, ell_c.p, seg_beg.p, seg_end.p, seg_dst.p, seg_aux.p,
+                     long_a.p, long_b.p, long_c.p, fix_dst.p, fix_aux.p, fix_ptr.p, partials.p, G, S, F};
 }
 
 // ------------------------------------------------------------------------------------------
 // deterministic segmented gather-sum
 // ------------------------------------------------------------------------------------------
 template <int OP>
-__device__ __forceinline__ void seg_store(double* out, int32_t dst, double acc, const SegExtra& ex) {
+__device__ __forceinline__ void seg_store(double* out, const double* src, int32_t dst, int32_t aux, double acc,
+                                          const SegExtra& ex) {
   if (OP == SEG_COEF_SET) out[dst] = acc;
   else if (OP == SEG_PROD_SUB) out[dst] -= acc;
-  else out[dst] = (*ex.cscal) * acc - ex.psi[dst] - ex.d[dst];
+  else if (OP == SEG_PROD_SUB_DIV) out[dst] = (out[dst] - acc) / src[aux];
+  else out[dst] = ex.cscal * acc - ex.psi[aux] - ex.d[aux];
 }
+template <int OP> struct seg_is_prod { static constexpr bool v = (OP == SEG_PROD_SUB || OP == SEG_PROD_SUB_DIV); };
 
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed butterfly order -> bitwise reproducible
@@ -43,8 +46,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double* __restrict__ src,
-                                                     double* out, SegExtra ex) {
+__global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
+  if (ex.skip && *ex.skip) return;
   const int lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (task < p.G) {
@@ -55,35 +58,36 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
       const size_t idx = (size_t)col * 64 + lane;
       const float c = p.ell_c[idx];
       if (c != 0.0f) {
-        if (OP == SEG_PROD_SUB) acc += src[p.ell_a[idx]] * src[p.ell_b[idx]];
+        if (seg_is_prod<OP>::v) acc += src[p.ell_a[idx]] * src[p.ell_b[idx]];
         else acc += (double)c * src[p.ell_a[idx]];
       }
     }
-    if (dst >= 0) seg_store<OP>(out, dst, acc, ex);
+    if (dst >= 0) seg_store<OP>(out, src, dst, p.grp_aux[task * 64 + lane], acc, ex);
   } else if (task < p.G + p.S) {
     const int sidx = task - p.G;
     const int32_t e0 = p.seg_beg[sidx], e1 = p.seg_end[sidx];
     double acc = 0.0;
     for (int32_t e = e0 + lane; e < e1; e += 64) {
-      if (OP == SEG_PROD_SUB) acc += src[p.long_a[e]] * src[p.long_b[e]];
+      if (seg_is_prod<OP>::v) acc += src[p.long_a[e]] * src[p.long_b[e]];
       else acc += (double)p.long_c[e] * src[p.long_a[e]];
     }
     acc = wave_sum(acc);
     if (lane == 0) {
       const int32_t dst = p.seg_dst[sidx];
-      if (dst >= 0) seg_store<OP>(out, dst, acc, ex);
+      if (dst >= 0) seg_store<OP>(out, src, dst, p.seg_aux[sidx], acc, ex);
       else p.partials[-dst - 1] = acc;
     }
   }
 }
 
 template <int OP>
-__global__ void segsum_fix_kernel(SegPlanView p, double* out, SegExtra ex) {
+__global__ void segsum_fix_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
+  if (ex.skip && *ex.skip) return;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= p.F) return;
   double acc = 0.0;
   for (int32_t q = p.fix_ptr[f]; q < p.fix_ptr[f + 1]; q++) acc += p.partials[q];
-  seg_store<OP>(out, p.fix_dst[f], acc, ex);
+  seg_store<OP>(out, src, p.fix_dst[f], p.fix_aux[f], acc, ex);
 }
 
 void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* out, const SegExtra& ex, hipStream_t s) {
@@ -94,14 +98,16 @@ void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* ou
       case SEG_COEF_SET: hipLaunchKernelGGL(segsum_kernel<SEG_COEF_SET>, grid, block, 0, s, p, src, out, ex); break;
       case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, src, out, ex); break;
       case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_SUB_DIV: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SUB_DIV>, grid, block, 0, s, p, src, out, ex); break;
     }
   }
   if (p.F > 0) {
     dim3 grid((unsigned)ceil_div(p.F, 64)), block(64);
     switch (op) {
-      case SEG_COEF_SET: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_SET>, grid, block, 0, s, p, out, ex); break;
-      case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, out, ex); break;
-      case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, out, ex); break;
+      case SEG_COEF_SET: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_SET>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_SUB_DIV: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB_DIV>, grid, block, 0, s, p, src, out, ex); break;
     }
   }
   KIN_HIP(hipGetLastError());

@@ -7,17 +7,17 @@ namespace kin {
 
 // raw-pointer view of a SegPlan, passed to kernels by value
 struct SegPlanView {
-  const int32_t* grp_off; const int32_t* grp_dst;
+  const int32_t* grp_off; const int32_t* grp_dst; const int32_t* grp_aux;
   const int32_t* ell_a; const int32_t* ell_b; const float* ell_c;
-  const int32_t* seg_beg; const int32_t* seg_end; const int32_t* seg_dst;
+  const int32_t* seg_beg; const int32_t* seg_end; const int32_t* seg_dst; const int32_t* seg_aux;
   const int32_t* long_a; const int32_t* long_b; const float* long_c;
-  const int32_t* fix_dst; const int32_t* fix_ptr;
+  const int32_t* fix_dst; const int32_t* fix_aux; const int32_t* fix_ptr;
   double* partials;
   int32_t G, S, F;
 };
 
 struct SegPlanDev {
-  DevBuf<int32_t> grp_off, grp_dst, ell_a, ell_b, seg_beg, seg_end, seg_dst, long_a, long_b, fix_dst, fix_ptr;
+  DevBuf<int32_t> grp_off, grp_dst, grp_aux, ell_a, ell_b, seg_beg, seg_end, seg_dst, seg_aux, long_a, long_b, fix_dst, fix_aux, fix_ptr;
   DevBuf<float> ell_c, long_c;
   DevBuf<double> partials;
   int32_t G = 0, S = 0, F = 0;
@@ -29,10 +29,13 @@ struct SegPlanDev {
 enum SegOp : int {
   SEG_COEF_SET = 0,   // out[dst]  = sum c * src[a]
   SEG_PROD_SUB = 1,   // out[dst] -= sum src[a] * src[b]                 (Schur update of the sparse LU)
-  SEG_COEF_BDF = 2,   // out[dst]  = cscal * (sum c * src[a]) - psi[dst] - d[dst]   (Newton residual of a BDF step)
+  SEG_COEF_BDF = 2,   // out[dst]  = cscal * (sum c * src[a]) - psi[aux] - d[aux]   (Newton residual of a BDF step;
+                      //            aux = species index, dst = position in the permuted solve vector)
+  SEG_PROD_SUB_DIV = 3,  // out[dst] = (out[dst] - sum src[a] * src[b]) / src[aux]        (backward substitution)
 };
 struct SegExtra {  // extra operands of SEG_COEF_BDF
-  const double* psi = nullptr; const double* d = nullptr; const double* cscal = nullptr;
+  const double* psi = nullptr; const double* d = nullptr; double cscal = 0.0;
+  const int* skip = nullptr;   // optional device flag: the kernel returns immediately when *skip != 0
 };
 
 void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* out, const SegExtra& ex, hipStream_t s);

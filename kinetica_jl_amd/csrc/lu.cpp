@@ -1,0 +1,247 @@
+#include "lu.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace kin {
+
+namespace {
+
+// position of `target` in the sorted neighbour list of pivot p
+inline int32_t find_entry(const std::vector<int32_t>& ent_ptr, const std::vector<int32_t>& nbr, int32_t p, int32_t target) {
+  auto b = nbr.begin() + ent_ptr[p], e = nbr.begin() + ent_ptr[p + 1];
+  auto it = std::lower_bound(b, e, target);
+  if (it == e || *it != target) throw KinError(ERR_DEVICE, "internal: missing fill entry in symbolic LU");
+  return (int32_t)(it - nbr.begin());
+}
+
+struct Triple { int64_t t; int32_t a, b; };
+
+SegPlanHost plan_from_triples(std::vector<Triple>& tr, bool with_aux_diag, int64_t aux_base, int64_t dst_base) {
+  (void)with_aux_diag; (void)aux_base; (void)dst_base;
+  std::sort(tr.begin(), tr.end(), [](const Triple& x, const Triple& y) {
+    if (x.t != y.t) return x.t < y.t;
+    if (x.a != y.a) return x.a < y.a;
+    return x.b < y.b;
+  });
+  std::vector<int32_t> ptr{0}, dst, a, b;
+  a.reserve(tr.size()); b.reserve(tr.size());
+  for (size_t q = 0; q < tr.size();) {
+    size_t q2 = q;
+    while (q2 < tr.size() && tr[q2].t == tr[q].t) { a.push_back(tr[q2].a); b.push_back(tr[q2].b); q2++; }
+    dst.push_back((int32_t)tr[q].t);
+    ptr.push_back((int32_t)a.size());
+    q = q2;
+  }
+  return build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, true);
+}
+
+}  // namespace
+
+void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std::vector<int32_t>& j_col,
+                       const LUOptions& opt, hipStream_t s) {
+  n = n_;
+  nnzJ = (int64_t)j_col.size();
+  // ---- symmetric adjacency of J + J^T without self loops
+  std::vector<std::vector<int32_t>> adj(n);
+  for (int32_t i = 0; i < n; i++)
+    for (int32_t e = j_ptr[i]; e < j_ptr[i + 1]; e++) {
+      int32_t j = j_col[e];
+      if (j != i) { adj[i].push_back(j); adj[j].push_back(i); }
+    }
+  std::vector<char> hub(n, 0);
+  for (int32_t i = 0; i < n; i++) {
+    auto& a = adj[i];
+    std::sort(a.begin(), a.end());
+    a.erase(std::unique(a.begin(), a.end()), a.end());
+    if ((int)a.size() >= opt.hub_degree) hub[i] = 1;
+  }
+  for (int32_t i = 0; i < n; i++)
+    if (hub[i]) std::vector<int32_t>().swap(adj[i]);  // hub lists are never needed
+
+  // ---- rounds of independent-set elimination
+  std::vector<char> alive(n, 1);
+  std::vector<int32_t> mark(n, -1), order, tmp;
+  std::vector<std::vector<int32_t>> nb_at_elim(n);
+  round_ptr.assign(1, 0);
+  auto tail_deg = [&](int32_t i) { int d = 0; for (int32_t j : adj[i]) if (!hub[j]) d++; return d; };
+  for (int r = 0; r < opt.max_rounds; r++) {
+    std::vector<std::pair<int64_t, int32_t>> keyed;
+    for (int32_t i = 0; i < n; i++)
+      if (!hub[i] && alive[i]) {
+        int td = tail_deg(i);
+        if (td <= opt.max_tail_degree && (int)adj[i].size() <= opt.max_degree)
+          keyed.push_back({(int64_t)td * 1000000 + (int64_t)adj[i].size(), i});
+      }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<int32_t> I;
+    for (auto& kv : keyed) {
+      int32_t i = kv.second;
+      bool ok = true;
+      for (int32_t j : adj[i]) if (!hub[j] && mark[j] == r) { ok = false; break; }
+      if (ok) { mark[i] = r; I.push_back(i); }
+    }
+    // stop when a round no longer pays for its two dependent kernel launches
+    if (I.empty() || (r > 0 && (int)I.size() < 8)) { for (int32_t i : I) mark[i] = -1; break; }
+    for (int32_t i : I) {
+      auto& nb = adj[i];
+      for (int32_t t : nb) {
+        if (hub[t]) continue;
+        tmp.clear();
+        auto& a = adj[t];
+        size_t x = 0, y = 0;
+        while (x < a.size() || y < nb.size()) {
+          int32_t v;
+          if (y >= nb.size() || (x < a.size() && a[x] < nb[y])) v = a[x++];
+          else if (x >= a.size() || nb[y] < a[x]) v = nb[y++];
+          else { v = a[x]; x++; y++; }
+          if (v != i && v != t) tmp.push_back(v);
+        }
+        a.swap(tmp);
+      }
+      alive[i] = 0;
+      nb_at_elim[i] = nb;
+      order.push_back(i);
+    }
+    round_ptr.push_back((int32_t)order.size());
+  }
+  nrounds = (int32_t)round_ptr.size() - 1;
+  ns = (int32_t)order.size();
+  m = n - ns;
+  mpad = (int32_t)(ceil_div(std::max(m, 1), 64) * 64);
+  if (m == 0) mpad = 0;
+  perm = order;
+  for (int32_t i = 0; i < n; i++) if (alive[i]) perm.push_back(i);
+  iperm.assign(n, -1);
+  for (int32_t q = 0; q < n; q++) iperm[perm[q]] = q;
+
+  // ---- sparse structure in new indices
+  ent_ptr.assign(ns + 1, 0);
+  std::vector<int32_t> nbr;
+  std::vector<int32_t> ent_piv;
+  for (int32_t p = 0; p < ns; p++) {
+    std::vector<int32_t> v;
+    for (int32_t o : nb_at_elim[perm[p]]) v.push_back(iperm[o]);
+    std::sort(v.begin(), v.end());
+    for (int32_t q : v) {
+      if (q <= p) throw KinError(ERR_DEVICE, "internal: elimination order violated");
+      nbr.push_back(q); ent_piv.push_back(p);
+    }
+    ent_ptr[p + 1] = (int32_t)nbr.size();
+  }
+  nnzU = (int64_t)nbr.size();
+  auto align = [](int64_t x) { return (x + 7) / 8 * 8; };
+  off_diag = 0;
+  off_U = align(ns);
+  off_L = align(off_U + nnzU);
+  off_S = align(off_L + nnzU);
+  off_y = align(off_S + (int64_t)mpad * mpad);
+  off_x = align(off_y + n);
+  w_size = align(off_x + mpad + 8);
+  if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
+
+  auto pos_of = [&](int32_t j, int32_t c) -> int64_t {  // location of W[j][c] (new indices), j,c later than the pivot
+    if (j == c) return j < ns ? off_diag + j : off_S + (int64_t)(j - ns) * mpad + (j - ns);
+    if (j >= ns && c >= ns) return off_S + (int64_t)(j - ns) * mpad + (c - ns);
+    if (j < c) return off_U + find_entry(ent_ptr, nbr, j, c);   // U row j
+    return off_L + find_entry(ent_ptr, nbr, c, j);              // L column c
+  };
+
+  // ---- J scatter map
+  {
+    std::vector<int32_t> jm(nnzJ);
+    for (int32_t i = 0; i < n; i++)
+      for (int32_t e = j_ptr[i]; e < j_ptr[i + 1]; e++) {
+        int32_t j = j_col[e];
+        int64_t p = pos_of(iperm[i], iperm[j]);
+        jm[e] = (int32_t)p | (i == j ? (int32_t)0x80000000 : 0);
+      }
+    jmap.upload(jm, s);
+    ent_pivot.upload(ent_piv, s);
+    std::vector<int32_t> yl(n), xl(n);
+    for (int32_t v = 0; v < n; v++) {
+      yl[v] = (int32_t)(off_y + iperm[v]);
+      xl[v] = iperm[v] < ns ? (int32_t)(off_y + iperm[v]) : (int32_t)(off_x + iperm[v] - ns);
+    }
+    yloc.upload(yl, s); xloc.upload(xl, s);
+    KIN_HIP(hipStreamSynchronize(s));
+  }
+
+  // ---- per-round Schur update plans
+  schur.clear(); fwd.clear(); bwd.clear();
+  schur.resize(nrounds); fwd.resize(nrounds); bwd.resize(nrounds);
+  schur_macs = 0;
+  std::vector<Triple> tr;
+  for (int r = 0; r < nrounds; r++) {
+    tr.clear();
+    for (int32_t p = round_ptr[r]; p < round_ptr[r + 1]; p++)
+      for (int32_t ej = ent_ptr[p]; ej < ent_ptr[p + 1]; ej++)
+        for (int32_t ec = ent_ptr[p]; ec < ent_ptr[p + 1]; ec++)
+          tr.push_back({pos_of(nbr[ej], nbr[ec]), (int32_t)(off_L + ej), (int32_t)(off_U + ec)});
+    schur_macs += (int64_t)tr.size();
+    schur[r].upload(plan_from_triples(tr, false, 0, 0), s);
+  }
+  // ---- forward substitution: y_q -= sum_{p < q, q in nb(p)} L[q][p] * y_p, grouped by the round of q
+  {
+    std::vector<std::vector<Triple>> per_round(nrounds + 1);
+    auto round_of = [&](int32_t q) {
+      if (q >= ns) return nrounds;
+      return (int)(std::upper_bound(round_ptr.begin(), round_ptr.end(), q) - round_ptr.begin()) - 1;
+    };
+    for (int32_t p = 0; p < ns; p++)
+      for (int32_t e = ent_ptr[p]; e < ent_ptr[p + 1]; e++) {
+        int32_t q = nbr[e];
+        per_round[round_of(q)].push_back({off_y + q, (int32_t)(off_L + e), (int32_t)(off_y + p)});
+      }
+    for (int r = 0; r < nrounds; r++) fwd[r].upload(plan_from_triples(per_round[r], false, 0, 0), s);
+    fwd_dense.upload(plan_from_triples(per_round[nrounds], false, 0, 0), s);
+  }
+  // ---- backward substitution: x_p = (y_p - sum_c U[p][c] x_c) / diag_p
+  for (int r = 0; r < nrounds; r++) {
+    int32_t p0 = round_ptr[r], p1 = round_ptr[r + 1];
+    std::vector<int32_t> ptr{0}, dst, aux, a, b;
+    for (int32_t p = p0; p < p1; p++) {
+      for (int32_t e = ent_ptr[p]; e < ent_ptr[p + 1]; e++) {
+        int32_t c = nbr[e];
+        a.push_back((int32_t)(off_U + e));
+        b.push_back(c < ns ? (int32_t)(off_y + c) : (int32_t)(off_x + c - ns));
+      }
+      ptr.push_back((int32_t)a.size());
+      dst.push_back((int32_t)(off_y + p));
+      aux.push_back((int32_t)(off_diag + p));
+    }
+    a.push_back(0); b.push_back(0);  // keep data() valid for all-empty rounds
+    bwd[r].upload(build_seg_plan(p1 - p0, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+  }
+
+  W.alloc((size_t)w_size);
+  KIN_HIP(hipMemsetAsync(W.p, 0, (size_t)w_size * sizeof(double), s));
+  pinv.alloc(32 * 32);
+  rowp.alloc((size_t)32 * std::max(mpad, 64));
+  colp.alloc((size_t)32 * std::max(mpad, 64));
+  KIN_HIP(hipStreamSynchronize(s));
+}
+
+void SparseLU::factor(double c, const double* d_jvals, hipStream_t s) {
+  // zero everything up to the solve vectors, then scatter I - c*J
+  KIN_HIP(hipMemsetAsync(W.p, 0, (size_t)off_y * sizeof(double), s));
+  launch_lu_assemble(nnzJ, jmap.p, d_jvals, c, W.p, off_S, m, mpad, s);
+  for (int r = 0; r < nrounds; r++) {
+    launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W.p, off_L, off_diag, s);
+    launch_segsum(schur[r].view(), SEG_PROD_SUB, W.p, W.p, SegExtra{}, s);
+  }
+  if (m > 0) launch_gauss_jordan(W.p + off_S, mpad, pinv.p, rowp.p, colp.p, s);
+}
+
+void SparseLU::solve(const int* skip, hipStream_t s) {
+  SegExtra ex;
+  ex.skip = skip;
+  for (int r = 1; r < nrounds; r++) launch_segsum(fwd[r].view(), SEG_PROD_SUB, W.p, W.p, ex, s);
+  if (m > 0) {
+    if (ns > 0) launch_segsum(fwd_dense.view(), SEG_PROD_SUB, W.p, W.p, ex, s);
+    launch_gemv(W.p + off_S, mpad, m, W.p + off_y + ns, W.p + off_x, skip, s);
+  }
+  for (int r = nrounds - 1; r >= 0; r--) launch_segsum(bwd[r].view(), SEG_PROD_SUB_DIV, W.p, W.p, ex, s);
+}
+
+}  // namespace kin

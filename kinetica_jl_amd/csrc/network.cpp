@@ -8,7 +8,7 @@
 namespace kin {
 
 SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
-                           const int32_t* b, const float* c, bool skip_empty) {
+                           const int32_t* b, const float* c, bool skip_empty, const int32_t* aux) {
   SegPlanHost P;
   std::vector<int32_t> shorts, longs;
   for (int64_t i = 0; i < n_rows; i++) {
@@ -30,9 +30,10 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     P.ell_c.resize(base + (size_t)width * 64, 0.0f);
     for (int lane = 0; lane < 64; lane++) {
       size_t q = g0 + lane;
-      if (q >= g1) { P.grp_dst.push_back(-1); continue; }
+      if (q >= g1) { P.grp_dst.push_back(-1); P.grp_aux.push_back(0); continue; }
       int32_t row = shorts[q];
       P.grp_dst.push_back(dst ? dst[row] : row);
+      P.grp_aux.push_back(aux ? aux[row] : 0);
       for (int32_t e = ptr[row], col = 0; e < ptr[row + 1]; e++, col++) {
         size_t pos = base + (size_t)col * 64 + lane;
         P.ell_a[pos] = a[e];
@@ -59,9 +60,11 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
       }
       P.seg_end.push_back((int32_t)P.long_a.size());
       P.seg_dst.push_back(nseg == 1 ? out : -(P.n_partials++) - 1);
+      P.seg_aux.push_back(aux ? aux[row] : 0);
     }
     if (nseg > 1) {
       P.fix_dst.push_back(out);
+      P.fix_aux.push_back(aux ? aux[row] : 0);
       P.fix_ptr.push_back(P.n_partials);
     }
   }

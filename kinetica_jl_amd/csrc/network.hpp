@@ -22,15 +22,18 @@ struct SegPlanHost {
   // ELL groups
   std::vector<int32_t> grp_off;  // G+1: first ELL column of each group
   std::vector<int32_t> grp_dst;  // G*64: output index per lane (-1 = idle lane)
+  std::vector<int32_t> grp_aux;  // G*64: optional per-row auxiliary index (divisor position)
   std::vector<int32_t> ell_a, ell_b;
   std::vector<float> ell_c;      // 0.0f marks padding
   // long-row segments (payload copied contiguously)
   std::vector<int32_t> seg_beg, seg_end;  // S
   std::vector<int32_t> seg_dst;           // S: >=0 output index (single-segment row), <0: -(partial slot)-1
+  std::vector<int32_t> seg_aux;           // S
   std::vector<int32_t> long_a, long_b;
   std::vector<float> long_c;
   // fix-up for multi-segment rows
   std::vector<int32_t> fix_dst;           // F output index
+  std::vector<int32_t> fix_aux;           // F
   std::vector<int32_t> fix_ptr;           // F+1 ranges of partial slots
   int32_t n_partials = 0;
   int32_t n_groups() const { return (int32_t)grp_off.size() - 1; }
@@ -41,7 +44,7 @@ struct SegPlanHost {
 // Build a plan from CSR rows. `dst[row]` is the output index of a row; rows with no entries
 // are still scheduled (they produce 0) unless skip_empty. `b` and `c` may be null.
 SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
-                           const int32_t* b, const float* c, bool skip_empty);
+                           const int32_t* b, const float* c, bool skip_empty, const int32_t* aux = nullptr);
 
 struct NetworkHost {
   int64_t N = 0, R = 0;

@@ -1,15 +1,518 @@
+// kin_solve: the MI355X replacement for init / solve! / reinit! of the reference's stiff
+// integrator together with the orchestration around it:
+//   * chunkwise local-time solving + output stitching  (reference src/solving/methods.jl:185-303, 717-865)
+//   * complete-timespan solving                        (methods.jl:132-183, 655-714)
+//   * discrete rate-constant updates at tstops         (src/solving/solve_utils.jl:435-509)
+//   * adaptive_solve! tolerance-tightening retries     (solve_utils.jl:376-424)
+//
+// Integrator. The reference delegates to a user-supplied SciML algorithm (documented choice:
+// Sundials CVODE_BDF + KLU, docs/src/getting-started.md:69) that is not vendored, so the
+// algorithm restated here is the published quasi-constant-step variable-order BDF/NDF of
+// Shampine & Reichelt ("The MATLAB ODE Suite", SIAM J. Sci. Comput. 18, 1997; orders 1-5,
+// backward-difference form, modified Newton with an iteration-count dependent safety factor,
+// order selection from the error estimates one order down/up). oracle/bdf.py restates the
+// same algorithm on the CPU; both are checked against closed-form and high-accuracy truths.
+//
+// Control flow lives on the host; every vector operation, the RHS, the Jacobian, the LU and
+// the triangular solves are device kernels on one stream. A step attempt enqueues predictor +
+// two Newton iterations + error estimate blind (kernels turn into no-ops once the device-side
+// convergence flag is set) and synchronises ONCE to read a 96-byte control block.
 #include "solver.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+#include "lu.hpp"
+#include "solver_kernels.hpp"
+
 namespace kin {
-struct Solver {};
+
+namespace {
+constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
+const double KAPPA[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+enum StepStatus { STEP_OK = 0, STEP_DT_MIN = 1, STEP_UNSTABLE = 2 };
+
+void compute_R(int order, double factor, double R[6][6]) {
+  double M[6][6];
+  for (int i = 0; i <= order; i++)
+    for (int j = 0; j <= order; j++) M[i][j] = 0.0;
+  for (int j = 0; j <= order; j++) M[0][j] = 1.0;
+  for (int i = 1; i <= order; i++)
+    for (int j = 1; j <= order; j++) M[i][j] = ((double)i - 1.0 - factor * (double)j) / (double)i;
+  for (int j = 0; j <= order; j++) {
+    double p = 1.0;
+    for (int i = 0; i <= order; i++) { p *= M[i][j]; R[i][j] = p; }
+  }
 }
+}  // namespace
+
+struct Solver {
+  kin_network* h;
+  int N;
+  hipStream_t s;
+  SparseLU lu;
+  SegPlanDev resid_plan;                  // Newton residual written straight into the permuted solve vector
+  DevBuf<double> D, y, psi, d, scale, f0, f1, ytmp, jv, umax;
+  DevBuf<BdfCtrl> ctrl;
+  BdfCtrl* hc = nullptr;                  // pinned host mirror
+  BdfCoef cf;
+  // integrator state
+  double t = 0, h_abs = 0, atol = 0, rtol = 0, newton_tol = 0, dtmin = 0;
+  int order = 1, n_equal = 0;
+  bool lu_valid = false, jac_current = false, ban_negatives = false;
+  kin_stats st{};
+  int64_t iters_left = 0;
+
+  explicit Solver(kin_network* hh) : h(hh), N((int)hh->host.N), s(hh->stream) {
+    const NetworkHost& H = h->host;
+    LUOptions opt;
+    if (const char* e = getenv("KIN_LU_HUB_DEGREE")) opt.hub_degree = atoi(e);
+    if (const char* e = getenv("KIN_LU_MAX_ROUNDS")) opt.max_rounds = atoi(e);
+    if (const char* e = getenv("KIN_LU_MAX_TAIL_DEGREE")) opt.max_tail_degree = atoi(e);
+    if (const char* e = getenv("KIN_LU_MAX_DEGREE")) opt.max_degree = atoi(e);
+    lu.analyze(N, H.j_ptr, H.j_col, opt, s);
+    std::vector<int32_t> yl(N), ident(N);
+    lu.yloc.download(yl.data(), N, s);
+    KIN_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < N; i++) ident[i] = i;
+    resid_plan.upload(build_seg_plan(N, H.sp_ptr.data(), yl.data(), H.sp_rxn.data(), nullptr, H.sp_coef.data(), false, ident.data()), s);
+    D.alloc((size_t)BDF_D_ROWS * N);
+    y.alloc(N); psi.alloc(N); d.alloc(N); scale.alloc(N); f0.alloc(N); f1.alloc(N); ytmp.alloc(N); umax.alloc(N);
+    jv.alloc(H.nnz());
+    ctrl.alloc(1);
+    KIN_HIP(hipHostMalloc((void**)&hc, sizeof(BdfCtrl), hipHostMallocDefault));
+    cf.gamma[0] = 0.0;
+    for (int j = 1; j <= BDF_MAX_ORDER; j++) cf.gamma[j] = cf.gamma[j - 1] + 1.0 / j;
+    for (int j = 0; j <= BDF_MAX_ORDER; j++) cf.alpha[j] = (1.0 - KAPPA[j]) * cf.gamma[j];
+    for (int j = 0; j <= BDF_MAX_ORDER; j++) cf.error_const[j] = KAPPA[j] * cf.gamma[j] + 1.0 / (j + 1);
+    cf.error_const[BDF_MAX_ORDER + 1] = 0.0;
+  }
+  ~Solver() { if (hc) (void)hipHostFree(hc); }
+
+  void set_tols(double a, double r) {
+    atol = a; rtol = r;
+    newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, std::min(0.03, std::sqrt(rtol)));
+  }
+
+  void sync_ctrl() {
+    KIN_HIP(hipMemcpyAsync(hc, ctrl.p, sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
+    KIN_HIP(hipStreamSynchronize(s));
+  }
+
+  void rhs(const double* u, double* out) { h->rhs_dev(u, out); st.n_rhs++; }
+
+  void eval_jac(const double* u) { h->jac_dev(u, jv.p); st.n_jac++; lu_valid = false; }
+
+  void change_D(int ord, double factor) {
+    double R[6][6], U[6][6];
+    compute_R(ord, factor, R);
+    compute_R(ord, 1.0, U);
+    BdfMat ru;
+    for (int a = 0; a <= ord; a++)
+      for (int b = 0; b <= ord; b++) {
+        double v = 0.0;
+        for (int q = 0; q <= ord; q++) v += R[a][q] * U[q][b];
+        ru.v[a][b] = v;
+      }
+    launch_bdf_change_D(N, ord, ru, D.p, s);
+  }
+
+  // (re)start the integrator at time t0 from the state in y (reinit! semantics: order 1, fresh
+  // initial step, fresh Jacobian). Returns false when f(y0) is not finite.
+  bool restart(double t0, double t_bound) {
+    t = t0;
+    st.n_restarts++;
+    rhs(y.p, f0.p);
+    launch_bdf_norms(N, y.p, f0.p, nullptr, atol, rtol, ctrl.p, s);
+    sync_ctrl();
+    if (hc->nonfinite) return false;
+    const double interval = std::fabs(t_bound - t0);
+    const double d0 = hc->scratch[0], d1 = hc->scratch[1];
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    h0 = std::min(h0, interval);
+    launch_axpy_out(N, y.p, h0, f0.p, ytmp.p, s);
+    rhs(ytmp.p, f1.p);
+    launch_bdf_norms(N, y.p, f0.p, f1.p, atol, rtol, ctrl.p, s);
+    sync_ctrl();
+    if (hc->nonfinite) return false;
+    const double d2 = hc->scratch[2] / h0;
+    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 0.5);
+    h_abs = std::min({100.0 * h0, h1, interval});
+    launch_bdf_init_D(N, BDF_D_ROWS, y.p, f0.p, h_abs, D.p, s);
+    order = 1;
+    n_equal = 0;
+    eval_jac(y.p);
+    jac_current = true;
+    return true;
+  }
+
+  void newton_iteration(int it, double c) {
+    const int* skip = &ctrl.p->newton_done;
+    launch_rates_skip(h->host.R, h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s);
+    SegExtra ex;
+    ex.psi = psi.p; ex.d = d.p; ex.cscal = c; ex.skip = skip;
+    launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, lu.W.p, ex, s);
+    lu.solve(skip, s);
+    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, lu.W.p, scale.p, y.p, d.p, ctrl.p, s);
+    st.n_rhs++; st.n_linsolve++;
+  }
+
+  // one accepted step towards t_bound (internally retries rejected attempts)
+  StepStatus step(double t_bound) {
+    bool accepted = false;
+    double safety = 0.9, err_norm = 0.0, t_new = t;
+    while (!accepted) {
+      if (iters_left-- <= 0) return STEP_OK;  // caller checks iters_left < 0 -> MaxIters
+      const double min_step = std::max(dtmin, 10.0 * (std::nextafter(t, INF) - t));
+      if (h_abs < min_step) return STEP_DT_MIN;
+      t_new = t + h_abs;
+      if (t_new - t_bound > 0.0) {
+        t_new = t_bound;
+        change_D(order, std::fabs(t_new - t) / h_abs);
+        n_equal = 0;
+        lu_valid = false;
+      }
+      const double hh = t_new - t;
+      h_abs = std::fabs(hh);
+      const double c = hh / cf.alpha[order];
+      bool converged = false;
+      for (;;) {
+        if (!lu_valid) {
+          lu.factor(c, jv.p, s);
+          lu_valid = true;
+          st.n_factor++;
+        }
+        launch_bdf_ctrl_reset(ctrl.p, s);
+        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, s);
+        newton_iteration(0, c);
+        newton_iteration(1, c);
+        launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, s);
+        sync_ctrl();
+        if (!hc->newton_done) {
+          newton_iteration(2, c);
+          newton_iteration(3, c);
+          launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, s);
+          sync_ctrl();
+        }
+        converged = hc->newton_done && hc->converged && !hc->nonfinite;
+        if (converged) break;
+        st.n_newton_fail++;
+        if (jac_current) break;
+        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, s);
+        eval_jac(y.p);
+        jac_current = true;
+      }
+      if (!converged || (ban_negatives && hc->any_negative)) {
+        // isoutofdomain (methods.jl:169-171) is treated like a failed corrector: halve the step
+        h_abs *= 0.5;
+        change_D(order, 0.5);
+        n_equal = 0;
+        lu_valid = false;
+        st.n_rejected++;
+        continue;
+      }
+      safety = 0.9 * (2.0 * BDF_NEWTON_MAXITER + 1.0) / (2.0 * BDF_NEWTON_MAXITER + hc->n_iter);
+      err_norm = hc->err_norm;
+      if (err_norm > 1.0) {
+        const double factor = std::max(MIN_FACTOR, safety * std::pow(err_norm, -1.0 / (order + 1)));
+        h_abs *= factor;
+        change_D(order, factor);
+        n_equal = 0;
+        // the corrector converged with this iteration matrix: it is kept for the retry
+        st.n_rejected++;
+      } else {
+        accepted = true;
+      }
+    }
+    st.n_steps++;
+    n_equal++;
+    t = t_new;
+    launch_bdf_accept(N, order, D.p, d.p, s);
+    jac_current = false;
+    pending_order_change = (n_equal >= order + 1);
+    if (pending_order_change) {
+      err_m = order > 1 ? hc->err_m_norm : INF;
+      err_p = order < BDF_MAX_ORDER ? hc->err_p_norm : INF;
+      err_o = err_norm;
+      safety_o = safety;
+    }
+    return STEP_OK;
+  }
+
+  // order / step-size selection after an accepted step (done after the dense-output saves,
+  // which need the differences of the step just taken)
+  bool pending_order_change = false;
+  double err_m = 0, err_p = 0, err_o = 0, safety_o = 0.9;
+  void select_order() {
+    if (!pending_order_change) return;
+    pending_order_change = false;
+    const double norms[3] = {err_m, err_o, err_p};
+    double best = -1.0;
+    int arg = 1;
+    for (int i = 0; i < 3; i++) {
+      double f;
+      if (norms[i] == 0.0) f = INF;
+      else if (std::isinf(norms[i])) f = 0.0;
+      else f = std::pow(norms[i], -1.0 / (order + i));
+      if (f > best) { best = f; arg = i; }
+    }
+    order += arg - 1;
+    const double factor = std::min(MAX_FACTOR, safety_o * best);
+    h_abs *= factor;
+    change_D(order, factor);
+    n_equal = 0;
+    lu_valid = false;
+  }
+
+  // dense output of the step that ended at t (step size h_abs, differences D of `order`)
+  void interpolate(double ts, double* out) {
+    BdfVec p;
+    double prod = 1.0;
+    for (int j = 0; j < order; j++) {
+      prod *= (ts - (t - h_abs * j)) / (h_abs * (1.0 + j));
+      p.v[j + 1] = prod;
+    }
+    launch_bdf_interp(N, order, D.p, p, out, s);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// orchestration
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct SaveBuf {
+  kin_network* h;
+  int N;
+  int64_t cap = 0;
+  void reserve(int64_t rows) {
+    if (rows <= cap) return;
+    int64_t ncap = std::max<int64_t>(rows, cap * 2);
+    DevBuf<double> nb;
+    nb.alloc((size_t)ncap * N);
+    if (h->n_saved > 0)
+      KIN_HIP(hipMemcpyAsync(nb.p, h->d_sol_u.p, (size_t)h->n_saved * N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    KIN_HIP(hipStreamSynchronize(h->stream));
+    std::swap(h->d_sol_u.p, nb.p);
+    std::swap(h->d_sol_u.n, nb.n);
+    cap = ncap;
+  }
+  double* row(int64_t i) { return h->d_sol_u.p + (size_t)i * N; }
+  void push_time(double t) { h->sol_t.push_back(t); h->n_saved++; }
+};
+
+// sets the handle's current rates for time-stop index si
+void apply_rates(kin_network* h, const double* T_stops, bool have_table, int64_t si) {
+  const int64_t R = h->host.R;
+  if (have_table) {
+    KIN_HIP(hipMemcpyAsync(h->k.p, h->table.p + (size_t)si * R, R * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    launch_arrhenius(R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, T_stops[si], h->k.p, h->stream);
+  }
+  h->has_rates = true;
+}
+
+}  // namespace
+
+int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
+                const double* k_table, int64_t n_stops, kin_stats* stats) {
+  auto wall0 = std::chrono::steady_clock::now();
+  const int64_t N = h->host.N, R = h->host.R;
+  // ---- validation (ODESimulationParams constructor, params.jl:77-104)
+  if (!(p.tspan0 < p.tspan1)) throw KinError(ERR_INVALID_ARG, "Invalid time span");
+  if (!(p.abstol > 0) || !(p.reltol > 0)) throw KinError(ERR_INVALID_ARG, "tolerances must be positive");
+  int64_t n_chunks = 1;
+  const bool chunks = p.solve_chunks != 0;
+  const bool has_save = p.save_interval >= 0;
+  if (chunks) {
+    if (!(p.solve_chunkstep > 0)) throw KinError(ERR_INVALID_ARG, "solve_chunkstep must be positive");
+    const double q = p.tspan1 / p.solve_chunkstep;   // Int(tspan[2] / solve_chunkstep) must be exact (params.jl:89-99)
+    if (q != std::floor(q) || q < 1) throw KinError(ERR_INVALID_ARG, "Simulation timespan is not divisible by requested chunkwise simulation step size");
+    n_chunks = (int64_t)q;
+    if (has_save && p.save_interval > p.solve_chunkstep) throw KinError(ERR_INVALID_ARG, "Solution save interval must be less than chunkwise simulation step size");
+    if (has_save && !(p.save_interval > 0)) throw KinError(ERR_INVALID_ARG, "save_interval must be positive");
+  }
+  const bool variable = n_stops > 0;
+  if (variable) {
+    if (!tstops) throw KinError(ERR_INVALID_ARG, "tstops is null");
+    if (!k_table && !T_stops) throw KinError(ERR_INVALID_ARG, "need k_table or T_stops with tstops");
+    if (!k_table && !h->has_arrhenius) throw KinError(ERR_STATE, "T_stops given but Arrhenius parameters were never set");
+    for (int64_t i = 1; i < n_stops; i++)
+      if (!(tstops[i] > tstops[i - 1])) throw KinError(ERR_INVALID_ARG, "tstops must be strictly increasing");
+  } else if (!h->has_rates) {
+    throw KinError(ERR_STATE, "rates were never set");
+  }
+  if (!h->solver) h->solver.reset(new Solver(h));
+  Solver& S = *h->solver;
+  hipStream_t s = h->stream;
+  S.st = kin_stats{};
+  S.ban_negatives = p.ban_negatives != 0;
+  double abstol = p.abstol, reltol = p.reltol;
+  S.set_tols(abstol, reltol);
+
+  const bool have_table = variable && k_table != nullptr;
+  if (have_table) {
+    h->table.upload(k_table, (size_t)n_stops * R, s);
+    h->table_rows = n_stops;
+  }
+
+  // ---- output storage
+  h->sol_t.clear();
+  h->n_saved = 0;
+  SaveBuf sb{h, (int)N};
+  // per-chunk local save grid: 0:save_interval:chunkstep (methods.jl:756-758); element i is the
+  // correctly rounded i*save_interval as produced by Julia's float ranges
+  std::vector<double> save_local;
+  double span_len = chunks ? p.solve_chunkstep : (p.tspan1 - p.tspan0);
+  if (chunks || has_save) {
+    const double si = has_save ? p.save_interval : p.solve_chunkstep;
+    const double base = chunks ? 0.0 : p.tspan0;
+    const double last = chunks ? p.solve_chunkstep : p.tspan1;
+    const int64_t cnt = (int64_t)std::floor(span_len / si + 1e-9) + 1;
+    for (int64_t i = 0; i < cnt; i++) save_local.push_back(std::min(base + (double)i * si, last));
+    if (!chunks && save_local.back() < last) save_local.push_back(last);  // save_end
+    if (chunks) save_local.back() = last;
+  }
+  const int64_t L = (int64_t)save_local.size();
+  if (chunks) sb.reserve((L - 1) * n_chunks + 1);
+  else sb.reserve(has_save ? L : 1024);
+
+  // initial state
+  S.y.upload(u0, N, s);
+  int64_t next_stop = 0;      // first tstop not yet applied
+  int retcode = KIN_RETCODE_SUCCESS;
+  const double t_origin = chunks ? 0.0 : p.tspan0;
+  DevBuf<double> chunk_start;
+  chunk_start.alloc(N);
+
+  // initial rates = calculator at the initial conditions (methods.jl:672, 734); a tstop at the
+  // very start overrides it below
+  if (variable && !have_table) { /* rates at T_stops[0] are applied by the loop when tstops[0] == start */ }
+
+  for (int64_t nc = 0; nc < n_chunks && retcode == KIN_RETCODE_SUCCESS; nc++) {
+    S.st.n_chunks++;
+    const double t_start_global = chunks ? p.solve_chunkstep * (double)nc : p.tspan0;
+    const double t_end_global = chunks ? t_start_global + p.solve_chunkstep : p.tspan1;
+    const double shift = chunks ? (double)nc * p.solve_chunkstep : 0.0;   // global = local + shift
+    const double t_loc0 = chunks ? 0.0 : p.tspan0;
+    const double t_loc1 = chunks ? p.solve_chunkstep : p.tspan1;
+    (void)t_origin;
+    // local stops of this chunk: tg - nc*chunkstep for tstops in [t_start, t_end) (methods.jl:798-800);
+    // the complete-timespan variant takes all of them (methods.jl:697)
+    const int64_t stop_first = next_stop;
+    KIN_HIP(hipMemcpyAsync(chunk_start.p, S.y.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const int64_t saved_at_chunk_start = h->n_saved;
+    const size_t times_at_chunk_start = h->sol_t.size();
+
+    int attempts = 0;
+    for (;;) {  // adaptive_solve! (solve_utils.jl:376-424)
+      attempts++;
+      retcode = KIN_RETCODE_SUCCESS;
+      S.iters_left = p.maxiters;
+      int64_t stop_i = stop_first;
+      // rates in force at the chunk start: the last stop at or before it (zero-order hold)
+      while (variable && stop_i < n_stops && tstops[stop_i] <= t_start_global) {
+        stop_i++;
+      }
+      if (variable) {
+        if (stop_i > 0) apply_rates(h, T_stops, have_table, stop_i - 1);
+        else apply_rates(h, T_stops, have_table, 0);  // before the first stop: initial conditions
+      }
+      int64_t save_i = 0;
+      double t_seg = t_loc0;
+      bool failed = false;
+      // save the chunk's first point (local t = 0)
+      auto save_state_now = [&](double t_local) {
+        sb.reserve(h->n_saved + 1);
+        KIN_HIP(hipMemcpyAsync(sb.row(h->n_saved), S.y.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        sb.push_time(t_local + shift);
+      };
+      if (L > 0) { save_state_now(save_local[0]); save_i = 1; }
+      else save_state_now(t_loc0);   // saveat = []: every step, starting with the initial state
+
+      while (t_seg < t_loc1 && !failed) {
+        // segment end: next tstop inside this chunk, else the chunk end
+        double seg_end = t_loc1;
+        bool ends_at_stop = false;
+        if (variable && stop_i < n_stops && tstops[stop_i] < t_end_global) {
+          const double loc = tstops[stop_i] - shift;
+          if (loc < t_loc1) { seg_end = loc; ends_at_stop = true; }
+        }
+        if (seg_end > t_seg) {
+          if (!S.restart(t_seg, seg_end)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
+          while (S.t < seg_end) {
+            StepStatus ss = S.step(seg_end);
+            if (S.iters_left < 0) { retcode = KIN_RETCODE_MAXITERS; failed = true; break; }
+            if (ss == STEP_DT_MIN) { retcode = KIN_RETCODE_DTLESSTHANMIN; failed = true; break; }
+            if (ss == STEP_UNSTABLE) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
+            // saves covered by this step
+            if (L > 0) {
+              const int64_t last = chunks ? L - 1 : L;   // the chunk's last point is saved below
+              while (save_i < last && save_local[save_i] <= S.t) {
+                if (chunks && save_i == L - 1) break;
+                sb.reserve(h->n_saved + 1);
+                S.interpolate(save_local[save_i], sb.row(h->n_saved));
+                sb.push_time(save_local[save_i] + shift);
+                save_i++;
+              }
+            } else {
+              sb.reserve(h->n_saved + 1);
+              KIN_HIP(hipMemcpyAsync(sb.row(h->n_saved), S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+              sb.push_time(S.t + shift);
+            }
+            S.select_order();
+          }
+          if (failed) break;
+          // state at the segment end = D[0]
+          KIN_HIP(hipMemcpyAsync(S.y.p, S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        t_seg = seg_end;
+        if (ends_at_stop) { apply_rates(h, T_stops, have_table, stop_i); stop_i++; }
+      }
+      if (!failed) {
+        // all but the chunk's last save point go to the output, the last only on the final chunk
+        // (methods.jl:829-846); its value is the state at the chunk end
+        if (chunks && nc == n_chunks - 1 && L > 1) save_state_now(save_local[L - 1]);
+        next_stop = stop_i;
+        break;
+      }
+      // ---- failure: tighten tolerances and redo this chunk from its start state
+      const double mintol = std::numeric_limits<double>::epsilon();
+      if (!p.adaptive_tols || attempts >= 5 || abstol / 10 <= mintol || reltol / 10 <= mintol) break;
+      abstol /= 10; reltol /= 10;
+      S.set_tols(abstol, reltol);
+      S.st.n_retries++;
+      KIN_HIP(hipMemcpyAsync(S.y.p, chunk_start.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+      h->n_saved = saved_at_chunk_start;
+      h->sol_t.resize(times_at_chunk_start);
+    }
+  }
+  KIN_HIP(hipStreamSynchronize(s));
+  S.st.final_abstol = abstol;
+  S.st.final_reltol = reltol;
+  S.st.lu_dense_dim = S.lu.m; S.st.lu_sparse_rows = S.lu.ns; S.st.lu_rounds = S.lu.nrounds;
+  S.st.lu_nnz = 2 * S.lu.nnzU + S.lu.ns + (int64_t)S.lu.m * S.lu.m;
+  S.st.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+  if (stats) *stats = S.st;
+  return retcode;
+}
+
+void solution_max(kin_network* h, double* out_umax) {
+  if (!h->solver) throw KinError(ERR_STATE, "no solution stored");
+  Solver& S = *h->solver;
+  launch_colmax((int)h->host.N, h->n_saved, h->d_sol_u.p, S.umax.p, h->stream);
+  S.umax.download(out_umax, h->host.N, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+}
+
+}  // namespace kin
+
 kin_network::kin_network() {}
 kin_network::~kin_network() {
   solver.reset();
   if (stream) (void)hipStreamDestroy(stream);
-}
-namespace kin {
-int solve_entry(kin_network*, const kin_params&, const double*, const double*, const double*, const double*, int64_t, kin_stats*) {
-  throw KinError(ERR_STATE, "solver not built yet");
-}
-void solution_max(kin_network*, double*) { throw KinError(ERR_STATE, "solver not built yet"); }
 }

@@ -1,0 +1,431 @@
+// gfx950 kernels of the implicit solve: Newton-matrix assembly, the dense Schur-block inverse
+// (blocked Gauss-Jordan, FP64), GEMV, and the vector kernels of the variable-order BDF.
+// Every kernel that belongs to a Newton iteration takes a device `skip` flag so that a whole
+// iteration can be enqueued ahead of the convergence decision and become a no-op afterwards
+// (one host synchronisation per step attempt instead of one per Newton iteration).
+#include "lu.hpp"
+#include "solver_kernels.hpp"
+
+namespace kin {
+
+// ------------------------------------------------------------------------------------------
+// M = I - c*J scattered into the factor storage
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lu_assemble_kernel(int nnzJ, const int32_t* __restrict__ jmap,
+                                                          const double* __restrict__ jvals, double c,
+                                                          double* __restrict__ W, long long off_S, int m, int mpad) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < nnzJ) {
+    const int32_t jm = jmap[e];
+    const bool diag = jm < 0;
+    W[jm & 0x7fffffff] = (diag ? 1.0 : 0.0) - c * jvals[e];
+  } else {
+    const int d = m + (e - nnzJ);  // identity on the padding rows of the dense block
+    if (d < mpad) W[off_S + (long long)d * mpad + d] = 1.0;
+  }
+}
+
+void launch_lu_assemble(int64_t nnzJ, const int32_t* jmap, const double* jvals, double c, double* W,
+                        int64_t off_S, int32_t m, int32_t mpad, hipStream_t s) {
+  const int64_t total = nnzJ + (mpad - m);
+  if (total == 0) return;
+  hipLaunchKernelGGL(lu_assemble_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, (int)nnzJ, jmap, jvals,
+                     c, W, (long long)off_S, m, mpad);
+  KIN_HIP(hipGetLastError());
+}
+
+// L[:, p] /= diag[p] for the pivots of one round
+__global__ __launch_bounds__(256) void lu_scale_kernel(int e0, int e1, const int32_t* __restrict__ ent_pivot, double* W,
+                                                       long long off_L, long long off_diag) {
+  const int e = e0 + blockIdx.x * 256 + threadIdx.x;
+  if (e >= e1) return;
+  W[off_L + e] = W[off_L + e] / W[off_diag + ent_pivot[e]];
+}
+
+void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, hipStream_t s) {
+  if (e1 <= e0) return;
+  hipLaunchKernelGGL(lu_scale_kernel, dim3((unsigned)ceil_div(e1 - e0, 256)), dim3(256), 0, s, (int)e0, (int)e1, ent_pivot,
+                     W, (long long)off_L, (long long)off_diag);
+  KIN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// In-place blocked Gauss-Jordan inverse of the dense Schur block (no pivoting), NB = 32.
+// Per block step k:  P^-1 ; row panel = P^-1 * S[k,:] ; every other block row  S[i,:] -= S[i,k] * panel
+// (column k of the result is -S[i,k] * P^-1). 2 m^3 flops in rank-32 updates.
+// ------------------------------------------------------------------------------------------
+constexpr int GJ_NB = 32;
+
+__global__ __launch_bounds__(1024) void gj_pivot_kernel(const double* __restrict__ S, int ld, int kb, double* __restrict__ pinv) {
+  __shared__ double A[GJ_NB][GJ_NB + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  A[ty][tx] = S[(size_t)(kb * GJ_NB + ty) * ld + kb * GJ_NB + tx];
+  __syncthreads();
+  for (int k = 0; k < GJ_NB; k++) {
+    const double piv = A[k][k];
+    const double akj = (tx == k) ? 1.0 : A[k][tx];
+    const double aik = A[ty][k];
+    const double old = (tx == k) ? 0.0 : A[ty][tx];
+    __syncthreads();
+    const double rowk = akj / piv;
+    A[ty][tx] = (ty == k) ? rowk : old - aik * rowk;
+    __syncthreads();
+  }
+  pinv[ty * GJ_NB + tx] = A[ty][tx];
+}
+
+// one workgroup per 32-column block cb: rowp[:, cb] = P^-1 * S[kb, cb]  (P^-1 itself for cb == kb),
+// written to the panel buffer and back into S; also saves column panel S[cb rows, kb] to colp.
+__global__ __launch_bounds__(1024) void gj_panel_kernel(double* S, int ld, int kb, const double* __restrict__ pinv,
+                                                        double* __restrict__ rowp, double* __restrict__ colp) {
+  __shared__ double P[GJ_NB][GJ_NB + 1];
+  __shared__ double B[GJ_NB][GJ_NB + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int cb = blockIdx.x;
+  // column panel copy first (block row cb, block column kb); block row kb is not used later
+  colp[(size_t)(cb * GJ_NB + ty) * GJ_NB + tx] = S[(size_t)(cb * GJ_NB + ty) * ld + kb * GJ_NB + tx];
+  P[ty][tx] = pinv[ty * GJ_NB + tx];
+  B[ty][tx] = S[(size_t)(kb * GJ_NB + ty) * ld + cb * GJ_NB + tx];
+  __syncthreads();
+  double acc;
+  if (cb == kb) acc = P[ty][tx];
+  else {
+    acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < GJ_NB; k++) acc += P[ty][k] * B[k][tx];
+  }
+  rowp[(size_t)ty * ld + cb * GJ_NB + tx] = acc;
+}
+
+// 64x64 output tile per workgroup (256 threads, 4x4 per thread), K = 32
+__global__ __launch_bounds__(256) void gj_update_kernel(double* S, int ld, int kb, const double* __restrict__ rowp,
+                                                        const double* __restrict__ colp) {
+  __shared__ double Cs[64][GJ_NB + 1];   // colp tile: rows x k
+  __shared__ double Rs[GJ_NB][64 + 1];   // rowp tile: k x cols
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int q = tid; q < 64 * GJ_NB; q += 256) {
+    const int i = q >> 5, k = q & 31;
+    Cs[i][k] = colp[(size_t)(r0 + i) * GJ_NB + k];
+  }
+  for (int q = tid; q < GJ_NB * 64; q += 256) {
+    const int k = q >> 6, j = q & 63;
+    Rs[k][j] = rowp[(size_t)k * ld + c0 + j];
+  }
+  __syncthreads();
+  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+  double acc[4][4] = {};
+#pragma unroll 8
+  for (int k = 0; k < GJ_NB; k++) {
+    double a[4], b[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { a[x] = Cs[ti + x][k]; b[x] = Rs[k][tj + x]; }
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+      for (int y = 0; y < 4; y++) acc[x][y] += a[x] * b[y];
+  }
+  const int kr0 = kb * GJ_NB, kr1 = kr0 + GJ_NB;
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int i = r0 + ti + x;
+    const bool pivot_row = (i >= kr0 && i < kr1);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      const int j = c0 + tj + y;
+      double* p = S + (size_t)i * ld + j;
+      if (pivot_row) *p = Rs[i - kr0][tj + y];                     // row panel goes back into S
+      else if (j >= kr0 && j < kr1) *p = -acc[x][y];                 // column kb: -C * P^-1
+      else *p = *p - acc[x][y];
+    }
+  }
+}
+
+void launch_gauss_jordan(double* S, int32_t mpad, double* pinv, double* rowp, double* colp, hipStream_t s) {
+  const int nblk = mpad / GJ_NB;
+  for (int kb = 0; kb < nblk; kb++) {
+    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(1024), 0, s, S, mpad, kb, pinv);
+    hipLaunchKernelGGL(gj_panel_kernel, dim3(nblk), dim3(1024), 0, s, S, mpad, kb, pinv, rowp, colp);
+    hipLaunchKernelGGL(gj_update_kernel, dim3(mpad / 64, mpad / 64), dim3(256), 0, s, S, mpad, kb, rowp, colp);
+  }
+  KIN_HIP(hipGetLastError());
+}
+
+// x = S[0:m, 0:m] * y : one wavefront per row
+__global__ __launch_bounds__(256) void gemv_kernel(const double* __restrict__ S, int ld, int m, const double* __restrict__ y,
+                                                   double* __restrict__ x, const int* skip) {
+  if (skip && *skip) return;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const double* a = S + (size_t)row * ld;
+  double acc = 0.0;
+  for (int j = lane; j < m; j += 64) acc += a[j] * y[j];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) x[row] = acc;
+}
+
+void launch_gemv(const double* S, int32_t ld, int32_t m, const double* y, double* x, const int* skip, hipStream_t s) {
+  if (m == 0) return;
+  hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(256), 0, s, S, ld, m, y, x, skip);
+  KIN_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// BDF vector kernels (algorithm: solver.cpp). D is the backward-difference array [MAXD][N].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+  // fixed-order reduction over a 1024-thread workgroup
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) t += sh[i];
+    sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+__global__ __launch_bounds__(256) void bdf_predict_kernel(int N, int order, const double* __restrict__ D, BdfCoef cf,
+                                                          double atol, double rtol, double* __restrict__ y,
+                                                          double* __restrict__ psi, double* __restrict__ d,
+                                                          double* __restrict__ scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double yp = D[i], ps = 0.0;
+  for (int j = 1; j <= order; j++) {
+    const double dj = D[(size_t)j * N + i];
+    yp += dj;
+    ps += dj * cf.gamma[j];
+  }
+  y[i] = yp;
+  psi[i] = ps / cf.alpha[order];
+  d[i] = 0.0;
+  scale[i] = atol + rtol * fabs(yp);
+}
+
+// One Newton update, a single 1024-thread workgroup so that the norm, the convergence
+// decision and the update need no second launch.
+__global__ __launch_bounds__(1024) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
+                                                          const double* __restrict__ W, const double* __restrict__ scale,
+                                                          double* __restrict__ y, double* __restrict__ d, BdfCtrl* ctrl) {
+  __shared__ double sh[17];
+  if (ctrl->newton_done) return;
+  const double old = ctrl->dy_norm_old;   // read before any thread can reach the final write
+  double s = 0.0;
+  int bad = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double dy = W[xloc[i]];
+    if (!isfinite(dy)) bad = 1;
+    const double q = dy / scale[i];
+    s += q * q;
+  }
+  const double tot = block_sum_1024(s, sh);
+  const double nbad = block_sum_1024((double)bad, sh);
+  const double dy_norm = sqrt(tot / (double)N);
+  const bool have_rate = iter > 0;
+  const double rate = have_rate ? dy_norm / old : 0.0;
+  bool diverged = (nbad > 0.0) || !isfinite(dy_norm);
+  if (!diverged && have_rate && (rate >= 1.0 || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
+  if (!diverged) {
+    for (int i = threadIdx.x; i < N; i += 1024) {
+      const double dy = W[xloc[i]];
+      y[i] += dy;
+      d[i] += dy;
+    }
+  }
+  if (threadIdx.x == 0) {
+    ctrl->n_iter = iter + 1;
+    ctrl->dy_norm = dy_norm;
+    if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nbad > 0.0; }
+    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol)) { ctrl->newton_done = 1; ctrl->converged = 1; }
+    else {
+      ctrl->dy_norm_old = dy_norm;
+      if (iter == maxit - 1) { ctrl->newton_done = 1; ctrl->converged = 0; }
+    }
+  }
+}
+
+// local error estimate of the step and the estimates one order down / up (all three before
+// the differences are updated: D_new[order] = D[order] + d, D_new[order+2] = d - D[order+1])
+__global__ __launch_bounds__(1024) void bdf_error_kernel(int N, int order, const double* __restrict__ D, const double* __restrict__ y,
+                                                         const double* __restrict__ d, double atol, double rtol, BdfCoef cf,
+                                                         BdfCtrl* ctrl) {
+  __shared__ double sh[17];
+  if (!ctrl->newton_done || !ctrl->converged) return;
+  double se = 0.0, sm = 0.0, sp = 0.0;
+  int neg = 0, bad = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double yi = y[i], di = d[i];
+    if (yi < 0.0) neg = 1;
+    if (!isfinite(yi)) bad = 1;
+    const double sc = atol + rtol * fabs(yi);
+    const double e = cf.error_const[order] * di / sc;
+    se += e * e;
+    if (order > 1) { const double em = cf.error_const[order - 1] * (D[(size_t)order * N + i] + di) / sc; sm += em * em; }
+    if (order < 5) { const double ep = cf.error_const[order + 1] * (di - D[(size_t)(order + 1) * N + i]) / sc; sp += ep * ep; }
+  }
+  const double te = block_sum_1024(se, sh);
+  const double tm = block_sum_1024(sm, sh);
+  const double tp = block_sum_1024(sp, sh);
+  const double tn = block_sum_1024((double)neg, sh);
+  const double tb = block_sum_1024((double)bad, sh);
+  if (threadIdx.x == 0) {
+    ctrl->err_norm = sqrt(te / (double)N);
+    ctrl->err_m_norm = sqrt(tm / (double)N);
+    ctrl->err_p_norm = sqrt(tp / (double)N);
+    ctrl->any_negative = tn > 0.0;
+    if (tb > 0.0) ctrl->nonfinite = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void bdf_accept_kernel(int N, int order, double* __restrict__ D, const double* __restrict__ d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const double di = d[i];
+  D[(size_t)(order + 2) * N + i] = di - D[(size_t)(order + 1) * N + i];
+  D[(size_t)(order + 1) * N + i] = di;
+  double carry = di;
+  for (int j = order; j >= 0; j--) {
+    carry += D[(size_t)j * N + i];
+    D[(size_t)j * N + i] = carry;
+  }
+}
+
+// D[0..order] <- (R U)^T D[0..order]   (step-size change by `factor`, matrix built on the host)
+__global__ __launch_bounds__(256) void bdf_change_D_kernel(int N, int order, BdfMat ru, double* __restrict__ D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double v[6], o[6];
+  for (int j = 0; j <= order; j++) v[j] = D[(size_t)j * N + i];
+  for (int a = 0; a <= order; a++) {
+    double t = 0.0;
+    for (int b = 0; b <= order; b++) t += ru.v[b][a] * v[b];
+    o[a] = t;
+  }
+  for (int j = 0; j <= order; j++) D[(size_t)j * N + i] = o[j];
+}
+
+__global__ __launch_bounds__(256) void bdf_init_D_kernel(int N, int nrows, const double* __restrict__ y0, const double* __restrict__ f0,
+                                                         double h, double* __restrict__ D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  D[i] = y0[i];
+  D[(size_t)N + i] = f0[i] * h;
+  for (int j = 2; j < nrows; j++) D[(size_t)j * N + i] = 0.0;
+}
+
+// dense output: out = D[0] + sum_j p[j] D[j]
+__global__ __launch_bounds__(256) void bdf_interp_kernel(int N, int order, const double* __restrict__ D, BdfVec p, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double v = D[i];
+  for (int j = 1; j <= order; j++) v += p.v[j] * D[(size_t)j * N + i];
+  out[i] = v;
+}
+
+// out = a + s*b
+__global__ __launch_bounds__(256) void axpy_out_kernel(int N, const double* __restrict__ a, double s, const double* __restrict__ b, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) out[i] = a[i] + s * b[i];
+}
+
+// norms for the initial step size: rms(y0/sc), rms(f0/sc), rms((f1-f0)/sc), sc = atol + rtol |y0|;
+// f1 may be null. Also reports non-finite f.
+__global__ __launch_bounds__(1024) void bdf_norms_kernel(int N, const double* __restrict__ y0, const double* __restrict__ f0,
+                                                         const double* __restrict__ f1, double atol, double rtol, BdfCtrl* ctrl) {
+  __shared__ double sh[17];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  int bad = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double sc = atol + rtol * fabs(y0[i]);
+    const double a = y0[i] / sc, b = f0[i] / sc;
+    s0 += a * a; s1 += b * b;
+    if (!isfinite(f0[i])) bad = 1;
+    if (f1) { const double c = (f1[i] - f0[i]) / sc; s2 += c * c; if (!isfinite(f1[i])) bad = 1; }
+  }
+  const double t0 = block_sum_1024(s0, sh), t1 = block_sum_1024(s1, sh), t2 = block_sum_1024(s2, sh);
+  const double tb = block_sum_1024((double)bad, sh);
+  if (threadIdx.x == 0) {
+    ctrl->scratch[0] = sqrt(t0 / (double)N);
+    ctrl->scratch[1] = sqrt(t1 / (double)N);
+    ctrl->scratch[2] = sqrt(t2 / (double)N);
+    ctrl->nonfinite = tb > 0.0;
+  }
+}
+
+__global__ void bdf_ctrl_reset_kernel(BdfCtrl* ctrl) {
+  ctrl->newton_done = 0; ctrl->converged = 0; ctrl->n_iter = 0; ctrl->nonfinite = 0; ctrl->any_negative = 0;
+  ctrl->dy_norm_old = 0.0; ctrl->dy_norm = 0.0; ctrl->err_norm = 0.0; ctrl->err_m_norm = 0.0; ctrl->err_p_norm = 0.0;
+}
+
+// per-species running maximum over saved states (identify_next_seeds' reduction)
+__global__ __launch_bounds__(256) void colmax_kernel(int N, long long M, const double* __restrict__ U, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double v = U[i];
+  for (long long t = 1; t < M; t++) v = fmax(v, U[(size_t)t * N + i]);
+  out[i] = v;
+}
+
+// rates kernel with a skip flag (Newton iterations)
+__global__ __launch_bounds__(256) void rates_skip_kernel(int R, const double* __restrict__ k, const double* __restrict__ u,
+                                                         const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
+                                                         double* __restrict__ rate, const int* skip) {
+  if (skip && *skip) return;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const int32_t a = x0[r], b = x1[r];
+  const double ub = b >= 0 ? u[b] : 1.0;
+  rate[r] = k[r] * u[a] * ub;
+}
+
+#define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)
+
+void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
+                        double* d, double* scale, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_predict_kernel, GRID1(N), 0, s, N, order, D, cf, atol, rtol, y, psi, d, scale);
+}
+void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
+                       double* y, double* d, BdfCtrl* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_newton_kernel, dim3(1), dim3(1024), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, ctrl);
+}
+void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
+                      const BdfCoef& cf, BdfCtrl* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_error_kernel, dim3(1), dim3(1024), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl);
+}
+void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d);
+}
+void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_change_D_kernel, GRID1(N), 0, s, N, order, ru, D);
+}
+void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, double h, double* D, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_init_D_kernel, GRID1(N), 0, s, N, nrows, y0, f0, h, D);
+}
+void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_interp_kernel, GRID1(N), 0, s, N, order, D, p, out);
+}
+void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_out_kernel, GRID1(N), 0, s, N, a, sc, b, out);
+}
+void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_norms_kernel, dim3(1), dim3(1024), 0, s, N, y0, f0, f1, atol, rtol, ctrl);
+}
+void launch_bdf_ctrl_reset(BdfCtrl* ctrl, hipStream_t s) { hipLaunchKernelGGL(bdf_ctrl_reset_kernel, dim3(1), dim3(1), 0, s, ctrl); }
+void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(colmax_kernel, GRID1(N), 0, s, N, (long long)M, U, out);
+}
+void launch_rates_skip(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate,
+                       const int* skip, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(rates_skip_kernel, GRID1(R), 0, s, (int)R, k, u, x0, x1, rate, skip);
+}
+
+}  // namespace kin

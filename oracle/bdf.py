@@ -1,0 +1,363 @@
+"""CPU oracle of the implicit solve - TEST INFRASTRUCTURE ONLY (see oracle.py's header).
+
+The reference hands integration to a user-supplied SciML solver; its documented choice is
+Sundials CVODE_BDF with the KLU sparse LU (docs/src/getting-started.md:69), neither of which
+is vendored or runnable here (Project.toml:36-60 pins only compat bounds; docs/Project.toml:9
+leaves Sundials unpinned). The stand-in restated here is the published quasi-constant-step,
+variable-order (1-5) BDF/NDF of Shampine & Reichelt, "The MATLAB ODE Suite", SIAM J. Sci.
+Comput. 18 (1997): backward differences D, Newton corrector on  d - c f(y_pred + d) + psi = 0
+with c = h / alpha_k, local error kappa-corrected, order chosen from the error estimates at
+k-1, k, k+1. SciPy's solve_ivp(method="BDF") implements the same paper; tests/test_oracle_bdf.py
+pins this file against it step for step. Sparse LU: SuperLU (scipy.sparse.linalg.splu) with a
+minimum-degree ordering - the same class of CPU solver as KLU.
+
+PARITY UNPINNED against the reference itself: trajectories are checked against closed forms and
+a high-accuracy Radau integration instead (tests/golden/make_truth.py).
+
+The orchestration around the integrator restates src/solving/methods.jl (chunk loop, save
+grid stitching, discrete rate updates) and adaptive_solve! (solve_utils.jl:376-424).
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+MAX_ORDER = 5
+NEWTON_MAXITER = 4
+MIN_FACTOR = 0.2
+MAX_FACTOR = 10.0
+EPS = np.finfo(float).eps
+
+KAPPA = np.array([0, -0.1850, -1 / 9, -0.0823, -0.0415, 0])
+GAMMA = np.hstack((0, np.cumsum(1 / np.arange(1, MAX_ORDER + 1))))
+ALPHA = (1 - KAPPA) * GAMMA
+ERROR_CONST = KAPPA * GAMMA + 1 / np.arange(1, MAX_ORDER + 2)
+
+RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
+
+
+def rms(x):
+    return np.linalg.norm(x) / math.sqrt(x.size)
+
+
+def _R(order, factor):
+    I = np.arange(1, order + 1)[:, None]
+    J = np.arange(1, order + 1)
+    M = np.zeros((order + 1, order + 1))
+    M[1:, 1:] = (I - 1 - factor * J) / I
+    M[0] = 1
+    return np.cumprod(M, axis=0)
+
+
+def change_D(D, order, factor):
+    RU = _R(order, factor).dot(_R(order, 1))
+    D[:order + 1] = RU.T.dot(D[:order + 1])
+
+
+class OracleBDF:
+    """fun(y) -> f, jac(y) -> scipy CSR (autonomous system: the rate constants are frozen
+    between restarts, exactly as in the discrete-rate solves of methods.jl:655-865)."""
+
+    def __init__(self, fun, jac, n, atol, rtol, dtmin=0.0, ban_negatives=False):
+        self.fun, self.jac, self.n = fun, jac, n
+        self.dtmin = dtmin
+        self.ban_negatives = ban_negatives
+        self.set_tols(atol, rtol)
+        self.stats = dict(n_steps=0, n_rejected=0, n_rhs=0, n_jac=0, n_factor=0, n_linsolve=0, n_newton_fail=0,
+                          n_restarts=0)
+        self.I = sp.identity(n, format="csc")
+        self.iters_left = 0
+
+    def set_tols(self, atol, rtol):
+        self.atol, self.rtol = atol, rtol
+        self.newton_tol = max(10 * EPS / rtol, min(0.03, rtol ** 0.5))
+
+    def _f(self, y):
+        self.stats["n_rhs"] += 1
+        return self.fun(y)
+
+    def _factor(self, c):
+        self.stats["n_factor"] += 1
+        if self.n <= 64:
+            return ("dense", sla.lu_factor(np.eye(self.n) - c * self.J.toarray()))
+        return ("sparse", spla.splu((self.I - c * self.J).tocsc(), permc_spec="MMD_AT_PLUS_A"))
+
+    def _lusolve(self, LU, b):
+        self.stats["n_linsolve"] += 1
+        return sla.lu_solve(LU[1], b) if LU[0] == "dense" else LU[1].solve(b)
+
+    def restart(self, t0, y0, t_bound):
+        """reinit!-like restart: order 1, initial step from the standard two-evaluation
+        heuristic (Hairer, Norsett & Wanner, Solving ODEs I, II.4), fresh Jacobian."""
+        self.stats["n_restarts"] += 1
+        self.t = t0
+        y0 = np.array(y0, dtype=float)
+        f0 = self._f(y0)
+        if not np.all(np.isfinite(f0)):
+            return False
+        interval = abs(t_bound - t0)
+        scale = self.atol + np.abs(y0) * self.rtol
+        d0, d1 = rms(y0 / scale), rms(f0 / scale)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        h0 = min(h0, interval)
+        f1 = self._f(y0 + h0 * f0)
+        if not np.all(np.isfinite(f1)):
+            return False
+        d2 = rms((f1 - f0) / scale) / h0
+        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.5
+        self.h_abs = min(100 * h0, h1, interval)
+        self.D = np.zeros((MAX_ORDER + 3, self.n))
+        self.D[0] = y0
+        self.D[1] = f0 * self.h_abs
+        self.order = 1
+        self.n_equal = 0
+        self.J = self.jac(y0); self.stats["n_jac"] += 1
+        self.LU = None
+        self.jac_current = True
+        self.pending = None
+        return True
+
+    def step(self, t_bound):
+        """One accepted step towards t_bound. Returns 'ok' | 'dtmin' | 'maxiters'."""
+        t, D, order = self.t, self.D, self.order
+        accepted = False
+        while not accepted:
+            self.iters_left -= 1
+            if self.iters_left < 0:
+                return "maxiters"
+            min_step = max(self.dtmin, 10 * (np.nextafter(t, np.inf) - t))
+            if self.h_abs < min_step:
+                return "dtmin"
+            t_new = t + self.h_abs
+            if t_new - t_bound > 0:
+                t_new = t_bound
+                change_D(D, order, abs(t_new - t) / self.h_abs)
+                self.n_equal = 0
+                self.LU = None
+            h = t_new - t
+            self.h_abs = abs(h)
+            y_pred = np.sum(D[:order + 1], axis=0)
+            scale = self.atol + self.rtol * np.abs(y_pred)
+            psi = np.dot(D[1:order + 1].T, GAMMA[1:order + 1]) / ALPHA[order]
+            c = h / ALPHA[order]
+            converged = False
+            while True:
+                if self.LU is None:
+                    self.LU = self._factor(c)
+                converged, n_iter, y_new, d = self._newton(y_pred, c, psi, scale)
+                if converged:
+                    break
+                self.stats["n_newton_fail"] += 1
+                if self.jac_current:
+                    break
+                self.J = self.jac(y_pred); self.stats["n_jac"] += 1
+                self.LU = None
+                self.jac_current = True
+            if not converged or (self.ban_negatives and np.any(y_new < 0)):
+                self.h_abs *= 0.5
+                change_D(D, order, 0.5)
+                self.n_equal = 0
+                self.LU = None
+                self.stats["n_rejected"] += 1
+                continue
+            safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter)
+            scale = self.atol + self.rtol * np.abs(y_new)
+            err_norm = rms(ERROR_CONST[order] * d / scale)
+            if err_norm > 1:
+                factor = max(MIN_FACTOR, safety * err_norm ** (-1 / (order + 1)))
+                self.h_abs *= factor
+                change_D(D, order, factor)
+                self.n_equal = 0
+                # the corrector converged with this iteration matrix: it is kept for the retry
+                self.stats["n_rejected"] += 1
+            else:
+                accepted = True
+        self.stats["n_steps"] += 1
+        self.n_equal += 1
+        self.t = t_new
+        D[order + 2] = d - D[order + 1]
+        D[order + 1] = d
+        for i in reversed(range(order + 1)):
+            D[i] += D[i + 1]
+        self.jac_current = False
+        self.pending = None
+        if self.n_equal >= order + 1:
+            err_m = rms(ERROR_CONST[order - 1] * D[order] / scale) if order > 1 else np.inf
+            err_p = rms(ERROR_CONST[order + 1] * D[order + 2] / scale) if order < MAX_ORDER else np.inf
+            self.pending = (err_m, err_norm, err_p, safety)
+        return "ok"
+
+    def _newton(self, y_pred, c, psi, scale):
+        d = np.zeros_like(y_pred)
+        y = y_pred.copy()
+        dy_norm_old = None
+        converged = False
+        k = 0
+        for k in range(NEWTON_MAXITER):
+            f = self._f(y)
+            dy = self._lusolve(self.LU, c * f - psi - d)
+            if not np.all(np.isfinite(dy)):
+                break
+            dy_norm = rms(dy / scale)
+            rate = None if dy_norm_old is None else dy_norm / dy_norm_old
+            if rate is not None and (rate >= 1 or rate ** (NEWTON_MAXITER - k) / (1 - rate) * dy_norm > self.newton_tol):
+                break
+            y += dy
+            d += dy
+            if dy_norm == 0 or (rate is not None and rate / (1 - rate) * dy_norm < self.newton_tol):
+                converged = True
+                break
+            dy_norm_old = dy_norm
+        return converged, k + 1, y, d
+
+    def select_order(self):
+        """Order / step-size selection; called after the dense-output saves of the step."""
+        if self.pending is None:
+            return
+        err_m, err_o, err_p, safety = self.pending
+        self.pending = None
+        norms = np.array([err_m, err_o, err_p])
+        with np.errstate(divide="ignore"):
+            factors = norms ** (-1 / np.arange(self.order, self.order + 3))
+        delta = int(np.argmax(factors)) - 1
+        self.order += delta
+        factor = min(MAX_FACTOR, safety * np.max(factors))
+        self.h_abs *= factor
+        change_D(self.D, self.order, factor)
+        self.n_equal = 0
+        self.LU = None
+
+    def interpolate(self, ts):
+        """Dense output over the step that ended at self.t (Newton form on the backward differences)."""
+        order, h = self.order, self.h_abs
+        j = np.arange(order)
+        x = (ts - (self.t - h * j)) / (h * (1 + j))
+        p = np.cumprod(x)
+        return self.D[0] + np.dot(self.D[1:order + 1].T, p)
+
+
+def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None, k_of_stop=None):
+    """CPU restatement of the solve orchestration. `fun_of_k(k)(y)`, `jac_of_k(k)(y)`;
+    `k_of_stop(i)` gives the rate vector in force from tstops[i] on (zero-order hold,
+    solve_utils.jl:435-509). params: dict with the kin_params fields. Returns
+    (t[M], u[M][n], retcode, stats)."""
+    wall0 = time.time()
+    tspan0, tspan1 = params["tspan"]
+    abstol, reltol = params.get("abstol", 1e-10), params.get("reltol", 1e-8)
+    chunks = params.get("solve_chunks", True)
+    chunkstep = params.get("solve_chunkstep", 1e-3)
+    save_interval = params.get("save_interval", None)
+    maxiters = params.get("maxiters", 100000)
+    adaptive_tols = params.get("adaptive_tols", True)
+    variable = tstops is not None and len(tstops) > 0
+    if not tspan0 < tspan1:
+        raise ValueError("Invalid time span")
+    n_chunks = 1
+    if chunks:
+        q = tspan1 / chunkstep
+        if q != math.floor(q):
+            raise ValueError("Simulation timespan is not divisible by requested chunkwise simulation step size")
+        n_chunks = int(q)
+        if save_interval is not None and save_interval > chunkstep:
+            raise ValueError("Solution save interval must be less than chunkwise simulation step size")
+    span_len = chunkstep if chunks else tspan1 - tspan0
+    save_local = None
+    if chunks or save_interval is not None:
+        si = save_interval if save_interval is not None else chunkstep
+        base, last = (0.0, chunkstep) if chunks else (tspan0, tspan1)
+        cnt = int(math.floor(span_len / si + 1e-9)) + 1
+        save_local = [min(base + i * si, last) for i in range(cnt)]
+        if not chunks and save_local[-1] < last:
+            save_local.append(last)
+        if chunks:
+            save_local[-1] = last
+    L = len(save_local) if save_local is not None else 0
+
+    state = {"k": None if k0 is None else np.array(k0, dtype=float)}
+    bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
+                    dtmin=0.0, ban_negatives=params.get("ban_negatives", False))
+    out_t, out_u = [], []
+    y = np.array(u0, dtype=float)
+    next_stop = 0
+    retcode = RET_SUCCESS
+    n_retries = 0
+    for nc in range(n_chunks):
+        t_start_g = chunkstep * nc if chunks else tspan0
+        t_end_g = t_start_g + chunkstep if chunks else tspan1
+        shift = nc * chunkstep if chunks else 0.0
+        t_loc0, t_loc1 = (0.0, chunkstep) if chunks else (tspan0, tspan1)
+        y_start = y.copy()
+        n_out_start = len(out_t)
+        attempts = 0
+        while True:
+            attempts += 1
+            retcode = RET_SUCCESS
+            bdf.iters_left = maxiters
+            stop_i = next_stop
+            while variable and stop_i < len(tstops) and tstops[stop_i] <= t_start_g:
+                stop_i += 1
+            if variable:
+                state["k"] = k_of_stop(max(stop_i - 1, 0))
+            failed = False
+            save_i = 0
+            if L > 0:
+                out_t.append(save_local[0] + shift); out_u.append(y.copy()); save_i = 1
+            else:
+                out_t.append(t_loc0 + shift); out_u.append(y.copy())
+            t_seg = t_loc0
+            while t_seg < t_loc1 and not failed:
+                seg_end, ends_at_stop = t_loc1, False
+                if variable and stop_i < len(tstops) and tstops[stop_i] < t_end_g:
+                    loc = tstops[stop_i] - shift
+                    if loc < t_loc1:
+                        seg_end, ends_at_stop = loc, True
+                if seg_end > t_seg:
+                    if not bdf.restart(t_seg, y, seg_end):
+                        retcode, failed = RET_UNSTABLE, True
+                        break
+                    while bdf.t < seg_end:
+                        status = bdf.step(seg_end)
+                        if status == "maxiters":
+                            retcode, failed = RET_MAXITERS, True
+                            break
+                        if status == "dtmin":
+                            retcode, failed = RET_DTMIN, True
+                            break
+                        if L > 0:
+                            last_i = L - 1 if chunks else L
+                            while save_i < last_i and save_local[save_i] <= bdf.t:
+                                out_t.append(save_local[save_i] + shift)
+                                out_u.append(bdf.interpolate(save_local[save_i]))
+                                save_i += 1
+                        else:
+                            out_t.append(bdf.t + shift); out_u.append(bdf.D[0].copy())
+                        bdf.select_order()
+                    if failed:
+                        break
+                    y = bdf.D[0].copy()
+                t_seg = seg_end
+                if ends_at_stop:
+                    state["k"] = k_of_stop(stop_i)
+                    stop_i += 1
+            if not failed:
+                if chunks and nc == n_chunks - 1 and L > 1:
+                    out_t.append(save_local[L - 1] + shift); out_u.append(y.copy())
+                next_stop = stop_i
+                break
+            if (not adaptive_tols) or attempts >= 5 or abstol / 10 <= EPS or reltol / 10 <= EPS:
+                break
+            abstol /= 10; reltol /= 10
+            bdf.set_tols(abstol, reltol)
+            n_retries += 1
+            y = y_start.copy()
+            del out_t[n_out_start:]; del out_u[n_out_start:]
+        if retcode != RET_SUCCESS:
+            break
+    stats = dict(bdf.stats)
+    stats.update(n_retries=n_retries, final_abstol=abstol, final_reltol=reltol, wall_seconds=time.time() - wall0)
+    return np.array(out_t), np.array(out_u).reshape(len(out_t), n), retcode, stats

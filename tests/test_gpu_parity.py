@@ -62,11 +62,13 @@ def test_jacobian_matches_oracle(case):
     D = abs(Jd - Jo)
     assert D.max() <= TOL * abs(Jo).max()
     # finite-difference check of the device Jacobian against the device RHS (independent of the oracle)
+    # (mass action is at most quadratic in u_j, so a central difference is exact up to round-off)
     j = 5
-    hstep = 1e-6 * u[j]
+    hstep = 0.25 * u[j]
     up, um = u.copy(), u.copy(); up[j] += hstep; um[j] -= hstep
     fd = (h.rhs(up) - h.rhs(um)) / (2 * hstep)
-    np.testing.assert_allclose(Jd[:, j].toarray().ravel(), fd, rtol=1e-5, atol=1e-5 * np.abs(fd).max())
+    noise = 1e-12 * (on.abs_rhs(k, up) + on.abs_rhs(k, um)) / hstep
+    assert np.all(np.abs(Jd[:, j].toarray().ravel() - fd) <= noise + 1e-12 * np.abs(fd))
 
 
 def test_arrhenius_matches_oracle(case, golden_dir):
