@@ -91,13 +91,10 @@ int kin_rhs(kin_network* h, const double* u, double* du);
 /* B states at once, host buffers in the reference's layout u[b][N], du[b][N] (sol.u is a
  * Vector of Vectors); k is per state k[b][R] or NULL (current rates for every state). */
 int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k, double* du);
-/* The same sweep on device-resident buffers (no PCIe): species-major, state-contiguous
- * layouts u[N][ldb], k[R][ldb] (or NULL), du[N][ldb]; ldb >= B and ldb % 8 == 0.
- * `stream` is a hipStream_t (NULL = the handle's stream); the call only enqueues. */
-int kin_rhs_batched_dev(kin_network* h, int64_t B, int64_t ldb, const double* d_u, const double* d_k,
-                        double* d_du, void* stream);
-/* Workspace the batched sweep needs for B states (the handle grows it on demand). */
-int kin_rhs_batched_reserve(kin_network* h, int64_t B);
+/* The same sweep on device-resident buffers (no PCIe), same state-major layouts u[b][N],
+ * k[b][R] (or NULL), du[b][N]. `stream` is a hipStream_t (NULL = the handle's stream); the
+ * call only enqueues (no allocation, no synchronisation: graph-capturable). */
+int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const double* d_k, double* d_du, void* stream);
 
 /* ---- A3: analytic sparse Jacobian ---------------------------------------------------- */
 /* Replaces ODEProblem(...; jac=true, sparse=true) (methods.jl:157-158): pattern (CSR,
@@ -155,6 +152,11 @@ int kin_solution_copy(const kin_network* h, double* out_t, double* out_u);
 /* N2: max over saved times of each species (what identify_next_seeds reads,
  * src/exploration/explore_utils.jl:344-351), reduced on the device. */
 int kin_solution_max(const kin_network* h, double* out_umax);
+
+/* Diagnostic: one Newton-matrix solve on the device, (I - c*J(u)) x = b with the current rates,
+ * through exactly the factorisation / substitution kernels kin_solve uses (what KLU does for
+ * CVODE in the reference's documented setup, docs/src/getting-started.md:69). */
+int kin_newton_solve(kin_network* h, double c, const double* u, const double* b, double* x);
 
 /* ---- device / build information ------------------------------------------------------- */
 int kin_device_count(int* n);

@@ -21,9 +21,9 @@ RETCODE_NAMES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable"}
 SYMBOLS = [
     "kin_network_create", "kin_network_destroy", "kin_network_sizes", "kin_last_error",
     "kin_set_rates", "kin_get_rates", "kin_set_arrhenius", "kin_rates_at", "kin_arrhenius_eval",
-    "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev", "kin_rhs_batched_reserve",
+    "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev",
     "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solution_size",
-    "kin_solution_copy", "kin_solution_max", "kin_device_count", "kin_set_device", "kin_version",
+    "kin_solution_copy", "kin_solution_max", "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
 ]
 
 
@@ -77,8 +77,7 @@ def lib():
         L.kin_rate_table.argtypes = [c_void_p, PD, c_int64, PD]
         L.kin_rhs.argtypes = [c_void_p, PD, PD]
         L.kin_rhs_batched.argtypes = [c_void_p, c_int64, PD, PD, PD]
-        L.kin_rhs_batched_dev.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
-        L.kin_rhs_batched_reserve.argtypes = [c_void_p, c_int64]
+        L.kin_rhs_batched_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         L.kin_jac_nnz.argtypes = [c_void_p, P64]
         L.kin_jac_pattern.argtypes = [c_void_p, P64, P64, c_int]
         L.kin_jac_values.argtypes = [c_void_p, PD, PD]
@@ -87,6 +86,7 @@ def lib():
         L.kin_solution_size.argtypes = [c_void_p, P64, P64]
         L.kin_solution_copy.argtypes = [c_void_p, PD, PD]
         L.kin_solution_max.argtypes = [c_void_p, PD]
+        L.kin_newton_solve.argtypes = [c_void_p, c_double, PD, PD, PD]
         L.kin_device_count.argtypes = [POINTER(c_int)]
         L.kin_set_device.argtypes = [c_int]
         _lib = L
@@ -199,12 +199,9 @@ class HipNetwork:
         self._chk(lib().kin_rhs_batched(self._h, B, _pd(u), _pd(k), _pd(du)))
         return du
 
-    def rhs_batched_reserve(self, B):
-        self._chk(lib().kin_rhs_batched_reserve(self._h, int(B)))
-
-    def rhs_batched_dev(self, B, ldb, d_u, d_k, d_du, stream=0):
-        """Device pointers (ints), state-contiguous layouts; only enqueues."""
-        self._chk(lib().kin_rhs_batched_dev(self._h, int(B), int(ldb), c_void_p(d_u), c_void_p(d_k) if d_k else None,
+    def rhs_batched_dev(self, B, d_u, d_k, d_du, stream=0):
+        """Device pointers (ints), state-major u[b][N], k[b][R] or 0, du[b][N]; only enqueues."""
+        self._chk(lib().kin_rhs_batched_dev(self._h, int(B), c_void_p(d_u), c_void_p(d_k) if d_k else None,
                                             c_void_p(d_du), c_void_p(stream) if stream else None))
 
     def jac_pattern(self, index_base=0):
@@ -248,6 +245,13 @@ class HipNetwork:
         if n_saved.value:
             self._chk(lib().kin_solution_copy(self._h, _pd(t), _pd(u)))
         return t, u, rc.value, stats.as_dict(), st
+
+    def newton_solve(self, c, u, b):
+        """(I - c J(u)) x = b through the solver's on-device LU (diagnostic)."""
+        u, b = _f64(u), _f64(b)
+        x = np.empty(self.n)
+        self._chk(lib().kin_newton_solve(self._h, float(c), _pd(u), _pd(b), _pd(x)))
+        return x
 
     def solution_max(self):
         out = np.empty(self.n)

@@ -23,12 +23,6 @@ void kin_network::jac_dev(const double* d_u, double* d_vals) {
   launch_segsum(jac_plan.view(), SEG_COEF_SET, dr.p, d_vals, SegExtra{}, stream);
 }
 
-void kin_network::ensure_batched(int64_t ldb) {
-  if (ldb <= b_cap) return;
-  b_rate.alloc((size_t)host.R * ldb);
-  b_cap = ldb;
-}
-
 #define KIN_TRY(h) try {
 #define KIN_CATCH(h)                                                        \
   }                                                                         \
@@ -81,13 +75,17 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     hipStream_t s = h->stream;
     h->x0.upload(N.x0, s); h->x1.upload(N.x1, s);
     h->sp_ptr.upload(N.sp_ptr, s); h->sp_rxn.upload(N.sp_rxn, s); h->sp_coef.upload(N.sp_coef, s);
-    // rows of the batched gather, longest first
-    std::vector<int32_t> order(N.N);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-      return N.sp_ptr[a + 1] - N.sp_ptr[a] > N.sp_ptr[b + 1] - N.sp_ptr[b];
-    });
-    h->row_order.upload(order, s);
+    if (N.N < 65535) {  // packed 16-byte records of the batched sweep
+      std::vector<uint32_t> rec((size_t)4 * N.R);
+      for (int64_t r = 0; r < N.R; r++) {
+        auto s16 = [](int32_t v) { return v < 0 ? 0xffffu : (uint32_t)v; };
+        rec[4 * r + 0] = s16(N.x0[r]) | (s16(N.x1[r]) << 16);
+        rec[4 * r + 1] = s16(N.slot_sp[4 * r + 0]) | (s16(N.slot_sp[4 * r + 1]) << 16);
+        rec[4 * r + 2] = s16(N.slot_sp[4 * r + 2]) | (s16(N.slot_sp[4 * r + 3]) << 16);
+        rec[4 * r + 3] = (uint32_t)N.slot_co[r];
+      }
+      h->sweep_rec.upload(rec, s);
+    }
     h->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);
     h->jac_plan.upload(build_seg_plan(N.nnz(), N.jc_ptr.data(), nullptr, N.jc_src.data(), nullptr, N.jc_coef.data(), false), s);
     h->k.alloc(N.R); h->rate.alloc(N.R); h->dr.alloc(2 * N.R + 2);
@@ -203,25 +201,15 @@ int kin_rhs(kin_network* h, const double* u, double* du) {
   KIN_CATCH(h)
 }
 
-int kin_rhs_batched_reserve(kin_network* h, int64_t B) {
+int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const double* d_k, double* d_du, void* stream) {
   if (!h) return KIN_ERR_INVALID_ARG;
   KIN_TRY(h)
   require(B > 0, ERR_INVALID_ARG, "B must be positive");
-  h->ensure_batched(ceil_div(B, 8) * 8);
-  KIN_CATCH(h)
-}
-
-int kin_rhs_batched_dev(kin_network* h, int64_t B, int64_t ldb, const double* d_u, const double* d_k, double* d_du,
-                        void* stream) {
-  if (!h) return KIN_ERR_INVALID_ARG;
-  KIN_TRY(h)
-  require(B > 0 && ldb >= B && ldb % 8 == 0, ERR_INVALID_ARG, "need B > 0, ldb >= B, ldb % 8 == 0");
   require(d_u && d_du, ERR_INVALID_ARG, "null device buffer");
   require(d_k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
-  require(ldb <= h->b_cap, ERR_STATE, "call kin_rhs_batched_reserve(B) first (no allocation inside the sweep)");
+  require(h->host.N < 65535, ERR_UNSUPPORTED, "batched sweep packs species ids in 16 bits (N < 65535)");
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  launch_rates_batched(h->host.R, B, ldb, d_k, h->k.p, d_u, h->x0.p, h->x1.p, h->b_rate.p, s);
-  launch_gather_batched(h->host.N, B, ldb, h->sp_ptr.p, h->sp_rxn.p, h->sp_coef.p, h->row_order.p, h->b_rate.p, d_du, s);
+  launch_sweep(h->host.N, h->host.R, B, h->sweep_rec.p, d_u, d_k, h->k.p, d_du, s);
   KIN_CATCH(h)
 }
 
@@ -230,28 +218,14 @@ int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k,
   KIN_TRY(h)
   require(B > 0 && u && du, ERR_INVALID_ARG, "bad arguments");
   require(k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
-  const int64_t N = h->host.N, R = h->host.R, ldb = ceil_div(B, 8) * 8;
+  require(h->host.N < 65535, ERR_UNSUPPORTED, "batched sweep packs species ids in 16 bits (N < 65535)");
+  const int64_t N = h->host.N, R = h->host.R;
   hipStream_t s = h->stream;
-  h->ensure_batched(ldb);
-  h->b_u.alloc((size_t)N * ldb); h->b_du.alloc((size_t)N * ldb);
-  h->b_stage.alloc((size_t)B * std::max(N, R));
-  // host layout [b][N] -> device layout [N][ldb]
-  KIN_HIP(hipMemsetAsync(h->b_u.p, 0, (size_t)N * ldb * sizeof(double), s));
-  h->b_stage.upload(u, (size_t)B * N, s);
-  launch_transpose(B, N, h->b_stage.p, N, h->b_u.p, ldb, s);
-  const double* dk = nullptr;
-  if (k) {
-    h->b_k.alloc((size_t)R * ldb);
-    KIN_HIP(hipMemsetAsync(h->b_k.p, 0, (size_t)R * ldb * sizeof(double), s));
-    KIN_HIP(hipStreamSynchronize(s));  // b_stage is reused
-    h->b_stage.upload(k, (size_t)B * R, s);
-    launch_transpose(B, R, h->b_stage.p, R, h->b_k.p, ldb, s);
-    dk = h->b_k.p;
-  }
-  launch_rates_batched(R, B, ldb, dk, h->k.p, h->b_u.p, h->x0.p, h->x1.p, h->b_rate.p, s);
-  launch_gather_batched(N, B, ldb, h->sp_ptr.p, h->sp_rxn.p, h->sp_coef.p, h->row_order.p, h->b_rate.p, h->b_du.p, s);
-  launch_transpose(N, B, h->b_du.p, ldb, h->b_stage.p, N, s);
-  h->b_stage.download(du, (size_t)B * N, s);
+  h->b_u.upload(u, (size_t)B * N, s);
+  h->b_du.alloc((size_t)B * N);
+  if (k) h->b_k.upload(k, (size_t)B * R, s);
+  launch_sweep(N, R, B, h->sweep_rec.p, h->b_u.p, k ? h->b_k.p : nullptr, h->k.p, h->b_du.p, s);
+  h->b_du.download(du, (size_t)B * N, s);
   KIN_HIP(hipStreamSynchronize(s));
   KIN_CATCH(h)
 }
@@ -292,6 +266,15 @@ int kin_solve(kin_network* h, const kin_params* params, const double* u0, const 
   if (n_saved) *n_saved = h->n_saved;
   if (retcode) *retcode = rc;
   if (rc != KIN_RETCODE_SUCCESS) throw KinError(ERR_SOLVE_FAILED, "ODE solution failed.");
+  KIN_CATCH(h)
+}
+
+int kin_newton_solve(kin_network* h, double c, const double* u, const double* b, double* x) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(u && b && x, ERR_INVALID_ARG, "null buffer");
+  require(h->has_rates, ERR_STATE, "rates were never set");
+  newton_solve(h, c, u, b, x);
   KIN_CATCH(h)
 }
 

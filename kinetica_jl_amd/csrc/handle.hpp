@@ -15,7 +15,8 @@ struct kin_network {
   std::string err;
 
   // reaction tables
-  kin::DevBuf<int32_t> x0, x1, sp_ptr, sp_rxn, row_order;
+  kin::DevBuf<int32_t> x0, x1, sp_ptr, sp_rxn;
+  kin::DevBuf<uint32_t> sweep_rec;   // 4 words per reaction (kernels.hip: SweepRec)
   kin::DevBuf<float> sp_coef;
   kin::SegPlanDev rhs_plan, jac_plan;
 
@@ -29,8 +30,7 @@ struct kin_network {
   kin::DevBuf<double> u, du, rate, dr, jvals;
 
   // batched sweep workspace
-  kin::DevBuf<double> b_rate, b_u, b_k, b_du, b_stage;
-  int64_t b_cap = 0;
+  kin::DevBuf<double> b_u, b_k, b_du;
 
   // solver + stored solution (solver.cpp)
   std::unique_ptr<kin::Solver> solver;
@@ -42,5 +42,4 @@ struct kin_network {
   ~kin_network();
   void rhs_dev(const double* d_u, double* d_du);        // du = f(u) with current k
   void jac_dev(const double* d_u, double* d_vals);      // CSR values with current k
-  void ensure_batched(int64_t ldb);
 };

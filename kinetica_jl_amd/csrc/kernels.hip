@@ -4,6 +4,8 @@
 // wave-uniform (scalar) index loads, fixed summation order and enough waves in flight.
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace kin {
 
 // ------------------------------------------------------------------------------------------
@@ -213,110 +215,101 @@ void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const doubl
 }
 
 // ------------------------------------------------------------------------------------------
-// batched sweep, two passes over state-contiguous arrays (lanes = states, 2 states per lane)
-//   pass 1: rate[r][b] = k[r][b] * u[x0][b] * u[x1][b]       (reaction-major, streaming)
-//   pass 2: du[i][b]   = sum_e coef_e * rate[rxn_e][b]       (species-major, deterministic gather)
-// Reaction / species indices are wave-uniform, so they travel through the scalar cache.
+// batched RHS sweep: B independent states, state-major layouts u[b][N], k[b][R], du[b][N]
+// (the reference's own layout: sol.u is a Vector of Vectors).
+//
+// One 1024-thread workgroup owns one state at a time. The state's concentrations and its rate
+// accumulator live in LDS (2 x 8N bytes: 160 kB at N = 10k, the whole LDS of a CU), so HBM
+// sees exactly the algorithmic traffic: k[b][:] streamed once (coalesced 8 B/lane), u[b][:]
+// read once, du[b][:] written once. The packed reaction records (16 B: six 16-bit species
+// slots + four signed stoichiometric bytes) are shared by every state and stay L2 resident.
+// Species rates are accumulated with FP64 LDS atomics (ds_add_f64). For N too large for LDS
+// the kernel makes several passes over species tiles (du tile in LDS, u read through L1/L2).
 // ------------------------------------------------------------------------------------------
-constexpr int RB_RXN_PER_WAVE = 8;
-__global__ __launch_bounds__(256) void rates_batched_kernel(int R, int ldb, const double* __restrict__ k_rb,
-                                                            const double* __restrict__ k_r, const double* __restrict__ u,
-                                                            const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
-                                                            double* __restrict__ rate) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = (blockIdx.y * 64 + lane) * 2;            // two states per lane (16-byte accesses)
-  if (b >= ldb) return;
-  const int r0 = (blockIdx.x * 4 + wave) * RB_RXN_PER_WAVE;
-#pragma unroll
-  for (int j = 0; j < RB_RXN_PER_WAVE; j++) {
-    const int r = r0 + j;
-    if (r >= R) break;
-    const int32_t a = x0[r], c = x1[r];  // uniform -> s_load
-    double2 kv = k_rb ? *reinterpret_cast<const double2*>(k_rb + (size_t)r * ldb + b) : make_double2(k_r[r], k_r[r]);
-    const double2 ua = *reinterpret_cast<const double2*>(u + (size_t)a * ldb + b);
-    double2 out = make_double2(kv.x * ua.x, kv.y * ua.y);
-    if (c >= 0) {
-      const double2 uc = *reinterpret_cast<const double2*>(u + (size_t)c * ldb + b);
-      out.x *= uc.x; out.y *= uc.y;
+struct SweepRec { uint32_t ops, s01, s23; int32_t coef; };   // 0xFFFF = empty slot
+
+template <bool U_IN_LDS>
+__global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int B, int tile, int n_tiles,
+                                                         const SweepRec* __restrict__ rec, const double* __restrict__ u,
+                                                         const double* __restrict__ k_b, const double* __restrict__ k_1,
+                                                         double* __restrict__ du) {
+  extern __shared__ double lds[];
+  double* du_s = lds;
+  double* u_s = lds + tile;
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const double* ub = u + (size_t)b * N;
+    const double* kb = k_b ? k_b + (size_t)b * R : k_1;
+    double* dub = du + (size_t)b * N;
+    if (U_IN_LDS) {
+      for (int i = tid * 2; i < N; i += 2048) {
+        if (i + 1 < N) *reinterpret_cast<double2*>(u_s + i) = *reinterpret_cast<const double2*>(ub + i);
+        else u_s[i] = ub[i];
+      }
     }
-    *reinterpret_cast<double2*>(rate + (size_t)r * ldb + b) = out;
-  }
-}
-
-// one wavefront per (species, 128-state tile); long rows are walked by all 4 waves of the
-// workgroup and combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void gather_batched_kernel(int N, int ldb, const int32_t* __restrict__ sp_ptr,
-                                                             const int32_t* __restrict__ sp_rxn,
-                                                             const float* __restrict__ sp_coef,
-                                                             const int32_t* __restrict__ row_order,
-                                                             const double* __restrict__ rate, double* __restrict__ du) {
-  __shared__ double2 red[4][64];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = (blockIdx.y * 64 + lane) * 2;
-  const bool active = b < ldb;
-  // blockIdx.x enumerates rows in `row_order` (longest first so hub rows start early)
-  const int i = row_order[blockIdx.x];
-  const int32_t e0 = sp_ptr[i], e1 = sp_ptr[i + 1];
-  double2 acc = make_double2(0.0, 0.0);
-  if (active) {
-    for (int32_t e = e0 + wave; e < e1; e += 4) {
-      const int32_t r = sp_rxn[e];
-      const double c = (double)sp_coef[e];
-      const double2 v = *reinterpret_cast<const double2*>(rate + (size_t)r * ldb + b);
-      acc.x += c * v.x; acc.y += c * v.y;
+    for (int t = 0; t < n_tiles; t++) {
+      const int lo = t * tile, hi = min(N, lo + tile);
+      for (int i = tid; i < hi - lo; i += 1024) du_s[i] = 0.0;
+      __syncthreads();
+#pragma unroll 2
+      for (int r = tid; r < R; r += 1024) {
+        const SweepRec q = rec[r];
+        const double kk = kb[r];
+        const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
+        double rate = kk * (U_IN_LDS ? u_s[a] : ub[a]);
+        if (c != 0xffffu) rate *= (U_IN_LDS ? u_s[c] : ub[c]);
+        const uint32_t sl[4] = {q.s01 & 0xffffu, q.s01 >> 16, q.s23 & 0xffffu, q.s23 >> 16};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int cf = (int)(int8_t)((uint32_t)q.coef >> (8 * j));
+          const int sp = (int)sl[j];
+          if (cf != 0 && sp >= lo && sp < hi)
+            __hip_atomic_fetch_add(du_s + (sp - lo), (double)cf * rate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      __syncthreads();
+      for (int i = tid * 2; i < hi - lo; i += 2048) {
+        if (i + 1 < hi - lo && ((lo & 1) == 0)) *reinterpret_cast<double2*>(dub + lo + i) = *reinterpret_cast<double2*>(du_s + i);
+        else { dub[lo + i] = du_s[i]; if (i + 1 < hi - lo) dub[lo + i + 1] = du_s[i + 1]; }
+      }
+      __syncthreads();
     }
   }
-  red[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && active) {
-    double2 t = red[0][lane];
-#pragma unroll
-    for (int w = 1; w < 4; w++) { t.x += red[w][lane].x; t.y += red[w][lane].y; }
-    *reinterpret_cast<double2*>(du + (size_t)i * ldb + b) = t;
-  }
 }
 
-void launch_rates_batched(int64_t R, int64_t B, int64_t ldb, const double* k_rb, const double* k_r, const double* u,
-                          const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s) {
-  (void)B;
-  if (R == 0) return;
-  dim3 grid((unsigned)ceil_div(R, 4 * RB_RXN_PER_WAVE), (unsigned)ceil_div(ldb, 128));
-  hipLaunchKernelGGL(rates_batched_kernel, grid, dim3(256), 0, s, (int)R, (int)ldb, k_rb, k_r, u, x0, x1, rate);
-  KIN_HIP(hipGetLastError());
-}
-void launch_gather_batched(int64_t N, int64_t B, int64_t ldb, const int32_t* sp_ptr, const int32_t* sp_rxn,
-                           const float* sp_coef, const int32_t* row_order, const double* rate, double* du, hipStream_t s) {
-  (void)B;
-  dim3 grid((unsigned)N, (unsigned)ceil_div(ldb, 128));
-  hipLaunchKernelGGL(gather_batched_kernel, grid, dim3(256), 0, s, (int)N, (int)ldb, sp_ptr, sp_rxn, sp_coef, row_order, rate, du);
-  KIN_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------
-// tiled transpose (layout conversion of the host-buffer batched API)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const double* __restrict__ in, int ld_in,
-                                                        double* __restrict__ out, int ld_out) {
-  __shared__ double tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  for (int j = ty; j < 32; j += 8) {
-    const int r = r0 + j, c = c0 + tx;
-    if (r < rows && c < cols) tile[j][tx] = in[(size_t)r * ld_in + c];
+void launch_sweep(int64_t N, int64_t R, int64_t B, const void* rec, const double* u, const double* k_b, const double* k_1,
+                  double* du, hipStream_t s) {
+  if (B == 0) return;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0; hipDeviceProp_t pr;
+    KIN_HIP(hipGetDevice(&dev));
+    KIN_HIP(hipGetDeviceProperties(&pr, dev));
+    n_cu = pr.multiProcessorCount;
   }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    const int c = c0 + j, r = r0 + tx;
-    if (r < rows && c < cols) out[(size_t)c * ld_out + r] = tile[tx][j];
+  const size_t lds_max = 160 * 1024;
+  const int grid = (int)std::min<int64_t>(B, n_cu);
+  if ((size_t)(2 * N) * 8 <= lds_max) {
+    const int tile = (int)((N + 1) / 2 * 2);
+    const size_t smem = (size_t)(tile + N) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+      KIN_HIP(hipFuncSetAttribute((const void*)sweep_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(sweep_lds_kernel<true>, dim3(grid), dim3(1024), smem, s, (int)N, (int)R, (int)B, tile, 1,
+                       (const SweepRec*)rec, u, k_b, k_1, du);
+  } else {
+    const int tile = 16 * 1024;   // 128 kB of accumulators per pass
+    const int n_tiles = (int)ceil_div(N, tile);
+    static bool attr_done2 = false;
+    if (!attr_done2) {
+      KIN_HIP(hipFuncSetAttribute((const void*)sweep_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+      attr_done2 = true;
+    }
+    hipLaunchKernelGGL(sweep_lds_kernel<false>, dim3(grid), dim3(1024), (size_t)tile * 8, s, (int)N, (int)R, (int)B, tile,
+                       n_tiles, (const SweepRec*)rec, u, k_b, k_1, du);
   }
-}
-
-void launch_transpose(int64_t rows, int64_t cols, const double* in, int64_t ld_in, double* out, int64_t ld_out, hipStream_t s) {
-  if (rows == 0 || cols == 0) return;
-  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, (int)rows, (int)cols, in, (int)ld_in, out, (int)ld_out);
   KIN_HIP(hipGetLastError());
 }
 

@@ -49,12 +49,8 @@ void launch_arrhenius(int64_t n, const double* Ea, const double* A, int has_kmax
 void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const double* A, int has_kmax, double k_max,
                        double t_mult, const double* T, double* table, hipStream_t s);
 
-// batched sweep, state-contiguous layouts (see kin_rhs_batched_dev)
-void launch_rates_batched(int64_t R, int64_t B, int64_t ldb, const double* k_rb, const double* k_r, const double* u,
-                          const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s);
-void launch_gather_batched(int64_t N, int64_t B, int64_t ldb, const int32_t* sp_ptr, const int32_t* sp_rxn,
-                           const float* sp_coef, const int32_t* row_order, const double* rate, double* du, hipStream_t s);
-// out[c][r] = in[r][c] for a rows x cols row-major matrix (ld = leading dims)
-void launch_transpose(int64_t rows, int64_t cols, const double* in, int64_t ld_in, double* out, int64_t ld_out, hipStream_t s);
+// batched sweep over B states, state-major layouts (see kin_rhs_batched_dev); rec = packed 16-byte records
+void launch_sweep(int64_t N, int64_t R, int64_t B, const void* rec, const double* u, const double* k_b, const double* k_1,
+                  double* du, hipStream_t s);
 
 }  // namespace kin

@@ -509,6 +509,31 @@ void solution_max(kin_network* h, double* out_umax) {
   KIN_HIP(hipStreamSynchronize(h->stream));
 }
 
+// scatter b into the permuted solve vector / gather x back (diagnostic path only)
+void newton_solve(kin_network* h, double c, const double* u, const double* b, double* x) {
+  if (!h->solver) h->solver.reset(new Solver(h));
+  Solver& S = *h->solver;
+  hipStream_t s = h->stream;
+  const int N = S.N;
+  S.y.upload(u, N, s);
+  S.eval_jac(S.y.p);
+  S.lu.factor(c, S.jv.p, s);
+  std::vector<int32_t> yl(N), xl(N);
+  S.lu.yloc.download(yl.data(), N, s);
+  S.lu.xloc.download(xl.data(), N, s);
+  std::vector<double> W(S.lu.w_size);
+  KIN_HIP(hipStreamSynchronize(s));
+  std::vector<double> stage(N);
+  // the solve vectors live at the tail of W: write b there element by element
+  std::vector<double> tail(S.lu.w_size - S.lu.off_y, 0.0);
+  for (int i = 0; i < N; i++) tail[yl[i] - S.lu.off_y] = b[i];
+  KIN_HIP(hipMemcpyAsync(S.lu.W.p + S.lu.off_y, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  S.lu.solve(nullptr, s);
+  KIN_HIP(hipMemcpyAsync(tail.data(), S.lu.W.p + S.lu.off_y, tail.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  KIN_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < N; i++) x[i] = tail[xl[i] - S.lu.off_y];
+}
+
 }  // namespace kin
 
 kin_network::kin_network() {}

@@ -11,5 +11,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
                 const double* T_stops, const double* k_table, int64_t n_stops, kin_stats* stats);
 // max over saved times per species, reduced on the device
 void solution_max(kin_network* h, double* out_umax);
+// diagnostic: (I - c J(u)) x = b through the solver's LU
+void newton_solve(kin_network* h, double c, const double* u, const double* b, double* x);
 
 }  // namespace kin
