@@ -138,6 +138,69 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
         if (kv.second != 0) jcs.push_back({kv.first, ops[w], (int32_t)(2 * r + w), (float)kv.second});
   }
 
+  // ---- reversible-pair records (batched sweep). A reaction is "plain" when no species sits on
+  // both sides; two plain reactions pair up when each one's net stoichiometry is the negative
+  // of the other's and their operand lists are each other's product lists.
+  if (N < 65535) {
+    auto s16 = [](int32_t v) { return v < 0 ? 0xffffu : (uint32_t)v; };
+    struct Key { int32_t sp[4]; int8_t co[4]; bool operator<(const Key& o) const {
+      for (int j = 0; j < 4; j++) { if (sp[j] != o.sp[j]) return sp[j] < o.sp[j]; if (co[j] != o.co[j]) return co[j] < o.co[j]; }
+      return false; } };
+    auto key_of = [&](int64_t r, int sign, bool& plain) {
+      Key kq; plain = true;
+      int sumneg = 0;
+      for (int j = 0; j < 4; j++) {
+        kq.sp[j] = H.slot_sp[4 * r + j];
+        int c = (int)(int8_t)((uint32_t)H.slot_co[r] >> (8 * j));
+        kq.co[j] = (int8_t)(sign * c);
+        if (kq.sp[j] >= 0 && c < 0) sumneg += -c;
+      }
+      // plain: the operands are exactly the negative-coefficient slots with matching multiplicity
+      int nops = H.x1[r] >= 0 ? 2 : 1;
+      if (sumneg != nops) plain = false;
+      for (int j = 0; j < 4 && plain; j++) {
+        int c = (int)(int8_t)((uint32_t)H.slot_co[r] >> (8 * j));
+        if (kq.sp[j] >= 0 && c < 0) {
+          int cnt = (H.x0[r] == kq.sp[j]) + (H.x1[r] == kq.sp[j]);
+          if (cnt != -c) plain = false;
+        }
+      }
+      // the reverse's operands (positive slots) must also number 1 or 2
+      int sumpos = 0;
+      for (int j = 0; j < 4; j++) { int c = (int)(int8_t)((uint32_t)H.slot_co[r] >> (8 * j)); if (c > 0) sumpos += c; }
+      if (sumpos < 1 || sumpos > 2) plain = false;
+      return kq;
+    };
+    std::map<Key, std::vector<int32_t>> waiting;   // forward key -> unmatched reactions
+    std::vector<int32_t> partner(R, -1);
+    std::vector<char> is_plain(R, 0);
+    for (int64_t r = 0; r < R; r++) {
+      bool plain;
+      Key fwd = key_of(r, +1, plain);
+      is_plain[r] = plain;
+      if (!plain) continue;
+      Key rev = key_of(r, -1, plain);
+      auto it = waiting.find(rev);
+      if (it != waiting.end() && !it->second.empty()) {
+        int32_t q = it->second.back(); it->second.pop_back();
+        partner[r] = q; partner[q] = (int32_t)r;
+      } else waiting[fwd].push_back((int32_t)r);
+    }
+    for (int64_t r = 0; r < R; r++) {
+      if (partner[r] >= 0 && partner[r] < r) continue;   // emitted with its forward
+      H.pair_rec.push_back(s16(H.slot_sp[4 * r + 0]) | (s16(H.slot_sp[4 * r + 1]) << 16));
+      H.pair_rec.push_back(s16(H.slot_sp[4 * r + 2]) | (s16(H.slot_sp[4 * r + 3]) << 16));
+      H.pair_rec.push_back((uint32_t)H.slot_co[r]);
+      // unpaired, non-plain records carry explicit operands; plain ones derive them from the signs
+      H.pair_rec.push_back(is_plain[r] ? 0xffffffffu : (s16(H.x0[r]) | (s16(H.x1[r]) << 16)));
+      H.pair_k.push_back((int32_t)r);
+      H.pair_k.push_back(partner[r]);
+    }
+    H.pairs_adjacent = (R % 2 == 0) && (H.n_pairs() * 2 == R);
+    for (int64_t p = 0; p < H.n_pairs() && H.pairs_adjacent; p++)
+      if (H.pair_k[2 * p] != 2 * p || H.pair_k[2 * p + 1] != 2 * p + 1) H.pairs_adjacent = false;
+  }
+
   // species-major CSR
   H.sp_ptr.assign(N + 1, 0);
   for (int64_t i = 0; i < N; i++) H.sp_ptr[i + 1] = H.sp_ptr[i] + (int32_t)by_species[i].size();

@@ -53,6 +53,16 @@ struct NetworkHost {
   // per reaction: up to 4 update slots (distinct species with non-zero net stoichiometry)
   std::vector<int32_t> slot_sp;   // 4*R, species id or -1
   std::vector<int32_t> slot_co;   // R, four signed bytes packed
+  // reversible-pair records of the batched sweep: reaction `kf` and its exact reverse `kr`
+  // (kr = -1: no partner) share one record: <= 4 species slots with the FORWARD net
+  // stoichiometry; forward rate = k[kf] * prod_{coef<0} u^|coef|, reverse rate =
+  // k[kr] * prod_{coef>0} u^|coef|, every slot receives coef * (forward - reverse).
+  // Reactions with a species on both sides (colliders) stay unpaired, flagged by bit 31 of
+  // pair_k[2p+1]'s companion word pair_ops (explicit operands).
+  std::vector<uint32_t> pair_rec;  // 4 words per record: s01, s23, coefs, ops (explicit operands for unpaired records)
+  std::vector<int32_t> pair_k;     // 2 per record: kf, kr
+  bool pairs_adjacent = false;     // record p pairs reactions (2p, 2p+1): k streams as double2, no index load
+  int64_t n_pairs() const { return (int64_t)pair_k.size() / 2; }
   // species-major CSR: du[i] = sum_e sp_coef[e] * rate[sp_rxn[e]]
   std::vector<int32_t> sp_ptr, sp_rxn;
   std::vector<float> sp_coef;
