@@ -95,7 +95,9 @@ struct Solver {
 
   void set_tols(double a, double r) {
     atol = a; rtol = r;
-    newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, std::min(0.03, std::sqrt(rtol)));
+    // corrector tolerance of ode15s / CVODE: a fixed fraction of the error weight (0.05), not
+    // RADAU5's sqrt(rtol); see oracle/bdf.py (set_tols) for the rationale
+    newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, 0.05);
   }
 
   void sync_ctrl() {

@@ -244,7 +244,9 @@ __global__ __launch_bounds__(1024) void bdf_newton_kernel(int N, int iter, int m
     ctrl->n_iter = iter + 1;
     ctrl->dy_norm = dy_norm;
     if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nbad > 0.0; }
-    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol)) { ctrl->newton_done = 1; ctrl->converged = 1; }
+    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) || (!have_rate && dy_norm < tol)) {
+      ctrl->newton_done = 1; ctrl->converged = 1;   // (first-iteration acceptance as in ode15s / CVODE)
+    }
     else {
       ctrl->dy_norm_old = dy_norm;
       if (iter == maxit - 1) { ctrl->newton_done = 1; ctrl->converged = 0; }

@@ -1,0 +1,420 @@
+"""Host-side mirror of the reference's solve interface (src/solving/*.jl, src/analysis/io.jl):
+ODESimulationParams / StaticODESolve / VariableODESolve / solve_network / ODESolveOutput, the
+kinetic calculators, RxFilter and the CRN containers the solve reads. Same names, argument
+meaning and error behaviour as the reference; all numerics go through the C ABI
+(include/kinetica_hip.h) into libkinetica_hip.so - there is no CPU path here.
+
+A Julia user keeps the reference's own types and calls the same library through the `ccall`
+shim in INTEGRATION.md; this module is the runnable twin used by the parity tests.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import capi
+from .conditions import (ConditionSet, get_initial_conditions, get_static_conditions, get_tstops, isstatic,
+                         isvariable, solve_variable_conditions)
+from .synth import FlatNetwork, from_lists
+
+__all__ = ["SpeciesData", "RxData", "RxFilter", "get_filter_mask", "DummyKineticCalculator",
+           "PrecalculatedArrheniusCalculator", "PrecalculatedLindemannCalculator", "allows_continuous",
+           "has_conditions", "setup_network", "ODESimulationParams", "StaticODESolve", "VariableODESolve",
+           "solve_network", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
+           "get_max_rates", "get_initial_rates", "calculate_discrete_rates"]
+
+_T_UNIT = {  # src/utils.jl:77-97
+    "picoseconds": 1.0e-12, "ps": 1.0e-12, "nanoseconds": 1.0e-9, "ns": 1.0e-9, "microseconds": 1.0e-6, "us": 1.0e-6,
+    "milliseconds": 1.0e-3, "ms": 1.0e-3, "seconds": 1.0, "s": 1.0, "minutes": 60.0, "mins": 60.0, "hours": 3600.0,
+    "hrs": 3600.0, "days": 86400.0, "months": 2.6297368e06, "mts": 2.6297368e06, "years": 3.15576e07, "yrs": 3.15576e07,
+}
+
+
+def tconvert(*args):
+    """tconvert(t, from, to) / tconvert(from, to) (src/utils.jl:21-43)."""
+    t, fu, tu = (1.0, *args) if len(args) == 2 else args
+    if fu not in _T_UNIT or tu not in _T_UNIT:
+        raise RuntimeError("Unknown unit specified in time conversion!")
+    return float(t) * _T_UNIT[fu] / _T_UNIT[tu]
+
+
+# ---- CRN containers (src/exploration/network.jl:1-8, 193-203): only what the solve reads -------
+@dataclass
+class SpeciesData:
+    toInt: Dict[str, int]      # SMILES -> species id (1-based, as in the reference)
+    toStr: Dict[int, str]
+    n: int
+
+    @classmethod
+    def from_names(cls, names: Sequence[str]):
+        return cls({s: i + 1 for i, s in enumerate(names)}, {i + 1: s for i, s in enumerate(names)}, len(names))
+
+
+@dataclass
+class RxData:
+    nr: int
+    id_reacs: List[List[int]]      # 1-based species ids
+    id_prods: List[List[int]]
+    stoic_reacs: List[List[int]]
+    stoic_prods: List[List[int]]
+    dH: Optional[List[float]] = None
+
+    @classmethod
+    def from_flat(cls, net: FlatNetwork):
+        ir, ip, sr, sp = [], [], [], []
+        for r in range(net.n_reactions):
+            re, pr = net.reaction(r)
+            ir.append([int(s) + 1 for s, _ in re]); sr.append([int(c) for _, c in re])
+            ip.append([int(s) + 1 for s, _ in pr]); sp.append([int(c) for _, c in pr])
+        return cls(net.n_reactions, ir, ip, sr, sp)
+
+    def splice(self, rids):
+        """splice!(rd, rids): removes the reactions at the (0-based here) positions `rids`
+        (src/exploration/network.jl:514-529)."""
+        kill = set(int(i) for i in rids)
+        keep = [i for i in range(self.nr) if i not in kill]
+        for name in ("id_reacs", "id_prods", "stoic_reacs", "stoic_prods"):
+            setattr(self, name, [getattr(self, name)[i] for i in keep])
+        if self.dH is not None:
+            self.dH = [self.dH[i] for i in keep]
+        self.nr = len(keep)
+
+    def flat(self, n_species):
+        """Flat arrays for kin_network_create (index_base = 1)."""
+        rp, pp = [0], [0]
+        for r in range(self.nr):
+            rp.append(rp[-1] + len(self.id_reacs[r])); pp.append(pp[-1] + len(self.id_prods[r]))
+        cat = lambda L: np.array([x for row in L for x in row], dtype=np.int64)
+        return (n_species, np.array(rp, np.int64), cat(self.id_reacs), cat(self.stoic_reacs),
+                np.array(pp, np.int64), cat(self.id_prods), cat(self.stoic_prods))
+
+
+# ---- reaction filters (src/solving/filters.jl) ----------------------------------------------------
+class RxFilter:
+    def __init__(self, filters: Optional[List[Callable]] = None, keep_filtered: bool = False):
+        self.filters = [lambda sd, rd: [False] * rd.nr] if filters is None else filters
+        self.keep_filtered = keep_filtered
+
+
+def get_filter_mask(rf: RxFilter, sd, rd):
+    """filters.jl:40-52"""
+    if len(rf.filters) == 0:
+        raise RuntimeError("RxFilter has not filter functions defined.")
+    mask = np.zeros(rd.nr, bool)
+    for f in rf.filters:
+        mask |= np.asarray(f(sd, rd), dtype=bool)
+    return ~mask if rf.keep_filtered else mask
+
+
+# ---- kinetic calculators (src/solving/calculator.jl) ------------------------------------------------
+class AbstractKineticCalculator:
+    pass
+
+
+class DummyKineticCalculator(AbstractKineticCalculator):
+    """calculator.jl:72-158: always returns the stored rates (scaled to the time unit; note the
+    cap is applied BEFORE t_mult here, calculator.jl:130-132)."""
+
+    def __init__(self, rates, k_max=None, t_unit="s"):
+        self.rates = np.asarray(rates, dtype=float).copy()
+        self.k_max, self.t_unit, self.t_mult = k_max, t_unit, tconvert(t_unit, "s")
+
+    def __call__(self, T=None, V=None):
+        if T is None and V is None:
+            raise TypeError("DummyKineticCalculator needs T and/or V")   # MethodError in the reference
+        if self.k_max is None:
+            return self.rates * self.t_mult
+        return 1.0 / ((1.0 / self.k_max) + (1.0 / self.rates)) * self.t_mult
+
+    def splice(self, rids):
+        self.rates = np.delete(self.rates, np.asarray(rids, dtype=int))
+
+
+class PrecalculatedArrheniusCalculator(AbstractKineticCalculator):
+    """calculator.jl:164-238. k = A exp(-Ea/RT) N_A t_mult, optionally capped; evaluated on the device
+    (kin_arrhenius_eval), so the cutoff decision and the solve see the same numbers."""
+
+    def __init__(self, Ea, A, k_max=None, t_unit="s"):
+        self.Ea = np.asarray(Ea, dtype=float).copy()
+        self.A = np.asarray(A, dtype=float).copy()
+        self.k_max, self.t_unit, self.t_mult = k_max, t_unit, tconvert(t_unit, "s")
+
+    def __call__(self, T):
+        return capi.arrhenius_eval(self.Ea, self.A, float(T), self.k_max, self.t_mult)
+
+    def splice(self, rids):
+        rids = np.asarray(rids, dtype=int)
+        self.Ea = np.delete(self.Ea, rids)
+        self.A = np.delete(self.A, rids)
+
+
+class PrecalculatedLindemannCalculator(AbstractKineticCalculator):
+    """calculator.jl:244-320: a stub in the reference (its functor throws), mirrored as such."""
+
+    def __init__(self, Ea, A_0, A_inf, k_max=None, t_unit="s"):
+        self.Ea, self.A_0, self.A_inf = map(lambda x: np.asarray(x, dtype=float), (Ea, A_0, A_inf))
+        self.k_max, self.t_unit, self.t_mult = k_max, t_unit, tconvert(t_unit, "s")
+
+    def __call__(self, **kw):
+        raise RuntimeError("Lindemann calculator is not implemented yet.")   # calculator.jl:308, 313
+
+
+def setup_network(sd, rd, calc):
+    """setup_network! (calculator.jl:102-106, 200-204)"""
+    if isinstance(calc, DummyKineticCalculator):
+        if len(calc.rates) != rd.nr:
+            raise ValueError(f"Number of rates ({len(calc.rates)}) does not match number of reactions in `RxData` ({rd.nr})")
+    elif isinstance(calc, PrecalculatedArrheniusCalculator):
+        if len(calc.Ea) != rd.nr or len(calc.A) != rd.nr:
+            raise ValueError(f"Number of parameters (Ea: {len(calc.Ea)}, A: {len(calc.A)}) does not match number of reactions in `RxData` ({rd.nr})")
+
+
+def has_conditions(calc, symbols):
+    """calculator.jl:154-156, 234-236"""
+    allowed = {"T", "V"} if isinstance(calc, DummyKineticCalculator) else {"T"}
+    return all(str(s) in allowed for s in symbols)
+
+
+def allows_continuous(calc):
+    """calculator.jl:158, 238"""
+    return isinstance(calc, (DummyKineticCalculator, PrecalculatedArrheniusCalculator))
+
+
+def _call_calc(calc, conds: dict):
+    if isinstance(calc, DummyKineticCalculator):
+        return calc(T=conds.get("T"), V=conds.get("V"))
+    return calc(T=conds["T"])
+
+
+# ---- ODESimulationParams (src/solving/params.jl) ---------------------------------------------------
+@dataclass
+class ODESimulationParams:
+    tspan: tuple
+    u0: Union[Dict[str, float], Sequence[float]]
+    solver: object = None          # accepted for interface parity; the integrator is the library's BDF
+    jac: bool = True
+    sparse: bool = True
+    abstol: float = 1.0e-10
+    reltol: float = 1.0e-8
+    adaptive_tols: bool = True
+    update_tols: bool = False
+    solve_chunks: bool = True
+    solve_chunkstep: float = 1e-3
+    maxiters: int = 100000
+    ban_negatives: bool = False
+    progress: bool = False
+    save_interval: Optional[float] = None
+    low_k_cutoff: Union[float, str] = "auto"     # :auto / :none / number
+    low_k_maxconc: float = 2.0
+    allow_short_u0: bool = False
+
+    def __post_init__(self):
+        # validation of the keyword constructor (params.jl:77-104); ArgumentError -> ValueError
+        if self.tspan[0] >= self.tspan[1]:
+            raise ValueError(f"Invalid time span: Start = {self.tspan[0]}, End = {self.tspan[1]}")
+        if isinstance(self.low_k_cutoff, str):
+            if self.low_k_cutoff not in ("auto", "none"):
+                raise ValueError("low_k_cutoff must be a numerical value or one of [:auto, :none]")
+        elif self.low_k_cutoff < 0:
+            raise ValueError("low_k_cutoff must be a positive number or one of [:auto, :none]")
+        if self.solve_chunks:
+            q = self.tspan[1] / self.solve_chunkstep
+            if q != math.floor(q):
+                raise ValueError("Simulation timespan is not divisible by requested chunkwise simulation step size")
+        if self.solve_chunks and self.save_interval is not None and self.save_interval > self.solve_chunkstep:
+            raise ValueError("Solution save interval must be less than chunkwise simulation step size")
+
+    def to_kin_params(self):
+        return capi.KinParams(tspan0=self.tspan[0], tspan1=self.tspan[1], abstol=self.abstol, reltol=self.reltol,
+                              adaptive_tols=int(self.adaptive_tols), update_tols=int(self.update_tols),
+                              solve_chunks=int(self.solve_chunks), ban_negatives=int(self.ban_negatives),
+                              solve_chunkstep=self.solve_chunkstep, maxiters=int(self.maxiters),
+                              save_interval=-1.0 if self.save_interval is None else self.save_interval)
+
+
+# ---- solve methods (src/solving/methods.jl:7-58) -----------------------------------------------------
+class StaticODESolve:
+    def __init__(self, pars, conditions, calculator, filter=None):
+        if not isstatic(conditions):
+            raise ValueError("All conditions must be static to run a StaticODESolve.")
+        if not has_conditions(calculator, conditions.symbols):
+            raise ValueError("Calculator does not support all of the provided conditions.")
+        self.pars, self.conditions, self.calculator = pars, conditions, calculator
+        self.filter = RxFilter() if filter is None else filter
+
+
+class VariableODESolve:
+    def __init__(self, pars, conditions, calculator, filter=None):
+        if not has_conditions(calculator, conditions.symbols):
+            raise ValueError("Calculator does not support all of the provided conditions.")
+        if not conditions.discrete_updates and not allows_continuous(calculator):
+            raise ValueError("Calculator does not support continuous rate updates in simulations.")
+        self.pars, self.conditions, self.calculator = pars, conditions, calculator
+        self.filter = RxFilter() if filter is None else filter
+
+
+# ---- pre-solve pipeline (src/solving/solve_utils.jl) ---------------------------------------------------
+def get_max_rates(conditions, calculator):
+    """solve_utils.jl:19-54: enumerate min/max corners of the variable conditions (binary order,
+    minimum first), keep the corner with the greatest mean rate (first maximum)."""
+    static = get_static_conditions(conditions)
+    var = [(s, p.minimum(), p.maximum()) for s, p in zip(conditions.symbols, conditions.profiles) if not isstatic(p)]
+    if not var:
+        return _call_calc(calculator, static)
+    best, best_mean = None, -math.inf
+    for bits in range(2 ** len(var)):
+        conds = dict(static)
+        for j, (s, lo, hi) in enumerate(var):
+            conds[s] = hi if (bits >> (len(var) - 1 - j)) & 1 else lo
+        k = _call_calc(calculator, conds)
+        if np.mean(k) > best_mean:
+            best, best_mean = k, np.mean(k)
+    return best
+
+
+def get_initial_rates(conditions, calculator):
+    """solve_utils.jl:62-73"""
+    return _call_calc(calculator, get_initial_conditions(conditions))
+
+
+def apply_low_k_cutoff(rd, calc, pars, conditions):
+    """apply_low_k_cutoff! (solve_utils.jl:213-245). Mutates rd AND the calculator, as the
+    reference does. Returns the number of removed reactions."""
+    if pars.low_k_cutoff == "none":
+        return 0
+    k_cutoff = pars.reltol / pars.tspan[-1] if pars.low_k_cutoff == "auto" else float(pars.low_k_cutoff)
+    max_rates = get_max_rates(conditions, calc) * pars.low_k_maxconc ** 2
+    low = [i for i, rate in enumerate(max_rates) if rate < k_cutoff]
+    rd.splice(low)
+    calc.splice(low)
+    return len(low)
+
+
+def make_u0(sd, pars):
+    """solve_utils.jl:262-297"""
+    if not isinstance(pars.u0, dict):
+        u0 = np.asarray(pars.u0, dtype=float)
+        if len(u0) != sd.n:
+            if pars.allow_short_u0:
+                out = np.zeros(sd.n)
+                out[:len(u0)] = u0
+                return out
+            raise RuntimeError("Length of supplied initial concentration vector does not match with number of species in system.")
+        return u0.copy()
+    out = np.zeros(sd.n)
+    for spec, conc in pars.u0.items():
+        if spec not in sd.toInt:
+            raise RuntimeError(f"Species {spec} not in SpeciesData. Check pars.u0 is correct.")
+        out[sd.toInt[spec] - 1] = conc
+    return out
+
+
+def calculate_discrete_rates(conditions, calculator, nr, handle=None):
+    """solve_utils.jl:91-109: k_precalc[s] = calculator(conditions interpolated at tstop_s).
+    With the Arrhenius calculator and a live network handle the S x R table is generated by the
+    device kernel (kin_rate_table); otherwise by S calculator calls. Returns (tstops, T or None, table)."""
+    if not conditions.discrete_updates:
+        raise RuntimeError("Cannot calculate discrete rates for a continuous ConditionSet.")
+    tstops = get_tstops(conditions)
+    static = get_static_conditions(conditions)
+    var = {s: p.sol(tstops) for s, p in zip(conditions.symbols, conditions.profiles) if isvariable(p)}
+    if isinstance(calculator, PrecalculatedArrheniusCalculator) and handle is not None:
+        T = var["T"] if "T" in var else np.full(len(tstops), static["T"])
+        return tstops, T, handle.rate_table(T)
+    table = np.empty((len(tstops), nr))
+    for i in range(len(tstops)):
+        conds = dict(static)
+        conds.update({s: v[i] for s, v in var.items()})
+        table[i] = _call_calc(calculator, conds)
+    return tstops, None, table
+
+
+# ---- results (src/analysis/io.jl:3-48; SciMLBase solution fields the callers read) ----------------------
+@dataclass
+class ODESolution:
+    t: np.ndarray
+    u: np.ndarray            # [len(t)][n_species]
+    retcode: str
+    k: Optional[object] = None
+    stats: dict = field(default_factory=dict)
+
+    def __call__(self, tq):
+        """Linear interpolation res.sol(t) (docs/src/getting-started.md:232-236)."""
+        tq = np.atleast_1d(np.asarray(tq, dtype=float))
+        i = np.clip(np.searchsorted(self.t, tq, side="left"), 1, len(self.t) - 1)
+        th = ((tq - self.t[i - 1]) / (self.t[i] - self.t[i - 1]))[:, None]
+        return (1 - th) * self.u[i - 1] + th * self.u[i]
+
+
+@dataclass
+class DiscreteRates:
+    """sol_k: DiffEqArray(k_precalc, tstops) (methods.jl:739, io.jl:38)."""
+    t: np.ndarray
+    u: np.ndarray            # [S][R']
+
+
+@dataclass
+class ODESolveOutput:
+    sd: SpeciesData
+    rd: RxData
+    sol: ODESolution
+    sol_k: Optional[DiscreteRates]
+    sol_vcs: Optional[object]
+    pars: ODESimulationParams
+    conditions: ConditionSet
+
+
+# ---- solve_network (src/solving/methods.jl:105-130, 330-360) ----------------------------------------------
+def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
+    """Solve a network with static or variable kinetics on the MI355X.
+
+    Pipeline order as in the reference: deepcopy -> [variable: solve condition
+    profiles] -> filter -> splice -> setup_network! -> low-k cutoff (mutates the copies AND the
+    caller's calculator) -> rates -> u0 -> solve -> ODESolveOutput with the REDUCED network."""
+    if return_integrator:
+        raise NotImplementedError("return_integrator=true (manual stepping of the SciML integrator, methods.jl:175-178) "
+                                  "has no counterpart: the integrator lives on the device")
+    pars, conditions, calc = method.pars, method.conditions, method.calculator
+    sd_a, rd_a = (copy.deepcopy(sd), copy.deepcopy(rd)) if copy_network else (sd, rd)
+    variable = isinstance(method, VariableODESolve)
+    if variable:
+        solve_variable_conditions(conditions, pars)
+        if not conditions.discrete_updates:
+            raise NotImplementedError("continuous rate updates (methods.jl:363-653) are not part of the accelerated path; "
+                                      "pass ts_update to ConditionSet for discrete updates (recommended for large CRNs, "
+                                      "docs/src/tutorials/ode-solution.md:85-91)")
+    mask = get_filter_mask(method.filter, sd_a, rd_a)
+    rd_a.splice(np.nonzero(mask)[0])
+    setup_network(sd_a, rd_a, calc)
+    apply_low_k_cutoff(rd_a, calc, pars, conditions)
+    u0 = make_u0(sd_a, pars)
+
+    h = capi.HipNetwork(*rd_a.flat(sd_a.n), index_base=1)
+    try:
+        arr = isinstance(calc, PrecalculatedArrheniusCalculator)
+        if arr:
+            h.set_arrhenius(calc.Ea, calc.A, calc.k_max, calc.t_mult)
+        sol_k = None
+        if not variable:
+            k0 = get_initial_rates(conditions, calc)
+            h.set_rates(k0)
+            t, u, rc, st, status = h.solve(pars.to_kin_params(), u0)
+        else:
+            tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
+            sol_k = DiscreteRates(tstops, table)
+            if arr:
+                t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, T_stops=T)
+            else:
+                t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, k_table=table)
+        if status == capi.KIN_ERR_SOLVE_FAILED:
+            raise RuntimeError("ODE solution failed.")      # ErrorException (solve_utils.jl:405-411)
+        if pars.update_tols and st["final_abstol"] != pars.abstol:
+            pars.abstol, pars.reltol = st["final_abstol"], st["final_reltol"]   # solve_utils.jl:397-401
+    finally:
+        h.close()
+    sol = ODESolution(t, u, capi.RETCODE_NAMES[rc], k=sol_k, stats=st)
+    return ODESolveOutput(sd_a, rd_a, sol, sol_k, None, pars, conditions)

@@ -179,3 +179,123 @@ def test_failure_and_retry_semantics():
             h.solve(bad, [1.0, 0.0, 0.0])
         assert e.value.code == capi.KIN_ERR_INVALID_ARG
     h.close()
+
+
+# ---- end-to-end through the mirrored reference interface (solve_network) ---------------------------------
+def c1_network():
+    """C1: hand-written methane-pyrolysis-style CRN, 15 reactions + their reverses in the block
+    order duplicate_reverse produces (cde.jl:299-309: all forwards, then all reverses), sized to
+    the reference's 30-entry examples/getting_started/arrhenius_params.bson. The getting-started
+    CRN itself is generated by CDE at doc-build time and is not in the reference repository."""
+    names = ["C", "[CH3]", "[H]", "[H][H]", "CC", "C[CH2]", "C=C", "C=[CH]", "C#C"]
+    CH4, CH3, H, H2, C2H6, C2H5, C2H4, C2H3, C2H2 = range(1, 10)
+    fwd = [([CH4], [CH3, H]), ([CH4, H], [CH3, H2]), ([CH3, CH3], [C2H6]), ([C2H6], [C2H5, H]),
+           ([C2H6, H], [C2H5, H2]), ([C2H6, CH3], [C2H5, CH4]), ([C2H5], [C2H4, H]), ([C2H4, H], [C2H3, H2]),
+           ([C2H4, CH3], [C2H3, CH4]), ([C2H3], [C2H2, H]), ([C2H5, H], [C2H4, H2]), ([H, H], [H2]),
+           ([C2H3, H], [C2H2, H2]), ([C2H5, CH3], [C2H4, CH4]), ([C2H4], [C2H2, H2])]
+    allr = fwd + [(p, r) for r, p in fwd]
+
+    def side(sp):
+        ids = sorted(set(sp))
+        return ids, [sp.count(i) for i in ids]
+    from kinetica_jl_amd.solving import RxData, SpeciesData
+    ir, sr, ip, sp_ = [], [], [], []
+    for r, p in allr:
+        a, b = side(r); c, d = side(p)
+        ir.append(a); sr.append(b); ip.append(c); sp_.append(d)
+    return SpeciesData.from_names(names), RxData(len(allr), ir, ip, sr, sp_)
+
+
+def c1_parameters(d):
+    """Assigns the reference's 30 (Ea, A) pairs to the hand network in a chemically sensible way:
+    the 8 barrierless entries go to the radical recombinations / disproportionations, the highest
+    barriers to the bond fissions, the rest in ascending order to H-abstractions and their
+    reverses. (An arbitrary assignment puts forward AND reverse of most reactions at the k_max
+    cap, i.e. O(1) radical concentrations exchanging at 1e12 /s: f then has an absolute round-off
+    floor of ~1e-4 and every Newton-based stiff integrator - SciPy's BDF included - crawls.)"""
+    order = np.argsort(np.asarray(d["Ea"]), kind="stable")
+    Ea = np.asarray(d["Ea"])[order]; A = np.asarray(d["A"])[order]
+    # reaction indices (0-based; forwards 0..14, reverses 15..29)
+    barrierless = [15 + 0, 2, 15 + 3, 15 + 6, 15 + 9, 11, 10, 12]          # X + H -> XH, CH3 + CH3, H + H, disproportionation
+    fissions = [0, 3, 15 + 2, 15 + 11, 6, 9, 14, 15 + 14]                   # strongest bonds last in `order`
+    rest = [r for r in range(30) if r not in barrierless and r not in fissions]
+    slot = {r: i for i, r in enumerate(barrierless + rest + fissions)}
+    Ea_r = np.array([Ea[slot[r]] for r in range(30)]); A_r = np.array([A[slot[r]] for r in range(30)])
+    return Ea_r, A_r
+
+
+def rd_to_flat(sd, rd):
+    n, rp, ri, rs, pp, pi, ps = rd.flat(sd.n)
+    from kinetica_jl_amd.synth import FlatNetwork
+    return FlatNetwork(n, rd.nr, rp, ri - 1, rs, pp, pi - 1, ps)
+
+
+def test_c1_getting_started_static_and_variable(golden_dir):
+    import json
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    d = json.load(open(os.path.join(golden_dir, "arrhenius_params.json")))
+    sd, rd = c1_network()
+    Ea, A = c1_parameters(d)
+    # --- StaticODESolve, tspan (0, 1) s, chunkwise (SURVEY 8(d) C1). 800 K rather than 1000 K: with the
+    # reference's rate formula (x N_A) methane fission itself reaches 1e11 /s at 1000 K, i.e. the
+    # unphysical regime described in c1_parameters.
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e12)
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0}, solve_chunkstep=0.25, save_interval=0.125)
+    res = S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 800.0}), calc), sd, rd)
+    assert res.sol.retcode == "Success" and len(res.sol.t) == 9 and res.sol_k is None
+    assert res.rd.nr <= 30 and rd.nr == 30                      # copy_network: the caller's rd is untouched ...
+    assert len(calc.Ea) == res.rd.nr                            # ... but its calculator is spliced (solve_utils.jl:241)
+    # oracle on the reduced network with the reduced parameters
+    k = orc.arrhenius(calc.Ea, calc.A, 800.0, k_max=1e12)
+    to, uo, rco, sto = oracle_solve(rd_to_flat(res.sd, res.rd), dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.25,
+                                                                        save_interval=0.125), res.sol.u[0], k0=k)
+    assert errscale(res.sol.u, uo) < 10
+    # carbon and hydrogen atoms are conserved by every reaction of the hand network
+    nC = np.array([1, 1, 0, 0, 2, 2, 2, 2, 2]); nH = np.array([4, 3, 1, 2, 6, 5, 4, 3, 2])
+    np.testing.assert_allclose(res.sol.u @ nC, 1.0, rtol=1e-6)
+    np.testing.assert_allclose(res.sol.u @ nH, 4.0, rtol=1e-6)
+    # --- VariableODESolve: the getting-started ramp (50 K/s from 500 K, docs/src/getting-started.md:43-49),
+    # stopped at 800 K; discrete updates every 0.5 s
+    sd, rd = c1_network()
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e12)
+    cs = C.ConditionSet({"T": C.LinearGradientProfile(rate=50.0, X_start=500.0, X_end=800.0)}, ts_update=0.5)
+    pars = S.ODESimulationParams(tspan=(0.0, 6.0), u0={"C": 1.0}, solve_chunkstep=1.0, save_interval=0.5)
+    res = S.solve_network(S.VariableODESolve(pars, cs, calc), sd, rd)
+    assert res.sol.retcode == "Success" and len(res.sol.t) == 13 and res.sol.t[-1] == 6.0
+    assert res.sol_k.u.shape == (13, res.rd.nr) and res.rd.nr <= 30
+    np.testing.assert_allclose(res.sol_k.u, orc.rate_table(calc.Ea, calc.A, 500.0 + 50.0 * res.sol_k.t, k_max=1e12), rtol=2e-15)
+    ks = res.sol_k.u
+    to, uo, rco, sto = oracle_solve(rd_to_flat(res.sd, res.rd), dict(tspan=(0.0, 6.0), solve_chunks=True, solve_chunkstep=1.0,
+                                                                        save_interval=0.5), res.sol.u[0], tstops=res.sol_k.t, ks=ks)
+    assert rco == 0
+    np.testing.assert_allclose(res.sol.t, to)
+    assert errscale(res.sol.u, uo) < 10
+    np.testing.assert_allclose(res.sol.u @ nC, 1.0, rtol=1e-6)
+    # linear interpolation functor res.sol(t)
+    np.testing.assert_allclose(res.sol([0.25])[0], 0.5 * (res.sol.u[0] + res.sol.u[1]))
+
+
+def test_solve_network_static_low_k_cutoff_and_filter():
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    net, Ea, A = synthetic_crn(40, 160, seed=5)
+    sd = S.SpeciesData.from_names([f"S{i}" for i in range(40)])
+    rd = S.RxData.from_flat(net)
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e3)
+    # at 300 K with tspan end 1 s the :auto cutoff (1e-8) removes the high-barrier reactions
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0={"S0": 1.0}, solve_chunkstep=0.5)
+    k_all = orc.arrhenius(Ea, A, 300.0, k_max=1e3)
+    keep = orc.low_k_keep_mask(k_all, orc.low_k_cutoff_value("auto", 1e-8, 1.0), 2.0)
+    res = S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 300.0}), calc), sd, rd)
+    assert res.rd.nr == int(keep.sum()) < 160 and res.sol.retcode == "Success"
+    to, uo, rco, sto = oracle_solve(net.subset(np.nonzero(keep)[0]), dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.5),
+                                    res.sol.u[0], k0=k_all[keep])
+    assert errscale(res.sol.u, uo) < 10
+    # a filter that removes every bimolecular reaction
+    calc2 = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e3)
+    flt = S.RxFilter([lambda sd_, rd_: [sum(s) == 2 for s in rd_.stoic_reacs]])
+    # removing a reaction must also remove its calculator entries: the reference leaves that to the
+    # caller (setup_network! length check throws, calculator.jl:200-204)
+    with pytest.raises(ValueError):
+        S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 300.0}), calc2, flt), sd, rd)

@@ -1,0 +1,153 @@
+"""CPU tests of the host-side mirror of the reference interface (kinetica_jl_amd.conditions /
+.solving): the reference's own condition tests (test/Main/conditions.jl) restated against this
+package, constructor validation (params.jl:77-104, methods.jl:12-20, 49-57), filters,
+calculators, u0, cutoff bookkeeping. Nothing here touches the GPU or the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kinetica_jl_amd import conditions as C
+from kinetica_jl_amd import solving as S
+
+
+def test_profile_construction_reference_values(golden_dir):
+    # test/Main/conditions.jl:4-90
+    kat = json.load(open(os.path.join(golden_dir, "conditions_kat.json")))
+    assert C.StaticConditionProfile(10.0).value == 10.0
+    nd = C.NullDirectProfile(X_start=300.0, t_end=10.0)
+    assert nd.X_start == 300.0 and nd.t_end == 10.0 and nd.f(5.0, nd) == pytest.approx(300.0)
+    assert len(nd.tstops) == 1 and nd.tstops[0] == pytest.approx(10.0)
+    ld = C.LinearDirectProfile(rate=50.0, X_start=300.0, X_end=500.0)
+    assert (ld.rate, ld.X_start, ld.X_end) == (50.0, 300.0, 500.0)
+    assert ld.t_end == pytest.approx(4.0) and ld.f(2.0, ld) == pytest.approx(400.0)
+    assert len(ld.tstops) == 1 and ld.tstops[0] == pytest.approx(4.0)
+    ng = C.NullGradientProfile(X_start=300.0, t_end=10.0)
+    assert ng.grad(5.0, ng) == 0.0 and ng.tstops[0] == pytest.approx(10.0)
+    lg = C.LinearGradientProfile(rate=50.0, X_start=300.0, X_end=500.0)
+    assert lg.t_end == pytest.approx(4.0) and lg.grad(2.0, lg) == 50.0 and lg.grad(5.0, lg) == 0.0
+    dr = C.DoubleRampGradientProfile(**kat["doubleramp"]["args"])
+    assert dr.t_blend == 0.0 and dr.t_end == pytest.approx(48.0)
+    np.testing.assert_allclose(dr.tstops, [5.0, 25.0, 28.0, 43.0, 48.0])
+    for t, v in kat["doubleramp"]["grad_at"]:
+        assert dr.grad(t, dr) == v
+    db = C.DoubleRampGradientProfile(**kat["doubleramp_blended"]["args"])
+    assert db.t_blend == 0.1
+    np.testing.assert_allclose(db.tstops, [4.9, 5.1, 24.9, 25.1, 27.9, 28.1, 42.9, 43.1, 48.0])
+    with pytest.raises(RuntimeError):
+        C.LinearDirectProfile(rate=-50.0, X_start=300.0, X_end=500.0)
+
+
+def _cs(ts_update=None):
+    return C.ConditionSet({
+        "T": C.LinearDirectProfile(rate=50.0, X_start=300.0, X_end=500.0),
+        "P": C.DoubleRampGradientProfile(X_start=1e5, t_start_plateau=1.0, rate1=1e3, X_mid=2e5, t_mid_plateau=10.0,
+                                         rate2=-1e3, X_end=1e5, t_end_plateau=1.0, t_blend=0.1),
+        "V": 1e3}, ts_update=ts_update)
+
+
+def test_condition_set_construction_reference_values():
+    # test/Main/conditions.jl:92-135
+    csc = _cs()
+    assert set(csc.symbols) == {"T", "P", "V"} and len(csc.profiles) == 3
+    assert csc.discrete_updates is False and csc.ts_update is None
+    csd = _cs(1e-3)
+    assert csd.discrete_updates is True and csd.ts_update == pytest.approx(1e-3)
+    with pytest.raises(ValueError):
+        C.ConditionSet({"X": "abc"})
+    assert C.isstatic(csc, "V") and C.isvariable(csc, "T") and not C.isstatic(csc) and not C.isvariable(csc)
+    ts = C.get_tstops(csd)
+    assert ts[0] == 0.0 and np.all(np.diff(ts) > 0) and ts[-1] == pytest.approx(C.get_t_final(csd))
+    with pytest.raises(RuntimeError):
+        C.get_tstops(C.ConditionSet({"T": 300.0}))
+
+
+def test_discrete_tstops_and_profile_solutions():
+    p = C.LinearGradientProfile(rate=50.0, X_start=500.0, X_end=1200.0)
+    cs = C.ConditionSet({"T": p}, ts_update=1e-3)
+    ts = C.get_tstops(cs)
+    assert len(ts) == 14001 and ts[1234] == 1.234 and ts[-1] == 14.0
+    pars = S.ODESimulationParams(tspan=(0.0, 14.0), u0={"C": 1.0}, solve_chunkstep=1e-2, save_interval=5e-3)
+    C.solve_variable_conditions(cs, pars)
+    np.testing.assert_allclose(p.sol(ts), 500.0 + 50.0 * ts, rtol=1e-12)
+    assert p.minimum() == pytest.approx(500.0) and p.maximum() == pytest.approx(1200.0)
+    ld = C.LinearDirectProfile(rate=50.0, X_start=300.0, X_end=500.0)
+    cs2 = C.ConditionSet({"T": ld}, ts_update=0.5)
+    np.testing.assert_allclose(ld.tstops, np.arange(9) * 0.5)
+    pars2 = S.ODESimulationParams(tspan=(0.0, 5.0), u0=[1.0], solve_chunks=False)
+    C.solve_variable_conditions(cs2, pars2)
+    assert ld.sol([2.0])[0] == pytest.approx(400.0) and ld.sol([4.5])[0] == pytest.approx(500.0)
+    with pytest.raises(ValueError):
+        C.ConditionSet({"T": C.LinearDirectProfile(rate=50.0, X_start=300.0, X_end=500.0)}, ts_update=10.0)
+
+
+def test_params_validation():
+    ok = S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0})
+    assert (ok.abstol, ok.reltol, ok.solve_chunks, ok.solve_chunkstep, ok.maxiters) == (1e-10, 1e-8, True, 1e-3, 100000)
+    assert ok.low_k_cutoff == "auto" and ok.low_k_maxconc == 2.0 and ok.save_interval is None
+    for bad in (dict(tspan=(1.0, 1.0)), dict(tspan=(0.0, 1.0), low_k_cutoff="sometimes"), dict(tspan=(0.0, 1.0), low_k_cutoff=-1.0),
+                dict(tspan=(0.0, 1.0), solve_chunkstep=0.3), dict(tspan=(0.0, 1.0), solve_chunkstep=0.1, save_interval=0.2)):
+        with pytest.raises(ValueError):
+            S.ODESimulationParams(u0=[1.0], **bad)
+    S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0], solve_chunks=False, solve_chunkstep=0.3)   # only checked when chunking
+    kp = ok.to_kin_params()
+    assert kp.save_interval == -1.0 and kp.solve_chunks == 1 and kp.maxiters == 100000
+
+
+def test_solve_method_constructors():
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0])
+    calc = S.PrecalculatedArrheniusCalculator([1.0], [1.0])
+    S.StaticODESolve(pars, C.ConditionSet({"T": 300.0}), calc)
+    with pytest.raises(ValueError):   # variable condition in a static solve (methods.jl:13-14)
+        S.StaticODESolve(pars, C.ConditionSet({"T": C.NullDirectProfile(X_start=300.0, t_end=1.0)}), calc)
+    with pytest.raises(ValueError):   # Arrhenius knows only T (calculator.jl:234-236)
+        S.StaticODESolve(pars, C.ConditionSet({"T": 300.0, "V": 1.0}), calc)
+    S.StaticODESolve(pars, C.ConditionSet({"T": 300.0, "V": 1.0}), S.DummyKineticCalculator([1.0]))
+    assert S.allows_continuous(calc) and S.has_conditions(calc, ["T"])
+    with pytest.raises(RuntimeError):
+        S.PrecalculatedLindemannCalculator([1.0], [1.0], [1.0])(T=300.0)
+
+
+def test_filters_network_and_u0():
+    sd = S.SpeciesData.from_names(["A", "B", "C"])
+    rd = S.RxData(3, [[1], [2], [1, 2]], [[2], [3], [3]], [[1], [1], [1, 1]], [[1], [1], [1]])
+    assert not get_mask(S.RxFilter(), sd, rd).any()
+    bimol = lambda sd_, rd_: [len(r) == 2 for r in rd_.id_reacs]
+    assert list(get_mask(S.RxFilter([bimol]), sd, rd)) == [False, False, True]
+    assert list(get_mask(S.RxFilter([bimol], keep_filtered=True), sd, rd)) == [True, True, False]
+    rd.splice([2])
+    assert rd.nr == 2 and rd.id_reacs == [[1], [2]]
+    n, rp, ri, rs, pp, pi, ps = rd.flat(3)
+    assert list(rp) == [0, 1, 2] and list(ri) == [1, 2] and list(pi) == [2, 3]
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0})
+    assert list(S.make_u0(sd, pars)) == [0.0, 0.0, 1.0]
+    with pytest.raises(RuntimeError):
+        S.make_u0(sd, S.ODESimulationParams(tspan=(0.0, 1.0), u0={"X": 1.0}))
+    with pytest.raises(RuntimeError):
+        S.make_u0(sd, S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0]))
+    assert list(S.make_u0(sd, S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0], allow_short_u0=True))) == [1.0, 0.0, 0.0]
+
+
+def get_mask(rf, sd, rd):
+    return S.get_filter_mask(rf, sd, rd)
+
+
+def test_dummy_calculator_and_low_k_cutoff_bookkeeping():
+    calc = S.DummyKineticCalculator([1e3, 1e-12, 5.0, 1e-11], t_unit="ms")
+    np.testing.assert_allclose(calc(T=300.0), np.array([1e3, 1e-12, 5.0, 1e-11]) * 1e-3)
+    capped = S.DummyKineticCalculator([1e3, 1e13], k_max=1e12)
+    np.testing.assert_allclose(capped(T=1.0), 1.0 / (1e-12 + 1.0 / np.array([1e3, 1e13])))
+    sd = S.SpeciesData.from_names(["A", "B"])
+    rd = S.RxData(4, [[1], [2], [1], [2]], [[2], [1], [2], [1]], [[1]] * 4, [[1]] * 4)
+    pars = S.ODESimulationParams(tspan=(0.0, 10.0), u0=[1.0, 0.0])          # :auto -> cutoff = 1e-8 / 10
+    cs = C.ConditionSet({"T": 300.0})
+    calc = S.DummyKineticCalculator([1e3, 1e-12, 5.0, 2e-10])
+    S.setup_network(sd, rd, calc)
+    removed = S.apply_low_k_cutoff(rd, calc, pars, cs)      # removed iff k * 2^2 < 1e-9
+    assert removed == 2 and rd.nr == 2 and list(calc.rates) == [1e3, 5.0]
+    with pytest.raises(ValueError):
+        S.setup_network(sd, rd, S.DummyKineticCalculator([1.0]))
+    pars_none = S.ODESimulationParams(tspan=(0.0, 10.0), u0=[1.0, 0.0], low_k_cutoff="none")
+    assert S.apply_low_k_cutoff(rd, calc, pars_none, cs) == 0
+    assert S.tconvert("ms", "s") == 1e-3 and S.tconvert(2.0, "mins", "s") == 120.0

@@ -28,7 +28,7 @@ def test_step_sequence_matches_scipy_bdf():
     tf = 40.0
     ref = solve_ivp(lambda t, y: on.rhs(k, y), (0, tf), y0, method="BDF", jac=lambda t, y: on.jac(k, y).toarray(),
                     rtol=1e-8, atol=1e-10)
-    b = obdf.OracleBDF(lambda y: on.rhs(k, y), lambda y: on.jac(k, y), 3, 1e-10, 1e-8)
+    b = obdf.OracleBDF(lambda y: on.rhs(k, y), lambda y: on.jac(k, y), 3, 1e-10, 1e-8, scipy_newton=True)
     assert b.restart(0.0, y0, tf)
     b.iters_left = 10 ** 6
     ts, ys = [0.0], [y0]
