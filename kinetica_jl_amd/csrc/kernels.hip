@@ -254,13 +254,13 @@ __device__ __forceinline__ double sweep_net(const SweepRec& q, double kf, double
   return net;
 }
 
-// Each thread handles ILP records per trip and issues all of their global loads before
+// Each thread handles SWEEP_ILP records per trip and issues all of their global loads before
 // the first use: with one 1024-thread workgroup per CU (LDS bound) this is what keeps enough
 // bytes in flight to cover HBM latency. ADJ: record p pairs reactions (2p, 2p+1), so the rate
 // constants stream as one coalesced double2 per lane and do not depend on any index load.
+constexpr int SWEEP_ILP = 8;
 
-
-template <bool U_IN_LDS, bool ADJ, int VAR, int ILP>
+template <bool U_IN_LDS, bool ADJ>
 __global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int P, int B, int tile, int n_tiles,
                                                          const SweepRec* __restrict__ rec, const int2* __restrict__ pair_k,
                                                          const double* __restrict__ u, const double* __restrict__ k_b,
@@ -283,13 +283,12 @@ __global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int P, in
       const int lo = t * tile, hi = min(N, lo + tile);
       for (int i = tid; i < hi - lo; i += 1024) du_s[i] = 0.0;
       __syncthreads();
-      double accv = 0.0;
-      for (int p0 = tid; p0 < P; p0 += 1024 * ILP) {
-        SweepRec q[ILP];
-        double kf[ILP], kr[ILP];
+      for (int p0 = tid; p0 < P; p0 += 1024 * SWEEP_ILP) {
+        SweepRec q[SWEEP_ILP];
+        double kf[SWEEP_ILP], kr[SWEEP_ILP];
         if (ADJ) {
 #pragma unroll
-          for (int x = 0; x < ILP; x++) {
+          for (int x = 0; x < SWEEP_ILP; x++) {
             const int p = p0 + x * 1024;
             if (p < P) {
               const double2 kk = *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
@@ -298,40 +297,33 @@ __global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int P, in
             }
           }
         } else {
-          int2 kk[ILP];
+          int2 kk[SWEEP_ILP];
 #pragma unroll
-          for (int x = 0; x < ILP; x++) {
+          for (int x = 0; x < SWEEP_ILP; x++) {
             const int p = p0 + x * 1024;
             if (p < P) { kk[x] = pair_k[p]; q[x] = rec[p]; }
           }
 #pragma unroll
-          for (int x = 0; x < ILP; x++) {
+          for (int x = 0; x < SWEEP_ILP; x++) {
             const int p = p0 + x * 1024;
             if (p < P) { kf[x] = kb[kk[x].x]; kr[x] = kk[x].y >= 0 ? kb[kk[x].y] : 0.0; }
           }
         }
 #pragma unroll
-        for (int x = 0; x < ILP; x++) {
+        for (int x = 0; x < SWEEP_ILP; x++) {
           const int p = p0 + x * 1024;
           if (p < P) {
             uint32_t sl[4]; int cf[4];
-            double net;
-            if (VAR == 2) { net = kf[x] - kr[x]; sl[0] = q[x].s01 & 0xffffu; sl[1] = q[x].s01 >> 16; sl[2] = q[x].s23 & 0xffffu; sl[3] = q[x].s23 >> 16;
-              for (int j = 0; j < 4; j++) cf[j] = (int)(int8_t)((uint32_t)q[x].coef >> (8 * j)); }
-            else net = sweep_net<U_IN_LDS>(q[x], kf[x], kr[x], u_s, ub, sl, cf);
-            if (VAR == 1) { accv += net * (double)(cf[0] + cf[1] + cf[2] + cf[3] + (int)sl[0] + (int)sl[3]); }
-            else {
+            const double net = sweep_net<U_IN_LDS>(q[x], kf[x], kr[x], u_s, ub, sl, cf);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int sp = (int)sl[j];
               if (sp != 0xffff && sp >= lo && sp < hi)
                 __hip_atomic_fetch_add(du_s + (sp - lo), (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            }
           }
         }
       }
-      if (VAR == 1) du_s[tid] = accv;
       __syncthreads();
       for (int i = tid * 2; i < hi - lo; i += 2048) {
         if (i + 1 < hi - lo && ((lo & 1) == 0)) *reinterpret_cast<double2*>(dub + lo + i) = *reinterpret_cast<double2*>(du_s + i);
@@ -342,26 +334,16 @@ __global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int P, in
   }
 }
 
-template <bool U_IN_LDS, bool ADJ, int VAR, int ILP>
-static void launch_sweep_t2(int grid, size_t smem, int N, int R, int P, int B, int tile, int n_tiles, const void* rec,
-                           const void* pair_k, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    KIN_HIP(hipFuncSetAttribute((const void*)sweep_lds_kernel<U_IN_LDS, ADJ, VAR, ILP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((sweep_lds_kernel<U_IN_LDS, ADJ, VAR, ILP>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, n_tiles,
-                     (const SweepRec*)rec, (const int2*)pair_k, u, k_b, k_1, du);
-}
-
 template <bool U_IN_LDS, bool ADJ>
 static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, int tile, int n_tiles, const void* rec,
                            const void* pair_k, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
-  static int var = -1;
-  if (var < 0) { const char* e = getenv("KIN_SWEEP_VARIANT"); var = e ? atoi(e) : 0; }
-#define GO(V, I) launch_sweep_t2<U_IN_LDS, ADJ, V, I>(grid, smem, N, R, P, B, tile, n_tiles, rec, pair_k, u, k_b, k_1, du, s)
-  switch (var) { case 1: GO(1, 4); break; case 2: GO(2, 4); break; case 3: GO(0, 8); break; case 4: GO(0, 2); break; case 5: GO(1, 8); break; default: GO(0, 4); }
-#undef GO
+  static bool attr_done = false;
+  if (!attr_done) {
+    KIN_HIP(hipFuncSetAttribute((const void*)sweep_lds_kernel<U_IN_LDS, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((sweep_lds_kernel<U_IN_LDS, ADJ>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, n_tiles,
+                     (const SweepRec*)rec, (const int2*)pair_k, u, k_b, k_1, du);
 }
 
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
