@@ -99,16 +99,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    from kinetica_jl_amd.distributed import max_over_ranks
+    elapsed = max_over_ranks(elapsed, dist, dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     out = None
     if rank == 0:
         alg_bytes = 20 * R + B * (8 * R + 16 * N)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 runs of this same
+        # command, tools/collect_profiles.sh), only when they were taken on this configuration
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_sweep_pmc.json")))
+            if pm["algorithmic_bytes_per_launch"] == alg_bytes:
+                traffic = pm["hbm_bytes_per_launch_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "RHS evals/sec (batched sweep) + wall-clock per solve_network, 10k-species CRN",
             "value": world * B * args.steps / elapsed, "unit": "RHS evals/s",
@@ -118,7 +125,7 @@ def main():
                                    f"B={B} states per GPU with per-state Arrhenius k (500-1200 K)",
                        "states_per_gpu": B, "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "sweep_lds_kernel<true>",
+                         "traffic": traffic, "kernel": "sweep_lds_kernel<true>",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
         }
 

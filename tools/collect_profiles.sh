@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the default bench command and
+# separate PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950), then writes the
+# summaries that get committed under profiles/. Usage: tools/collect_profiles.sh r01
+set -e
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT" && mkdir -p "$OUT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --solve-chunks 5 --cpu-solve-chunks 0 > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 5 --solve-chunks 0 --no-cpu > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py --steps 5 --solve-chunks 0 --no-cpu > "$OUT/bench_write.log" 2>&1
+python3 tools/summarize_profiles.py "$OUT" "$TAG"
+# keep the merge-back small
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -name "*agent_info.csv" -delete
