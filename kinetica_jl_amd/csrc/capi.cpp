@@ -76,6 +76,7 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     h->x0.upload(N.x0, s); h->x1.upload(N.x1, s);
     h->sp_ptr.upload(N.sp_ptr, s); h->sp_rxn.upload(N.sp_rxn, s); h->sp_coef.upload(N.sp_coef, s);
     if (N.N < 65535) { h->sweep_rec.upload(N.pair_rec, s); h->sweep_k.upload(N.pair_k, s); }
+    if (!N.pair_rec64.empty()) h->sweep_rec64.upload(N.pair_rec64, s);
     h->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);
     h->jac_plan.upload(build_seg_plan(N.nnz(), N.jc_ptr.data(), nullptr, N.jc_src.data(), nullptr, N.jc_coef.data(), false), s);
     h->k.alloc(N.R); h->rate.alloc(N.R); h->dr.alloc(2 * N.R + 2);
@@ -199,7 +200,7 @@ int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const doub
   require(d_k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
   require(h->host.N < 65535, ERR_UNSUPPORTED, "batched sweep packs species ids in 16 bits (N < 65535)");
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  launch_sweep(h->host.N, h->host.R, h->host.n_pairs(), B, h->host.pairs_adjacent, h->sweep_rec.p, h->sweep_k.p, d_u, d_k, h->k.p, d_du, s);
+  launch_sweep(h->host.N, h->host.R, h->host.n_pairs(), B, h->host.pairs_adjacent, h->sweep_rec.p, h->sweep_k.p, h->host.pair_rec64.empty() ? nullptr : h->sweep_rec64.p, d_u, d_k, h->k.p, d_du, s);
   KIN_CATCH(h)
 }
 
@@ -214,7 +215,7 @@ int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k,
   h->b_u.upload(u, (size_t)B * N, s);
   h->b_du.alloc((size_t)B * N);
   if (k) h->b_k.upload(k, (size_t)B * R, s);
-  launch_sweep(N, R, h->host.n_pairs(), B, h->host.pairs_adjacent, h->sweep_rec.p, h->sweep_k.p, h->b_u.p, k ? h->b_k.p : nullptr, h->k.p, h->b_du.p, s);
+  launch_sweep(N, R, h->host.n_pairs(), B, h->host.pairs_adjacent, h->sweep_rec.p, h->sweep_k.p, h->host.pair_rec64.empty() ? nullptr : h->sweep_rec64.p, h->b_u.p, k ? h->b_k.p : nullptr, h->k.p, h->b_du.p, s);
   h->b_du.download(du, (size_t)B * N, s);
   KIN_HIP(hipStreamSynchronize(s));
   KIN_CATCH(h)

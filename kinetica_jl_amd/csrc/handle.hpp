@@ -18,6 +18,7 @@ struct kin_network {
   kin::DevBuf<int32_t> x0, x1, sp_ptr, sp_rxn;
   kin::DevBuf<uint32_t> sweep_rec;   // 4 words per reversible pair (kernels.hip: SweepRec)
   kin::DevBuf<int32_t> sweep_k;      // (kf, kr) per pair
+  kin::DevBuf<uint32_t> sweep_rec64; // 64-bit packed records (register-resident sweep)
   kin::DevBuf<float> sp_coef;
   kin::SegPlanDev rhs_plan, jac_plan;
 

@@ -334,6 +334,133 @@ __global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int P, in
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident variant (adjacent pairs, N < 16383, state fits LDS): the reaction records a
+// thread works on are the same for every state, so they are loaded ONCE into registers (64-bit
+// packing: 4 x 14-bit species slots + 4 x 2-bit stoichiometry codes) and the only per-state
+// global traffic left is the algorithmic one: k[b] streamed as double2, u[b] in, du[b] out.
+// T = records per thread (compile time, fully unrolled so the record array stays in VGPRs).
+// ------------------------------------------------------------------------------------------
+// one packed record: decode, 4 LDS reads, net rate, <= 4 LDS atomics
+__device__ __forceinline__ void sweep_apply(uint2 w, double2 kk, const double* u_s, double* du_s) {
+  const uint32_t sl[4] = {w.x & 0x3fffu, (w.x >> 14) & 0x3fffu, (w.x >> 28) | ((w.y & 0x3ffu) << 4), (w.y >> 10) & 0x3fffu};
+  const uint32_t codes = w.y >> 24;
+  double uf = 1.0, ur = 1.0;
+  int cf[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c2 = (codes >> (2 * j)) & 3;            // 0,1,2,3 -> -2,-1,+1,+2
+    cf[j] = c2 < 2 ? c2 - 2 : c2 - 1;
+    if (sl[j] != 0x3fffu) {
+      const double v = u_s[sl[j]];
+      const double v2 = (c2 == 0 || c2 == 3) ? v * v : v;
+      if (c2 < 2) uf *= v2; else ur *= v2;
+    }
+  }
+  const double net = kk.x * uf - kk.y * ur;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (sl[j] != 0x3fffu)
+      __hip_atomic_fetch_add(du_s + sl[j], (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// TR = records per thread kept in registers (compile time, fully unrolled); records beyond
+// TR*1024 are streamed as 8-byte words. ILP = records whose loads are issued together.
+template <int TR, int ILP>
+__global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, int B, int tile,
+                                                         const uint2* __restrict__ rec64, const double* __restrict__ u,
+                                                         const double* __restrict__ k_b, const double* __restrict__ k_1,
+                                                         double* __restrict__ du) {
+  extern __shared__ double lds[];
+  double* du_s = lds;
+  double* u_s = lds + tile;
+  const int tid = threadIdx.x;
+  constexpr int UPT = 5;            // double2 per thread of the staged state (N <= 10240)
+  constexpr uint2 EMPTY = {0xffffffffu, 0x00ffffffu};
+  uint2 rc[TR > 0 ? TR : 1];
+#pragma unroll
+  for (int i = 0; i < TR; i++) {
+    const int p = tid + i * 1024;
+    rc[i] = p < P ? rec64[p] : EMPTY;
+  }
+  // software pipeline over states: the next state's u travels HBM -> registers while this state's
+  // reactions are processed; du is written out and re-zeroed in one pass. N is even (host check).
+  double2 un[UPT];
+  int b = blockIdx.x;
+#pragma unroll
+  for (int x = 0; x < UPT; x++) {
+    const int i = (tid + x * 1024) * 2;
+    un[x] = (b < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)b * N + i) : make_double2(0.0, 0.0);
+  }
+  for (int i = tid * 2; i < N; i += 2048) *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
+  for (; b < B; b += gridDim.x) {
+    const double* kb = k_b ? k_b + (size_t)b * R : k_1;
+    double* dub = du + (size_t)b * N;
+#pragma unroll
+    for (int x = 0; x < UPT; x++) {
+      const int i = (tid + x * 1024) * 2;
+      if (i < N) *reinterpret_cast<double2*>(u_s + i) = un[x];
+    }
+    __syncthreads();
+    const int bn = b + gridDim.x;
+#pragma unroll
+    for (int x = 0; x < UPT; x++) {
+      const int i = (tid + x * 1024) * 2;
+      un[x] = (bn < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)bn * N + i) : make_double2(0.0, 0.0);
+    }
+    // register-resident records
+#pragma unroll
+    for (int i0 = 0; i0 < TR; i0 += ILP) {
+      double2 kk[ILP];
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        const int p = tid + (i0 + x) * 1024;
+        kk[x] = p < P ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        uint2 w = rc[i0 + x];
+        // opaque to the optimiser: without this the loop-invariant decode (slot indices and lane
+        // masks of every record) is hoisted out of the state loop and the kernel spills
+        asm volatile("" : "+v"(w.x), "+v"(w.y));
+        sweep_apply(w, kk[x], u_s, du_s);
+      }
+    }
+    // streamed records
+    for (int p0 = tid + TR * 1024; p0 < P; p0 += 1024 * ILP) {
+      double2 kk[ILP];
+      uint2 w[ILP];
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        const int p = p0 + x * 1024;
+        const bool ok = p < P;
+        kk[x] = ok ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+        w[x] = ok ? rec64[p] : EMPTY;
+      }
+#pragma unroll
+      for (int x = 0; x < ILP; x++) sweep_apply(w[x], kk[x], u_s, du_s);
+    }
+    __syncthreads();
+    for (int i = tid * 2; i < N; i += 2048) {
+      *reinterpret_cast<double2*>(dub + i) = *reinterpret_cast<double2*>(du_s + i);
+      *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
+    }
+    // no barrier needed here: the next trip only touches u_s before its own barrier
+  }
+}
+
+template <int TR, int ILP>
+static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B, int tile, const void* rec64,
+                               const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64, u,
+                     k_b, k_1, du);
+}
+
 template <bool U_IN_LDS, bool ADJ>
 static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, int tile, int n_tiles, const void* rec,
                            const void* pair_k, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
@@ -347,7 +474,7 @@ static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, in
 }
 
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
-                  const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+                  const void* rec64, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
   static int n_cu = 0;
   if (!n_cu) {
@@ -363,6 +490,22 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, con
   if ((size_t)(2 * N) * 8 <= lds_max) {
     const int tile = (int)((N + 1) / 2 * 2);
     const size_t smem = (size_t)(tile + N) * 8;
+    static int use_reg = -1;
+    if (use_reg < 0) { const char* e = getenv("KIN_SWEEP_REG"); use_reg = e ? atoi(e) : 8; }
+    if (adj && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 && N <= 10240) {
+      const int64_t T = P / 1024;   // full record rows available for residency
+#define KIN_REG_GO(TT, II) launch_sweep_reg_t<TT, II>(grid, smem, (int)N, (int)R, (int)P, (int)B, tile, rec64, u, k_b, k_1, du, s)
+      const int want = (int)std::min<int64_t>(use_reg, T);
+      if (want >= 16) KIN_REG_GO(16, 4);
+      else if (want >= 12) KIN_REG_GO(12, 4);
+      else if (want >= 8) KIN_REG_GO(8, 4);
+      else if (want >= 4) KIN_REG_GO(4, 4);
+      else if (use_reg == 1) KIN_REG_GO(0, 8);
+      else KIN_REG_GO(0, 4);
+#undef KIN_REG_GO
+      KIN_HIP(hipGetLastError());
+      return;
+    }
     if (adj) launch_sweep_t<true, true>(grid, smem, (int)N, (int)R, (int)P, (int)B, tile, 1, rec, pair_k, u, k_b, k_1, du, s);
     else launch_sweep_t<true, false>(grid, smem, (int)N, (int)R, (int)P, (int)B, tile, 1, rec, pair_k, u, k_b, k_1, du, s);
   } else {

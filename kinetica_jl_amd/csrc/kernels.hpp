@@ -51,6 +51,6 @@ void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const doubl
 
 // batched sweep over B states, state-major layouts (see kin_rhs_batched_dev); rec = packed 16-byte records
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
-                  const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
+                  const void* rec64, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
 
 }  // namespace kin

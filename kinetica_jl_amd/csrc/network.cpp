@@ -199,6 +199,28 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
     H.pairs_adjacent = (R % 2 == 0) && (H.n_pairs() * 2 == R);
     for (int64_t p = 0; p < H.n_pairs() && H.pairs_adjacent; p++)
       if (H.pair_k[2 * p] != 2 * p || H.pair_k[2 * p + 1] != 2 * p + 1) H.pairs_adjacent = false;
+    if (H.pairs_adjacent && N < 16383) {
+      bool ok = true;
+      for (int64_t p = 0; p < H.n_pairs() && ok; p++) {
+        uint64_t w = 0;
+        uint32_t codes = 0;
+        const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1], co = H.pair_rec[4 * p + 2];
+        const uint32_t sl[4] = {s01 & 0xffffu, s01 >> 16, s23 & 0xffffu, s23 >> 16};
+        for (int j = 0; j < 4; j++) {
+          const int c = (int)(int8_t)(co >> (8 * j));
+          const uint64_t sp = sl[j] == 0xffffu ? 0x3fffu : sl[j];
+          w |= sp << (14 * j);
+          if (sl[j] != 0xffffu) {
+            if (c < -2 || c > 2 || c == 0) { ok = false; break; }
+            codes |= (uint32_t)(c < 0 ? c + 2 : c + 1) << (2 * j);
+          }
+        }
+        w |= (uint64_t)codes << 56;
+        H.pair_rec64.push_back((uint32_t)w);
+        H.pair_rec64.push_back((uint32_t)(w >> 32));
+      }
+      if (!ok) H.pair_rec64.clear();
+    }
   }
 
   // species-major CSR

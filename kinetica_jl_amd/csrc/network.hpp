@@ -61,6 +61,7 @@ struct NetworkHost {
   // pair_k[2p+1]'s companion word pair_ops (explicit operands).
   std::vector<uint32_t> pair_rec;  // 4 words per record: s01, s23, coefs, ops (explicit operands for unpaired records)
   std::vector<int32_t> pair_k;     // 2 per record: kf, kr
+  std::vector<uint32_t> pair_rec64; // 2 words per record (14-bit slots + 2-bit codes); only when N < 16383 and pairs_adjacent
   bool pairs_adjacent = false;     // record p pairs reactions (2p, 2p+1): k streams as double2, no index load
   int64_t n_pairs() const { return (int64_t)pair_k.size() / 2; }
   // species-major CSR: du[i] = sum_e sp_coef[e] * rate[sp_rxn[e]]
