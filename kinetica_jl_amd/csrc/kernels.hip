@@ -56,22 +56,52 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
     const int32_t dst = p.grp_dst[task * 64 + lane];
     const int32_t c0 = p.grp_off[task], c1 = p.grp_off[task + 1];
     double acc = 0.0;
-    for (int32_t col = c0; col < c1; col++) {
-      const size_t idx = (size_t)col * 64 + lane;
-      const float c = p.ell_c[idx];
-      if (c != 0.0f) {
-        if (seg_is_prod<OP>::v) acc += src[p.ell_a[idx]] * src[p.ell_b[idx]];
-        else acc += (double)c * src[p.ell_a[idx]];
+    for (int32_t col = c0; col < c1; col += 4) {
+      // issue the index loads of up to four columns, then their gathers, then accumulate in order
+      float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const size_t idx = (size_t)(col + x) * 64 + lane;
+        const bool ok = col + x < c1;
+        c[x] = ok ? p.ell_c[idx] : 0.0f;
+        ia[x] = ok ? p.ell_a[idx] : 0;
+        ib[x] = (seg_is_prod<OP>::v && ok) ? p.ell_b[idx] : 0;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
+        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
+        else acc += (double)c[x] * va[x];
       }
     }
     if (dst >= 0) seg_store<OP>(out, src, dst, p.grp_aux[task * 64 + lane], acc, ex);
   } else if (task < p.G + p.S) {
     const int sidx = task - p.G;
     const int32_t e0 = p.seg_beg[sidx], e1 = p.seg_end[sidx];
+    // SEG_LEN = 256: at most four entries per lane, all loads in flight together
+    float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      const int32_t e = e0 + lane + 64 * x;
+      const bool ok = e < e1;
+      c[x] = ok ? p.long_c[e] : 0.0f;
+      ia[x] = ok ? p.long_a[e] : 0;
+      ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
+      vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
+    }
     double acc = 0.0;
-    for (int32_t e = e0 + lane; e < e1; e += 64) {
-      if (seg_is_prod<OP>::v) acc += src[p.long_a[e]] * src[p.long_b[e]];
-      else acc += (double)p.long_c[e] * src[p.long_a[e]];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
+      else acc += (double)c[x] * va[x];
     }
     acc = wave_sum(acc);
     if (lane == 0) {

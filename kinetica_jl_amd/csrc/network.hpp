@@ -17,8 +17,11 @@ namespace kin {
 // with several segments are finished by a fix-up pass that adds the partial sums in a fixed
 // order (bitwise reproducible, no atomics).
 struct SegPlanHost {
-  static constexpr int SHORT_MAX = 32;   // rows up to this many entries go to the ELL groups
-  static constexpr int SEG_LEN = 1024;   // entries per long-row segment (16 per lane)
+  // Everything these plans drive is cache resident and latency bound, so the sizes minimise the
+  // longest dependent chain per wavefront: ELL rows are walked 4 columns at a time with all loads
+  // in flight, a segment is consumed in ONE pass of 4 entries per lane.
+  static constexpr int SHORT_MAX = 8;    // rows up to this many entries go to the ELL groups
+  static constexpr int SEG_LEN = 256;    // entries per long-row segment (4 per lane)
   // ELL groups
   std::vector<int32_t> grp_off;  // G+1: first ELL column of each group
   std::vector<int32_t> grp_dst;  // G*64: output index per lane (-1 = idle lane)

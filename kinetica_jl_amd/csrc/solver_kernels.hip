@@ -220,11 +220,19 @@ __global__ __launch_bounds__(1024) void bdf_newton_kernel(int N, int iter, int m
   const double old = ctrl->dy_norm_old;   // read before any thread can reach the final write
   double s = 0.0;
   int bad = 0;
-  for (int i = threadIdx.x; i < N; i += 1024) {
-    const double dy = W[xloc[i]];
-    if (!isfinite(dy)) bad = 1;
-    const double q = dy / scale[i];
-    s += q * q;
+  // four elements per trip with all (dependent) loads in flight: this kernel is pure latency
+  for (int i0 = threadIdx.x; i0 < N; i0 += 4096) {
+    int32_t xl[4]; double dy[4], sc[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { const int i = i0 + 1024 * x; xl[x] = i < N ? xloc[i] : -1; sc[x] = i < N ? scale[i] : 1.0; }
+#pragma unroll
+    for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? W[xl[x]] : 0.0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      if (!isfinite(dy[x])) bad = 1;
+      const double q = dy[x] / sc[x];
+      s += q * q;
+    }
   }
   const double tot = block_sum_1024(s, sh);
   const double nbad = block_sum_1024((double)bad, sh);
@@ -234,10 +242,21 @@ __global__ __launch_bounds__(1024) void bdf_newton_kernel(int N, int iter, int m
   bool diverged = (nbad > 0.0) || !isfinite(dy_norm);
   if (!diverged && have_rate && (rate >= 1.0 || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
   if (!diverged) {
-    for (int i = threadIdx.x; i < N; i += 1024) {
-      const double dy = W[xloc[i]];
-      y[i] += dy;
-      d[i] += dy;
+    for (int i0 = threadIdx.x; i0 < N; i0 += 4096) {
+      int32_t xl[4]; double dy[4], yy[4], dd[4];
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const int i = i0 + 1024 * x;
+        xl[x] = i < N ? xloc[i] : -1;
+        yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? W[xl[x]] : 0.0;
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const int i = i0 + 1024 * x;
+        if (i < N) { y[i] = yy[x] + dy[x]; d[i] = dd[x] + dy[x]; }
+      }
     }
   }
   if (threadIdx.x == 0) {
