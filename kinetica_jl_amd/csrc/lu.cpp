@@ -216,9 +216,8 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
 
   W.alloc((size_t)w_size);
   KIN_HIP(hipMemsetAsync(W.p, 0, (size_t)w_size * sizeof(double), s));
-  pinv.alloc(32 * 32);
-  rowp.alloc((size_t)32 * std::max(mpad, 64));
-  colp.alloc((size_t)32 * std::max(mpad, 64));
+  pinv.alloc(2 * 32 * 32);
+  S2.alloc((size_t)std::max(mpad, 64) * std::max(mpad, 64));
   KIN_HIP(hipStreamSynchronize(s));
 }
 
@@ -230,7 +229,7 @@ void SparseLU::factor(double c, const double* d_jvals, hipStream_t s) {
     launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W.p, off_L, off_diag, s);
     launch_segsum(schur[r].view(), SEG_PROD_SUB, W.p, W.p, SegExtra{}, s);
   }
-  if (m > 0) launch_gauss_jordan(W.p + off_S, mpad, pinv.p, rowp.p, colp.p, s);
+  if (m > 0) sinv = launch_gauss_jordan(W.p + off_S, S2.p, mpad, pinv.p, s);
 }
 
 void SparseLU::solve(const int* skip, hipStream_t s) {
@@ -239,7 +238,7 @@ void SparseLU::solve(const int* skip, hipStream_t s) {
   for (int r = 1; r < nrounds; r++) launch_segsum(fwd[r].view(), SEG_PROD_SUB, W.p, W.p, ex, s);
   if (m > 0) {
     if (ns > 0) launch_segsum(fwd_dense.view(), SEG_PROD_SUB, W.p, W.p, ex, s);
-    launch_gemv(W.p + off_S, mpad, m, W.p + off_y + ns, W.p + off_x, skip, s);
+    launch_gemv(sinv, mpad, m, W.p + off_y + ns, W.p + off_x, skip, s);
   }
   for (int r = nrounds - 1; r >= 0; r--) launch_segsum(bwd[r].view(), SEG_PROD_SUB_DIV, W.p, W.p, ex, s);
 }

@@ -42,7 +42,8 @@ struct SparseLU {
   int64_t off_diag = 0, off_U = 0, off_L = 0, off_S = 0, off_y = 0, off_x = 0, w_size = 0;
 
   DevBuf<double> W;
-  DevBuf<double> pinv, rowp, colp;          // Gauss-Jordan panels
+  DevBuf<double> pinv, S2;                  // Gauss-Jordan pivot block inverse, ping-pong copy of the Schur block
+  const double* sinv = nullptr;             // where the inverse of the Schur block ended up (S or S2)
   DevBuf<int32_t> jmap;                     // J entry -> W position (bit 31: diagonal)
   DevBuf<int32_t> ent_pivot;                // sparse entry -> its pivot
   DevBuf<int32_t> yloc, xloc;               // species -> position of its rhs / solution in W
@@ -64,7 +65,7 @@ struct SparseLU {
 void launch_lu_assemble(int64_t nnzJ, const int32_t* jmap, const double* jvals, double c, double* W,
                         int64_t off_S, int32_t m, int32_t mpad, hipStream_t s);
 void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, hipStream_t s);
-void launch_gauss_jordan(double* S, int32_t mpad, double* pinv, double* rowp, double* colp, hipStream_t s);
+double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, hipStream_t s);
 void launch_gemv(const double* S, int32_t ld, int32_t m, const double* y, double* x, const int* skip, hipStream_t s);
 
 }  // namespace kin

@@ -6,6 +6,8 @@
 #include "lu.hpp"
 #include "solver_kernels.hpp"
 
+#include <utility>
+
 namespace kin {
 
 // ------------------------------------------------------------------------------------------
@@ -50,105 +52,162 @@ void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W
 }
 
 // ------------------------------------------------------------------------------------------
-// In-place blocked Gauss-Jordan inverse of the dense Schur block (no pivoting), NB = 32.
-// Per block step k:  P^-1 ; row panel = P^-1 * S[k,:] ; every other block row  S[i,:] -= S[i,k] * panel
-// (column k of the result is -S[i,k] * P^-1). 2 m^3 flops in rank-32 updates.
+// Blocked Gauss-Jordan inverse of the dense Schur block (no pivoting), NB = 32, 2 m^3 flops.
+// Block step k reads the current matrix X and writes the next one Y (ping-pong, so no tile ever
+// reads what another workgroup of the same launch writes):
+//     P  = X[k,k]^-1                                  (gj_pivot_kernel, one small workgroup)
+//     Y[k,:]  = P * X[k,:]          , Y[k,k] = P
+//     Y[i,:]  = X[i,:] - X[i,k] * Y[k,:]   , Y[i,k] = -X[i,k] * P          (gj_update_kernel)
+// The update runs on the matrix cores (v_mfma_f64_16x16x4_f64): each 64x64 tile first forms its
+// 32x64 slice of the row panel (P times X[k, tile columns]) into LDS, then applies the rank-32
+// update. Operand layout probed on gfx950 (tools/mfma_probe.hip): A[i][k] in lane i + 16k,
+// B[k][j] in lane j + 16k, D[i][j] in lane 16*(i % 4) + j, register i / 4.
 // ------------------------------------------------------------------------------------------
 constexpr int GJ_NB = 32;
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(1024) void gj_pivot_kernel(const double* __restrict__ S, int ld, int kb, double* __restrict__ pinv) {
-  __shared__ double A[GJ_NB][GJ_NB + 1];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  A[ty][tx] = S[(size_t)(kb * GJ_NB + ty) * ld + kb * GJ_NB + tx];
-  __syncthreads();
-  for (int k = 0; k < GJ_NB; k++) {
-    const double piv = A[k][k];
-    const double akj = (tx == k) ? 1.0 : A[k][tx];
-    const double aik = A[ty][k];
-    const double old = (tx == k) ? 0.0 : A[ty][tx];
-    __syncthreads();
-    const double rowk = akj / piv;
-    A[ty][tx] = (ty == k) ? rowk : old - aik * rowk;
-    __syncthreads();
-  }
-  pinv[ty * GJ_NB + tx] = A[ty][tx];
+__device__ __forceinline__ double fast_recip(double x) {
+  double r = __builtin_amdgcn_rcp(x);     // v_rcp_f64, then two Newton steps (quadratic: full precision)
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
 }
 
-// one workgroup per 32-column block cb: rowp[:, cb] = P^-1 * S[kb, cb]  (P^-1 itself for cb == kb),
-// written to the panel buffer and back into S; also saves column panel S[cb rows, kb] to colp.
-__global__ __launch_bounds__(1024) void gj_panel_kernel(double* S, int ld, int kb, const double* __restrict__ pinv,
-                                                        double* __restrict__ rowp, double* __restrict__ colp) {
-  __shared__ double P[GJ_NB][GJ_NB + 1];
-  __shared__ double B[GJ_NB][GJ_NB + 1];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int cb = blockIdx.x;
-  // column panel copy first (block row cb, block column kb); block row kb is not used later
-  colp[(size_t)(cb * GJ_NB + ty) * GJ_NB + tx] = S[(size_t)(cb * GJ_NB + ty) * ld + kb * GJ_NB + tx];
-  P[ty][tx] = pinv[ty * GJ_NB + tx];
-  B[ty][tx] = S[(size_t)(kb * GJ_NB + ty) * ld + cb * GJ_NB + tx];
-  __syncthreads();
-  double acc;
-  if (cb == kb) acc = P[ty][tx];
-  else {
-    acc = 0.0;
+// 32 dependent elimination steps on a 32x32 block held in a double-buffered LDS image (one barrier
+// per step); 256 threads, thread = (row, 4 consecutive columns). Result goes to `pinv`.
+__device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1], double* __restrict__ pinv) {
+  const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+  int cur = 0;
+  for (int k = 0; k < GJ_NB; k++) {
+    const double inv = fast_recip(A[cur][k][k]);
+    const double aik = A[cur][r][k];
 #pragma unroll
-    for (int k = 0; k < GJ_NB; k++) acc += P[ty][k] * B[k][tx];
+    for (int j = 0; j < 4; j++) {
+      const bool kc = (c0 + j == k);
+      const double rk = (kc ? 1.0 : A[cur][k][c0 + j]) * inv;
+      A[cur ^ 1][r][c0 + j] = (r == k) ? rk : (kc ? 0.0 : A[cur][r][c0 + j]) - aik * rk;
+    }
+    __syncthreads();
+    cur ^= 1;
   }
-  rowp[(size_t)ty * ld + cb * GJ_NB + tx] = acc;
+#pragma unroll
+  for (int j = 0; j < 4; j++) pinv[r * GJ_NB + c0 + j] = A[cur][r][c0 + j];
 }
 
-// 64x64 output tile per workgroup (256 threads, 4x4 per thread), K = 32
-__global__ __launch_bounds__(256) void gj_update_kernel(double* S, int ld, int kb, const double* __restrict__ rowp,
-                                                        const double* __restrict__ colp) {
-  __shared__ double Cs[64][GJ_NB + 1];   // colp tile: rows x k
-  __shared__ double Rs[GJ_NB][64 + 1];   // rowp tile: k x cols
-  const int tid = threadIdx.x;
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  for (int q = tid; q < 64 * GJ_NB; q += 256) {
-    const int i = q >> 5, k = q & 31;
-    Cs[i][k] = colp[(size_t)(r0 + i) * GJ_NB + k];
-  }
-  for (int q = tid; q < GJ_NB * 64; q += 256) {
-    const int k = q >> 6, j = q & 63;
-    Rs[k][j] = rowp[(size_t)k * ld + c0 + j];
-  }
+__global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv) {
+  __shared__ double A[2][GJ_NB][GJ_NB + 1];
+  const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) A[0][r][c0 + j] = X[(size_t)(kb * GJ_NB + r) * ld + kb * GJ_NB + c0 + j];
   __syncthreads();
-  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
-  double acc[4][4] = {};
-#pragma unroll 8
-  for (int k = 0; k < GJ_NB; k++) {
-    double a[4], b[4];
-#pragma unroll
-    for (int x = 0; x < 4; x++) { a[x] = Cs[ti + x][k]; b[x] = Rs[k][tj + x]; }
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-#pragma unroll
-      for (int y = 0; y < 4; y++) acc[x][y] += a[x] * b[y];
-  }
+  gj_invert_block_lds(A, pinv);
+}
+
+// grid = (mpad/64, mpad/64 + 1): the extra block row holds ONE active workgroup (blockIdx.x == 0) that
+// looks ahead: it recomputes only the next pivot block of Y and inverts it into pinv_next while the
+// regular workgroups update their tiles, which takes the pivot inversion off the critical path.
+__global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict__ X, double* __restrict__ Y, int ld, int kb,
+                                                        int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next) {
+  __shared__ double RP[GJ_NB][64 + 2];                 // row panel slice of this tile's columns
+  __shared__ double A[2][GJ_NB][GJ_NB + 1];            // look-ahead workgroup only
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
   const int kr0 = kb * GJ_NB, kr1 = kr0 + GJ_NB;
+  if (blockIdx.y == gridDim.y - 1) {
+    const int kn = kb + 1;
+    if (blockIdx.x != 0 || kn >= nblk) return;
+    const int n0 = kn * GJ_NB;                           // next pivot block: rows/cols n0..n0+31 (never pivot rows/cols of step kb)
+    const int rb = w >> 1, cb = w & 1;
+    {  // RP[0:32][0:32] = P * X[k rows, n0 + cols]
+      gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int x = 0; x < 4; x++) {
-    const int i = r0 + ti + x;
-    const bool pivot_row = (i >= kr0 && i < kr1);
+      for (int ks = 0; ks < 8; ks++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pinv[(16 * rb + li) * GJ_NB + 4 * ks + lk],
+                                                   X[(size_t)(kr0 + 4 * ks + lk) * ld + n0 + 16 * cb + li], acc, 0, 0, 0);
 #pragma unroll
-    for (int y = 0; y < 4; y++) {
-      const int j = c0 + tj + y;
-      double* p = S + (size_t)i * ld + j;
-      if (pivot_row) *p = Rs[i - kr0][tj + y];                     // row panel goes back into S
-      else if (j >= kr0 && j < kr1) *p = -acc[x][y];                 // column kb: -C * P^-1
-      else *p = *p - acc[x][y];
+      for (int v = 0; v < 4; v++) RP[16 * rb + 4 * v + lk][16 * cb + li] = acc[v];
+    }
+    __syncthreads();
+    {  // A[0] = X[n0 rows, n0 cols] - X[n0 rows, k cols] * RP
+      gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(size_t)(n0 + 16 * rb + li) * ld + kr0 + 4 * ks + lk],
+                                                   RP[4 * ks + lk][16 * cb + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = 16 * rb + 4 * v + lk, j = 16 * cb + li;
+        A[0][i][j] = X[(size_t)(n0 + i) * ld + n0 + j] - acc[v];
+      }
+    }
+    __syncthreads();
+    gj_invert_block_lds(A, pinv_next);
+    return;
+  }
+  const int r0 = blockIdx.y * 64 + 16 * w, c0 = blockIdx.x * 64;
+  // ---- row panel: wave w forms columns 16w..16w+15 (two 16-row blocks), RP = P * X[k rows, cols]
+  {
+    const int jc = c0 + 16 * w + li;
+    const bool pivot_cols = (c0 + 16 * w >= kr0 && c0 + 16 * w < kr1);   // 16-column block inside the pivot block
+    double bx[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) bx[ks] = X[(size_t)(kr0 + 4 * ks + lk) * ld + jc];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+      gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const double ap = pinv[(16 * rb + li) * GJ_NB + 4 * ks + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bx[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = 16 * rb + 4 * v + lk;                                  // panel row
+        RP[i][16 * w + li] = pivot_cols ? pinv[i * GJ_NB + (jc - kr0)] : acc[v];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- rank-32 update of this wave's 16 rows x 64 columns
+  const bool pivot_rows = (r0 >= kr0 && r0 < kr1);
+  double a[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) a[ks] = X[(size_t)(r0 + li) * ld + kr0 + 4 * ks + lk];
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++) {
+    gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (!pivot_rows) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], RP[4 * ks + lk][16 * blk + li], acc, 0, 0, 0);
+    }
+    const int j = c0 + 16 * blk + li;
+    const bool pivot_col = (j >= kr0 && j < kr1);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = r0 + 4 * v + lk;
+      const size_t off = (size_t)i * ld + j;
+      if (pivot_rows) Y[off] = RP[i - kr0][16 * blk + li];
+      else if (pivot_col) Y[off] = -acc[v];
+      else Y[off] = X[off] - acc[v];
     }
   }
 }
 
-void launch_gauss_jordan(double* S, int32_t mpad, double* pinv, double* rowp, double* colp, hipStream_t s) {
+// returns the buffer that holds the inverse (S or S2)
+double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, hipStream_t s) {
   const int nblk = mpad / GJ_NB;
+  double* X = S;
+  double* Y = S2;
+  double* p_cur = pinv;                 // two 32x32 slots: current / next pivot-block inverse
+  double* p_next = pinv + GJ_NB * GJ_NB;
+  hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, s, X, mpad, 0, p_cur);
   for (int kb = 0; kb < nblk; kb++) {
-    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(1024), 0, s, S, mpad, kb, pinv);
-    hipLaunchKernelGGL(gj_panel_kernel, dim3(nblk), dim3(1024), 0, s, S, mpad, kb, pinv, rowp, colp);
-    hipLaunchKernelGGL(gj_update_kernel, dim3(mpad / 64, mpad / 64), dim3(256), 0, s, S, mpad, kb, rowp, colp);
+    hipLaunchKernelGGL(gj_update_kernel, dim3(mpad / 64, mpad / 64 + 1), dim3(256), 0, s, X, Y, mpad, kb, nblk, p_cur, p_next);
+    std::swap(X, Y);
+    std::swap(p_cur, p_next);
   }
   KIN_HIP(hipGetLastError());
+  return X;
 }
 
 // x = S[0:m, 0:m] * y : one wavefront per row
