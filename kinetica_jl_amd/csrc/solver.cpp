@@ -165,12 +165,21 @@ struct Solver {
 
   // one accepted step towards t_bound (internally retries rejected attempts)
   StepStatus step(double t_bound) {
-    bool accepted = false;
+    bool accepted = false, first_attempt = true;
     double safety = 0.9, err_norm = 0.0, t_new = t;
     while (!accepted) {
       if (iters_left-- <= 0) return STEP_OK;  // caller checks iters_left < 0 -> MaxIters
       const double min_step = std::max(dtmin, 10.0 * (std::nextafter(t, INF) - t));
-      if (h_abs < min_step) return STEP_DT_MIN;
+      if (h_abs < min_step) {
+        if (!first_attempt) return STEP_DT_MIN;
+        // a step that merely STARTS below the resolution of t is raised to it (it only fails if
+        // the corrector / error test push it below again)
+        change_D(order, min_step / h_abs);
+        h_abs = min_step;
+        n_equal = 0;
+        lu_valid = false;
+      }
+      first_attempt = false;
       t_new = t + h_abs;
       if (t_new - t_bound > 0.0) {
         t_new = t_bound;
@@ -445,26 +454,32 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
           if (loc < t_loc1) { seg_end = loc; ends_at_stop = true; }
         }
         if (seg_end > t_seg) {
-          if (!S.restart(t_seg, seg_end)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
-          while (S.t < seg_end) {
-            StepStatus ss = S.step(seg_end);
+          // Every segment is integrated in segment-local time tau in [0, seg_len]: the rates are
+          // constant inside a segment (autonomous system), and restarting at tau = 0 keeps the tiny
+          // first steps of a restart (1e-20 s is common) above the floating-point resolution of the
+          // time variable - the underflow the reference's chunking exists to avoid
+          // (docs/src/development/implementation-details.md:5-28) but re-creates at tstops > 0.
+          const double seg_len = seg_end - t_seg;
+          if (!S.restart(0.0, seg_len)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
+          while (S.t < seg_len) {
+            StepStatus ss = S.step(seg_len);
             if (S.iters_left < 0) { retcode = KIN_RETCODE_MAXITERS; failed = true; break; }
             if (ss == STEP_DT_MIN) { retcode = KIN_RETCODE_DTLESSTHANMIN; failed = true; break; }
             if (ss == STEP_UNSTABLE) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
+            const double t_abs = S.t >= seg_len ? seg_end : t_seg + S.t;   // chunk-local time reached
             // saves covered by this step
             if (L > 0) {
               const int64_t last = chunks ? L - 1 : L;   // the chunk's last point is saved below
-              while (save_i < last && save_local[save_i] <= S.t) {
-                if (chunks && save_i == L - 1) break;
+              while (save_i < last && save_local[save_i] <= t_abs) {
                 sb.reserve(h->n_saved + 1);
-                S.interpolate(save_local[save_i], sb.row(h->n_saved));
+                S.interpolate(std::min(save_local[save_i] - t_seg, S.t), sb.row(h->n_saved));
                 sb.push_time(save_local[save_i] + shift);
                 save_i++;
               }
             } else {
               sb.reserve(h->n_saved + 1);
               KIN_HIP(hipMemcpyAsync(sb.row(h->n_saved), S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
-              sb.push_time(S.t + shift);
+              sb.push_time(t_abs + shift);
             }
             S.select_order();
           }

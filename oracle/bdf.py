@@ -137,13 +137,21 @@ class OracleBDF:
         """One accepted step towards t_bound. Returns 'ok' | 'dtmin' | 'maxiters'."""
         t, D, order = self.t, self.D, self.order
         accepted = False
+        first_attempt = True
         while not accepted:
             self.iters_left -= 1
             if self.iters_left < 0:
                 return "maxiters"
             min_step = max(self.dtmin, 10 * (np.nextafter(t, np.inf) - t))
             if self.h_abs < min_step:
-                return "dtmin"
+                if not first_attempt:
+                    return "dtmin"
+                # a step that merely starts below the resolution of t is raised to it
+                change_D(D, order, min_step / self.h_abs)
+                self.h_abs = min_step
+                self.n_equal = 0
+                self.LU = None
+            first_attempt = False
             t_new = t + self.h_abs
             if t_new - t_bound > 0:
                 t_new = t_bound
@@ -329,25 +337,28 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                     if loc < t_loc1:
                         seg_end, ends_at_stop = loc, True
                 if seg_end > t_seg:
-                    if not bdf.restart(t_seg, y, seg_end):
+                    # segment-local time (see solver.cpp): restart at tau = 0, integrate to seg_len
+                    seg_len = seg_end - t_seg
+                    if not bdf.restart(0.0, y, seg_len):
                         retcode, failed = RET_UNSTABLE, True
                         break
-                    while bdf.t < seg_end:
-                        status = bdf.step(seg_end)
+                    while bdf.t < seg_len:
+                        status = bdf.step(seg_len)
                         if status == "maxiters":
                             retcode, failed = RET_MAXITERS, True
                             break
                         if status == "dtmin":
                             retcode, failed = RET_DTMIN, True
                             break
+                        t_abs = seg_end if bdf.t >= seg_len else t_seg + bdf.t
                         if L > 0:
                             last_i = L - 1 if chunks else L
-                            while save_i < last_i and save_local[save_i] <= bdf.t:
+                            while save_i < last_i and save_local[save_i] <= t_abs:
                                 out_t.append(save_local[save_i] + shift)
-                                out_u.append(bdf.interpolate(save_local[save_i]))
+                                out_u.append(bdf.interpolate(min(save_local[save_i] - t_seg, bdf.t)))
                                 save_i += 1
                         else:
-                            out_t.append(bdf.t + shift); out_u.append(bdf.D[0].copy())
+                            out_t.append(t_abs + shift); out_u.append(bdf.D[0].copy())
                         bdf.select_order()
                     if failed:
                         break

@@ -172,4 +172,41 @@ def test_full_size_properties_c3():
     # forward/reverse pairs cancel exactly at k_f * prod(u_reac) == k_r * prod(u_prod): use u = 1, k = 1
     h.set_rates(np.ones(50000))
     assert np.all(np.abs(h.rhs(np.ones(10000))) < 1e-9)
+    # mass conservation (every generated reaction balances): sum_i m_i du_i = 0 up to round-off
+    h.set_rates(k)
+    assert abs(np.dot(net.mass, du)) <= 1e-11 * np.dot(net.mass, on.abs_rhs(k, u))
+    B = 64
+    U = np.stack([_state(10000, 100 + b) for b in range(B)])
+    dU = h.rhs_batched(U)
+    scale = np.array([np.dot(net.mass, on.abs_rhs(k, U[b])) for b in (0, B - 1)])
+    assert abs(np.dot(dU[0], net.mass)) <= 1e-11 * scale[0] and abs(np.dot(dU[B - 1], net.mass)) <= 1e-11 * scale[1]
+    h.close()
+
+
+def test_full_size_properties_c5_tiled_sweep():
+    """C5 size (50k / 250k): the batched sweep takes the species-tiled path (state too large for
+    LDS); checked against the single-state kernel, the oracle (spot states) and for linearity."""
+    net, Ea, A = synthetic_crn(50000, 250000)
+    h = capi.HipNetwork.from_flat(net)
+    on = orc.OracleNetwork.from_flat(net)
+    k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
+    h.set_rates(k)
+    B = 5
+    U = np.stack([_state(50000, 40 + b) for b in range(B)])
+    rng = np.random.default_rng(9)
+    K = k[None, :] * rng.uniform(0.5, 2.0, (B, 1))
+    got = h.rhs_batched(U, K)
+    for b in (0, B - 1):
+        sc = on.abs_rhs(K[b], U[b]) + 1e-300
+        assert (np.abs(got[b] - on.rhs(K[b], U[b])) / sc).max() < TOL
+    single = h.rhs(U[2])
+    shared = h.rhs_batched(U[2:3])[0]
+    sc = on.abs_rhs(k, U[2]) + 1e-300
+    assert (np.abs(single - shared) / sc).max() < TOL
+    assert (np.abs(single - on.rhs(k, U[2])) / sc).max() < TOL
+    # Jacobian at this size: oracle comparison
+    rowptr, col = h.jac_pattern()
+    Jd = sp.csr_matrix((h.jac_values(U[0]), col, rowptr), shape=(50000, 50000))
+    Jo = on.jac(k, U[0])
+    assert abs(Jd - Jo).max() <= TOL * abs(Jo).max()
     h.close()

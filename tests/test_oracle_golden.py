@@ -181,5 +181,13 @@ def test_synthetic_crn_is_seeded_and_valid():
     assert np.add.reduceat(n1.reac_sto, n1.reac_ptr[:-1]).max() <= 2
     assert np.add.reduceat(n1.prod_sto, n1.prod_ptr[:-1]).max() <= 2
     assert len(np.unique(np.concatenate([n1.reac_idx, n1.prod_idx]))) == 200
-    assert (Ea1 == 0).mean() == pytest.approx(0.25, abs=0.05) and Ea1.max() < 6e5
+    assert (Ea1 == 0).mean() == pytest.approx(0.25, abs=0.05) and Ea1.max() < 6.5e5
     assert 10 ** 8.8 <= A1.min() and A1.max() <= 10 ** 12.3
+    # mass conservation: every reaction balances, so sum_i m_i du_i = 0 for any state and any k
+    on = orc.OracleNetwork.from_flat(n1)
+    rng = np.random.default_rng(3)
+    k = rng.uniform(0.1, 10.0, 1000); u = rng.uniform(0.0, 1.0, 200)
+    assert abs(np.dot(n1.mass, on.rhs(k, u))) <= 1e-12 * np.dot(n1.mass, on.abs_rhs(k, u))
+    # detailed balance before the cap: k_f / k_r = exp(-dG / RT) with a common prefactor
+    assert np.array_equal(A1[0::2], A1[1::2]) and np.all(np.minimum(Ea1[0::2], Ea1[1::2]) >= 0)
+    assert np.all((Ea1[0::2] == 0) | (Ea1[1::2] == 0) | (np.minimum(Ea1[0::2], Ea1[1::2]) > 0))
