@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict_
   gj_invert_block_lds(A, pinv);
 }
 
-// grid = (mpad/64, mpad/64 + 1): the extra block row holds ONE active workgroup (blockIdx.x == 0) that
+// grid = (mpad/64, 1 + mpad/64): block row 0 (dispatched first) holds ONE active workgroup (blockIdx.x == 0) that
 // looks ahead: it recomputes only the next pivot block of Y and inverts it into pinv_next while the
 // regular workgroups update their tiles, which takes the pivot inversion off the critical path.
 __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict__ X, double* __restrict__ Y, int ld, int kb,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int kr0 = kb * GJ_NB, kr1 = kr0 + GJ_NB;
-  if (blockIdx.y == gridDim.y - 1) {
+  if (blockIdx.y == 0) {
     const int kn = kb + 1;
     if (blockIdx.x != 0 || kn >= nblk) return;
     const int n0 = kn * GJ_NB;                           // next pivot block: rows/cols n0..n0+31 (never pivot rows/cols of step kb)
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
     gj_invert_block_lds(A, pinv_next);
     return;
   }
-  const int r0 = blockIdx.y * 64 + 16 * w, c0 = blockIdx.x * 64;
+  const int r0 = (blockIdx.y - 1) * 64 + 16 * w, c0 = blockIdx.x * 64;
   // ---- row panel: wave w forms columns 16w..16w+15 (two 16-row blocks), RP = P * X[k rows, cols]
   {
     const int jc = c0 + 16 * w + li;

@@ -25,11 +25,11 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w", newline="") a
 def pmc(sub, name):
     f = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)[0]
     return [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "sweep_lds_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if "kin::sweep_" in r["Kernel_Name"] and r["Counter_Name"] == name]
 
 
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
-sweep = [r for r in rows if "sweep_lds_kernel" in r["Name"]][0]
+sweep = [r for r in rows if "kin::sweep_" in r["Name"]][0]
 line = [l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")][-1]
 bench = json.loads(line)
 summary = {
