@@ -64,6 +64,7 @@ struct Solver {
   double t = 0, h_abs = 0, atol = 0, rtol = 0, newton_tol = 0, dtmin = 0;
   int order = 1, n_equal = 0;
   bool lu_valid = false, jac_current = false, ban_negatives = false;
+  double fail_score = 0.0;   // leaky count of rejected attempts (history reset at 3, see reset_history)
   kin_stats st{};
   int64_t iters_left = 0;
 
@@ -147,9 +148,39 @@ struct Solver {
     launch_bdf_init_D(N, BDF_D_ROWS, y.p, f0.p, h_abs, D.p, s);
     order = 1;
     n_equal = 0;
+    fail_score = 0.0;
     eval_jac(y.p);
     jac_current = true;
     return true;
+  }
+
+  // After repeated step failures the interpolated difference history is not trusted any more: drop
+  // to order 1 and rebuild it from f at the current state, keeping the (already reduced) step size -
+  // CVODE's strategy after MXNEF1 error-test failures (oracle/bdf.py: _reset_history).
+  void reset_history() {
+    KIN_HIP(hipMemcpyAsync(ytmp.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    rhs(ytmp.p, f0.p);
+    launch_bdf_init_D(N, BDF_D_ROWS, ytmp.p, f0.p, h_abs, D.p, s);
+    order = 1;
+    n_equal = 0;
+    lu_valid = false;
+    fail_score = 0.0;
+  }
+
+  // Warm continuation at a segment boundary (chunk start or rate update): the system is autonomous
+  // and segments run in local time, so the difference history, order and step size stay valid;
+  // only the Jacobian (and with it the iteration matrix) is refreshed when the rates changed.
+  // The reference re-initialises its integrator there (reinit!, methods.jl:260, 819 - order 1 and a
+  // ~1e-20 s first step, i.e. ~60 steps and ~20 factorisations per segment); results agree within
+  // the solver tolerance. Opt-in (KIN_WARM_RESTART=1); the default re-initialises like the reference.
+  void resume(bool rates_changed) {
+    t = 0.0;
+    st.n_restarts++;
+    if (rates_changed) {
+      KIN_HIP(hipMemcpyAsync(y.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+      eval_jac(y.p);
+      jac_current = true;
+    }
   }
 
   void newton_iteration(int it, double c) {
@@ -224,6 +255,8 @@ struct Solver {
         n_equal = 0;
         lu_valid = false;
         st.n_rejected++;
+        fail_score += 1.0;
+        if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
       }
       safety = 0.9 * (2.0 * BDF_NEWTON_MAXITER + 1.0) / (2.0 * BDF_NEWTON_MAXITER + hc->n_iter);
@@ -235,11 +268,14 @@ struct Solver {
         n_equal = 0;
         // the corrector converged with this iteration matrix: it is kept for the retry
         st.n_rejected++;
+        fail_score += 1.0;
+        if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
         accepted = true;
       }
     }
     st.n_steps++;
+    fail_score = std::max(0.0, fail_score - 0.2);
     n_equal++;
     t = t_new;
     launch_bdf_accept(N, order, D.p, d.p, s);
@@ -399,6 +435,12 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   const double t_origin = chunks ? 0.0 : p.tspan0;
   DevBuf<double> chunk_start;
   chunk_start.alloc(N);
+  bool have_history = false, rates_changed = false;
+  int64_t rates_in_force = -1;
+  // default: re-initialise at every segment start like the reference; KIN_WARM_RESTART=1 opts in to
+  // the warm continuation (experimental: larger steps make tolerance-level negative undershoots of
+  // species with fast self-reactions more likely, and d/dt u = -2 k u^2 runs away once u < 0)
+  static const bool cold_restarts = !(getenv("KIN_WARM_RESTART") && atoi(getenv("KIN_WARM_RESTART")) != 0);
 
   // initial rates = calculator at the initial conditions (methods.jl:672, 734); a tstop at the
   // very start overrides it below
@@ -422,6 +464,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     int attempts = 0;
     for (;;) {  // adaptive_solve! (solve_utils.jl:376-424)
       attempts++;
+      if (attempts > 1) have_history = false;   // a retry starts cold from the chunk's first state
       retcode = KIN_RETCODE_SUCCESS;
       S.iters_left = p.maxiters;
       int64_t stop_i = stop_first;
@@ -430,8 +473,8 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
         stop_i++;
       }
       if (variable) {
-        if (stop_i > 0) apply_rates(h, T_stops, have_table, stop_i - 1);
-        else apply_rates(h, T_stops, have_table, 0);  // before the first stop: initial conditions
+        const int64_t want = stop_i > 0 ? stop_i - 1 : 0;   // before the first stop: initial conditions
+        if (want != rates_in_force) { apply_rates(h, T_stops, have_table, want); rates_in_force = want; rates_changed = true; }
       }
       int64_t save_i = 0;
       double t_seg = t_loc0;
@@ -460,7 +503,10 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
           // time variable - the underflow the reference's chunking exists to avoid
           // (docs/src/development/implementation-details.md:5-28) but re-creates at tstops > 0.
           const double seg_len = seg_end - t_seg;
-          if (!S.restart(0.0, seg_len)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
+          if (have_history && !cold_restarts) S.resume(rates_changed);
+          else if (!S.restart(0.0, seg_len)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
+          have_history = true;
+          rates_changed = false;
           while (S.t < seg_len) {
             StepStatus ss = S.step(seg_len);
             if (S.iters_left < 0) { retcode = KIN_RETCODE_MAXITERS; failed = true; break; }
@@ -488,7 +534,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
           KIN_HIP(hipMemcpyAsync(S.y.p, S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         t_seg = seg_end;
-        if (ends_at_stop) { apply_rates(h, T_stops, have_table, stop_i); stop_i++; }
+        if (ends_at_stop) { apply_rates(h, T_stops, have_table, stop_i); rates_in_force = stop_i; stop_i++; rates_changed = true; }
       }
       if (!failed) {
         // all but the chunk's last save point go to the output, the last only on the final chunk
@@ -498,6 +544,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
         break;
       }
       // ---- failure: tighten tolerances and redo this chunk from its start state
+      rates_in_force = -1;
       const double mintol = std::numeric_limits<double>::epsilon();
       if (!p.adaptive_tols || attempts >= 5 || abstol / 10 <= mintol || reltol / 10 <= mintol) break;
       abstol /= 10; reltol /= 10;

@@ -131,7 +131,34 @@ class OracleBDF:
         self.LU = None
         self.jac_current = True
         self.pending = None
+        self.fail_score = 0.0
         return True
+
+    def _reset_history(self):
+        """After repeated step failures the interpolated difference history is not trusted any more:
+        drop to order 1 and rebuild it from f at the current state, keeping the (already reduced)
+        step size - CVODE's strategy after MXNEF1 error-test failures (Hindmarsh et al., SUNDIALS,
+        ACM TOMS 31, 2005, sec. 2.1)."""
+        y0 = self.D[0].copy()
+        f0 = self._f(y0)
+        self.D[:] = 0.0
+        self.D[0] = y0
+        self.D[1] = f0 * self.h_abs
+        self.order = 1
+        self.n_equal = 0
+        self.LU = None
+        self.fail_score = 0.0
+        self.stats["n_resets"] = self.stats.get("n_resets", 0) + 1
+
+    def resume(self, rates_changed):
+        """Warm continuation at a segment boundary (see Solver::resume in solver.cpp): history, order
+        and step size are kept, the Jacobian is refreshed when the rates changed."""
+        self.stats["n_restarts"] += 1
+        self.t = 0.0
+        if rates_changed:
+            self.J = self.jac(self.D[0]); self.stats["n_jac"] += 1
+            self.LU = None
+            self.jac_current = True
 
     def step(self, t_bound):
         """One accepted step towards t_bound. Returns 'ok' | 'dtmin' | 'maxiters'."""
@@ -183,6 +210,10 @@ class OracleBDF:
                 self.n_equal = 0
                 self.LU = None
                 self.stats["n_rejected"] += 1
+                self.fail_score += 1.0
+                if self.fail_score >= 3.0 and order > 1:
+                    self._reset_history()
+                    order = self.order
                 continue
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter)
             scale = self.atol + self.rtol * np.abs(y_new)
@@ -194,9 +225,14 @@ class OracleBDF:
                 self.n_equal = 0
                 # the corrector converged with this iteration matrix: it is kept for the retry
                 self.stats["n_rejected"] += 1
+                self.fail_score += 1.0
+                if self.fail_score >= 3.0 and order > 1:
+                    self._reset_history()
+                    order = self.order
             else:
                 accepted = True
         self.stats["n_steps"] += 1
+        self.fail_score = max(0.0, self.fail_score - 0.2)
         self.n_equal += 1
         self.t = t_new
         D[order + 2] = d - D[order + 1]
@@ -306,6 +342,10 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
     next_stop = 0
     retcode = RET_SUCCESS
     n_retries = 0
+    have_history, rates_changed, rates_in_force = False, False, -1
+    # default: re-initialise at every segment start like the reference (reinit!, methods.jl:260, 819);
+    # warm continuation is an opt-in experiment (see Solver::resume in solver.cpp)
+    cold_restarts = bool(params.get("cold_restarts", True))
     for nc in range(n_chunks):
         t_start_g = chunkstep * nc if chunks else tspan0
         t_end_g = t_start_g + chunkstep if chunks else tspan1
@@ -316,13 +356,17 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
         attempts = 0
         while True:
             attempts += 1
+            if attempts > 1:
+                have_history = False
             retcode = RET_SUCCESS
             bdf.iters_left = maxiters
             stop_i = next_stop
             while variable and stop_i < len(tstops) and tstops[stop_i] <= t_start_g:
                 stop_i += 1
-            if variable:
-                state["k"] = k_of_stop(max(stop_i - 1, 0))
+            if variable and max(stop_i - 1, 0) != rates_in_force:
+                rates_in_force = max(stop_i - 1, 0)
+                state["k"] = k_of_stop(rates_in_force)
+                rates_changed = True
             failed = False
             save_i = 0
             if L > 0:
@@ -339,9 +383,12 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                 if seg_end > t_seg:
                     # segment-local time (see solver.cpp): restart at tau = 0, integrate to seg_len
                     seg_len = seg_end - t_seg
-                    if not bdf.restart(0.0, y, seg_len):
+                    if have_history and not cold_restarts:
+                        bdf.resume(rates_changed)
+                    elif not bdf.restart(0.0, y, seg_len):
                         retcode, failed = RET_UNSTABLE, True
                         break
+                    have_history, rates_changed = True, False
                     while bdf.t < seg_len:
                         status = bdf.step(seg_len)
                         if status == "maxiters":
@@ -366,6 +413,8 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                 t_seg = seg_end
                 if ends_at_stop:
                     state["k"] = k_of_stop(stop_i)
+                    rates_in_force = stop_i
+                    rates_changed = True
                     stop_i += 1
             if not failed:
                 if chunks and nc == n_chunks - 1 and L > 1:
@@ -375,6 +424,7 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
             if (not adaptive_tols) or attempts >= 5 or abstol / 10 <= EPS or reltol / 10 <= EPS:
                 break
             abstol /= 10; reltol /= 10
+            rates_in_force = -1
             bdf.set_tols(abstol, reltol)
             n_retries += 1
             y = y_start.copy()
