@@ -146,6 +146,13 @@ typedef struct kin_stats {
 int kin_solve(kin_network* h, const kin_params* params, const double* u0,
               const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops,
               int64_t* n_saved, int32_t* retcode, kin_stats* stats);
+/* N3: continuous rate updates (reference: methods.jl:363-653, where k(t) = calculator(T(t)) is inlined
+ * symbolically into every species ODE). Here the integrator is simply non-autonomous: the Arrhenius
+ * rates are re-evaluated on the device at T(t_new) for every step attempt; T(t) is the linear
+ * interpolation of the profile solution (t_nodes, T_nodes), as the reference's DiffEqArray functor does
+ * (src/utils.jl:135-139). Chunking / save grid / retry semantics as kin_solve; no restarts at all. */
+int kin_solve_continuous(kin_network* h, const kin_params* params, const double* u0, const double* t_nodes,
+                         const double* T_nodes, int64_t n_nodes, int64_t* n_saved, int32_t* retcode, kin_stats* stats);
 int kin_solution_size(const kin_network* h, int64_t* n_saved, int64_t* n_species);
 /* out_t[n_saved], out_u[n_saved][N] (sol.t / sol.u of ODESolveOutput, analysis/io.jl:3-11). */
 int kin_solution_copy(const kin_network* h, double* out_t, double* out_u);

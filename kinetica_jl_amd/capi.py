@@ -22,7 +22,7 @@ SYMBOLS = [
     "kin_network_create", "kin_network_destroy", "kin_network_sizes", "kin_last_error",
     "kin_set_rates", "kin_get_rates", "kin_set_arrhenius", "kin_rates_at", "kin_arrhenius_eval",
     "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev",
-    "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solution_size",
+    "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solve_continuous", "kin_solution_size",
     "kin_solution_copy", "kin_solution_max", "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
 ]
 
@@ -83,6 +83,8 @@ def lib():
         L.kin_jac_values.argtypes = [c_void_p, PD, PD]
         L.kin_solve.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64, P64, POINTER(c_int32),
                                 POINTER(KinStats)]
+        L.kin_solve_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64, P64, POINTER(c_int32),
+                                           POINTER(KinStats)]
         L.kin_solution_size.argtypes = [c_void_p, P64, P64]
         L.kin_solution_copy.argtypes = [c_void_p, PD, PD]
         L.kin_solution_max.argtypes = [c_void_p, PD]
@@ -238,6 +240,21 @@ class HipNetwork:
         n_saved, rc, stats = c_int64(0), c_int32(0), KinStats()
         st = lib().kin_solve(self._h, ctypes.byref(params), _pd(u0), _pd(tstops), _pd(T_stops), _pd(k_table), n_stops,
                              ctypes.byref(n_saved), ctypes.byref(rc), ctypes.byref(stats))
+        if st not in (KIN_OK, KIN_ERR_SOLVE_FAILED):
+            self._chk(st)
+        t = np.empty(n_saved.value)
+        u = np.empty((n_saved.value, self.n))
+        if n_saved.value:
+            self._chk(lib().kin_solution_copy(self._h, _pd(t), _pd(u)))
+        return t, u, rc.value, stats.as_dict(), st
+
+    def solve_continuous(self, params: KinParams, u0, t_nodes, T_nodes):
+        """kin_solve_continuous + kin_solution_copy: k(t) = Arrhenius(T(t)), T piecewise linear."""
+        u0, t_nodes, T_nodes = _f64(u0), _f64(t_nodes), _f64(T_nodes)
+        assert len(u0) == self.n and len(t_nodes) == len(T_nodes)
+        n_saved, rc, stats = c_int64(0), c_int32(0), KinStats()
+        st = lib().kin_solve_continuous(self._h, ctypes.byref(params), _pd(u0), _pd(t_nodes), _pd(T_nodes), len(t_nodes),
+                                        ctypes.byref(n_saved), ctypes.byref(rc), ctypes.byref(stats))
         if st not in (KIN_OK, KIN_ERR_SOLVE_FAILED):
             self._chk(st)
         t = np.empty(n_saved.value)

@@ -18,6 +18,15 @@ void kin_network::rhs_dev(const double* d_u, double* d_du) {
   launch_segsum(rhs_plan.view(), SEG_COEF_SET, rate.p, d_du, SegExtra{}, stream);
 }
 
+void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, double* d_du, hipStream_t s) {
+  if (host.big_H > 0)
+    launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, host.big_tiles, big_rec.p, sweep_k.p,
+                     big_spec.p, big_bptr.p, big_bucket.p, d_u, d_k, k.p, d_du, s);
+  else
+    launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, sweep_rec.p, sweep_k.p,
+                 host.pair_rec64.empty() ? nullptr : sweep_rec64.p, d_u, d_k, k.p, d_du, s);
+}
+
 void kin_network::jac_dev(const double* d_u, double* d_vals) {
   launch_drates(host.R, k.p, d_u, x0.p, x1.p, dr.p, stream);
   launch_segsum(jac_plan.view(), SEG_COEF_SET, dr.p, d_vals, SegExtra{}, stream);
@@ -77,6 +86,10 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     h->sp_ptr.upload(N.sp_ptr, s); h->sp_rxn.upload(N.sp_rxn, s); h->sp_coef.upload(N.sp_coef, s);
     if (N.N < 65535) { h->sweep_rec.upload(N.pair_rec, s); h->sweep_k.upload(N.pair_k, s); }
     if (!N.pair_rec64.empty()) h->sweep_rec64.upload(N.pair_rec64, s);
+    if (N.big_H > 0) {
+      h->big_rec.upload(N.big_rec, s); h->big_spec.upload(N.big_spec_of_label, s);
+      h->big_bptr.upload(N.big_bucket_ptr, s); h->big_bucket.upload(N.big_bucket, s);
+    }
     h->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);
     h->jac_plan.upload(build_seg_plan(N.nnz(), N.jc_ptr.data(), nullptr, N.jc_src.data(), nullptr, N.jc_coef.data(), false), s);
     h->k.alloc(N.R); h->rate.alloc(N.R); h->dr.alloc(2 * N.R + 2);
@@ -200,7 +213,7 @@ int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const doub
   require(d_k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
   require(h->host.N < 65535, ERR_UNSUPPORTED, "batched sweep packs species ids in 16 bits (N < 65535)");
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  launch_sweep(h->host.N, h->host.R, h->host.n_pairs(), B, h->host.pairs_adjacent, h->sweep_rec.p, h->sweep_k.p, h->host.pair_rec64.empty() ? nullptr : h->sweep_rec64.p, d_u, d_k, h->k.p, d_du, s);
+  h->sweep_dev(B, d_u, d_k, d_du, s);
   KIN_CATCH(h)
 }
 
@@ -215,7 +228,7 @@ int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k,
   h->b_u.upload(u, (size_t)B * N, s);
   h->b_du.alloc((size_t)B * N);
   if (k) h->b_k.upload(k, (size_t)B * R, s);
-  launch_sweep(N, R, h->host.n_pairs(), B, h->host.pairs_adjacent, h->sweep_rec.p, h->sweep_k.p, h->host.pair_rec64.empty() ? nullptr : h->sweep_rec64.p, h->b_u.p, k ? h->b_k.p : nullptr, h->k.p, h->b_du.p, s);
+  h->sweep_dev(B, h->b_u.p, k ? h->b_k.p : nullptr, h->b_du.p, s);
   h->b_du.download(du, (size_t)B * N, s);
   KIN_HIP(hipStreamSynchronize(s));
   KIN_CATCH(h)
@@ -266,6 +279,18 @@ int kin_newton_solve(kin_network* h, double c, const double* u, const double* b,
   require(u && b && x, ERR_INVALID_ARG, "null buffer");
   require(h->has_rates, ERR_STATE, "rates were never set");
   newton_solve(h, c, u, b, x);
+  KIN_CATCH(h)
+}
+
+int kin_solve_continuous(kin_network* h, const kin_params* params, const double* u0, const double* t_nodes,
+                         const double* T_nodes, int64_t n_nodes, int64_t* n_saved, int32_t* retcode, kin_stats* stats) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(params && u0, ERR_INVALID_ARG, "params / u0 is null");
+  int rc = solve_entry(h, *params, u0, nullptr, nullptr, nullptr, 0, stats, t_nodes, T_nodes, n_nodes);
+  if (n_saved) *n_saved = h->n_saved;
+  if (retcode) *retcode = rc;
+  if (rc != KIN_RETCODE_SUCCESS) throw KinError(ERR_SOLVE_FAILED, "ODE solution failed.");
   KIN_CATCH(h)
 }
 

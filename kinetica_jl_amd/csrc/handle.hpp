@@ -19,6 +19,8 @@ struct kin_network {
   kin::DevBuf<uint32_t> sweep_rec;   // 4 words per reversible pair (kernels.hip: SweepRec)
   kin::DevBuf<int32_t> sweep_k;      // (kf, kr) per pair
   kin::DevBuf<uint32_t> sweep_rec64; // 64-bit packed records (register-resident sweep)
+  kin::DevBuf<uint32_t> big_rec;     // large-N sweep: label-space records, label -> species, tail buckets
+  kin::DevBuf<int32_t> big_spec, big_bptr, big_bucket;
   kin::DevBuf<float> sp_coef;
   kin::SegPlanDev rhs_plan, jac_plan;
 
@@ -44,4 +46,5 @@ struct kin_network {
   ~kin_network();
   void rhs_dev(const double* d_u, double* d_du);        // du = f(u) with current k
   void jac_dev(const double* d_u, double* d_vals);      // CSR values with current k
+  void sweep_dev(int64_t B, const double* d_u, const double* d_k, double* d_du, hipStream_t s);   // batched RHS
 };

@@ -491,6 +491,135 @@ static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B
                      k_b, k_1, du);
 }
 
+// ------------------------------------------------------------------------------------------
+// Large-N variant (the state does not fit LDS, e.g. 50k species): species are relabelled by how
+// often the records reference them; the H most popular ones ("hubs", ~90 % of all slot references
+// under a Zipf popularity) keep their u in LDS for the whole state. Pass 0 streams every record once
+// (coalesced double2 k) and accumulates the hubs' du in LDS; pass t >= 1 re-visits only the records
+// that touch tail tile t (precomputed bucket lists, ~5 % of the records each) and accumulates that
+// tile's du in the same LDS array. Tail operands are read through L2. No global atomics.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double big_u(uint32_t label, int H, const double* u_s, const double* __restrict__ ub,
+                                        const int32_t* __restrict__ spec_of_label) {
+  return (int)label < H ? u_s[label] : ub[spec_of_label[label]];
+}
+
+__device__ __forceinline__ double big_net(const SweepRec& q, double kf, double kr, int H, const double* u_s,
+                                          const double* __restrict__ ub, const int32_t* __restrict__ spec_of_label,
+                                          uint32_t sl[4], int cf[4]) {
+  sl[0] = q.s01 & 0xffffu; sl[1] = q.s01 >> 16; sl[2] = q.s23 & 0xffffu; sl[3] = q.s23 >> 16;
+#pragma unroll
+  for (int j = 0; j < 4; j++) cf[j] = (int)(int8_t)((uint32_t)q.coef >> (8 * j));
+  if (q.ops == 0xffffffffu) {
+    double uf = 1.0, ur = 1.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (sl[j] != 0xffffu) {
+        const double v = big_u(sl[j], H, u_s, ub, spec_of_label);
+        const double v2 = (cf[j] == 2 || cf[j] == -2) ? v * v : v;
+        if (cf[j] < 0) uf *= v2; else ur *= v2;
+      }
+    }
+    return kf * uf - kr * ur;
+  }
+  const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
+  double net = kf * big_u(a, H, u_s, ub, spec_of_label);
+  if (c != 0xffffu) net *= big_u(c, H, u_s, ub, spec_of_label);
+  return net;
+}
+
+template <bool ADJ>
+__global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, int B, int H, int n_tiles,
+                                                         const SweepRec* __restrict__ rec, const int2* __restrict__ pair_k,
+                                                         const int32_t* __restrict__ spec_of_label,
+                                                         const int32_t* __restrict__ bucket_ptr, const int32_t* __restrict__ bucket,
+                                                         const double* __restrict__ u, const double* __restrict__ k_b,
+                                                         const double* __restrict__ k_1, double* __restrict__ du) {
+  extern __shared__ double lds[];
+  double* du_s = lds;
+  double* u_s = lds + H;
+  const int tid = threadIdx.x;
+  constexpr int ILP = 4;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const double* ub = u + (size_t)b * N;
+    const double* kb = k_b ? k_b + (size_t)b * R : k_1;
+    double* dub = du + (size_t)b * N;
+    for (int l = tid; l < H; l += 1024) u_s[l] = ub[spec_of_label[l]];
+    for (int t = 0; t < n_tiles; t++) {
+      const int lo = t * H, hi = min(N, lo + H);
+      for (int i = tid; i < hi - lo; i += 1024) du_s[i] = 0.0;
+      __syncthreads();
+      const int q0 = t == 0 ? 0 : bucket_ptr[t], q1 = t == 0 ? P : bucket_ptr[t + 1];
+      for (int qq = q0 + tid; qq < q1; qq += 1024 * ILP) {
+        SweepRec q[ILP];
+        double kf[ILP], kr[ILP];
+        int pidx[ILP];
+#pragma unroll
+        for (int x = 0; x < ILP; x++) {
+          const int i = qq + x * 1024;
+          pidx[x] = i < q1 ? (t == 0 ? i : bucket[i]) : -1;
+        }
+#pragma unroll
+        for (int x = 0; x < ILP; x++) {
+          if (pidx[x] >= 0) {
+            q[x] = rec[pidx[x]];
+            if (ADJ) {
+              const double2 kk = *reinterpret_cast<const double2*>(kb + 2 * (size_t)pidx[x]);
+              kf[x] = kk.x; kr[x] = kk.y;
+            } else {
+              const int2 kk = pair_k[pidx[x]];
+              kf[x] = kb[kk.x]; kr[x] = kk.y >= 0 ? kb[kk.y] : 0.0;
+            }
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < ILP; x++) {
+          if (pidx[x] >= 0) {
+            uint32_t sl[4]; int cf[4];
+            const double net = big_net(q[x], kf[x], kr[x], H, u_s, ub, spec_of_label, sl, cf);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int sp = (int)sl[j];
+              if (sp != 0xffff && sp >= lo && sp < hi)
+                __hip_atomic_fetch_add(du_s + (sp - lo), (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < hi - lo; i += 1024) dub[spec_of_label[lo + i]] = du_s[i];
+      __syncthreads();
+    }
+  }
+}
+
+template <bool ADJ>
+static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tiles, const void* rec, const void* pair_k,
+                               const int32_t* spec_of_label, const int32_t* bucket_ptr, const int32_t* bucket, const double* u,
+                               const double* k_b, const double* k_1, double* du, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    KIN_HIP(hipFuncSetAttribute((const void*)sweep_big_kernel<ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * H * 8, s, N, R, P, B, H, n_tiles,
+                     (const SweepRec*)rec, (const int2*)pair_k, spec_of_label, bucket_ptr, bucket, u, k_b, k_1, du);
+}
+
+void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tiles, const void* rec,
+                      const void* pair_k, const int32_t* spec_of_label, const int32_t* bucket_ptr, const int32_t* bucket,
+                      const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+  if (B == 0) return;
+  int dev = 0; hipDeviceProp_t pr;
+  static int n_cu = 0;
+  if (!n_cu) { KIN_HIP(hipGetDevice(&dev)); KIN_HIP(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
+  const int grid = (int)std::min<int64_t>(B, n_cu);
+  const bool adj = adjacent && ((((uintptr_t)(k_b ? k_b : k_1)) & 15) == 0);
+  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tiles, rec, pair_k, spec_of_label, bucket_ptr, bucket, u, k_b, k_1, du, s);
+  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tiles, rec, pair_k, spec_of_label, bucket_ptr, bucket, u, k_b, k_1, du, s);
+  KIN_HIP(hipGetLastError());
+}
+
 template <bool U_IN_LDS, bool ADJ>
 static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, int tile, int n_tiles, const void* rec,
                            const void* pair_k, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {

@@ -53,4 +53,9 @@ void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const doubl
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
                   const void* rec64, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
 
+// large-N sweep (state too large for LDS): hub-resident LDS + tail bucket passes
+void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tiles, const void* rec,
+                      const void* pair_k, const int32_t* spec_of_label, const int32_t* bucket_ptr, const int32_t* bucket,
+                      const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
+
 }  // namespace kin

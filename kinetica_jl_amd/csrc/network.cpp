@@ -221,6 +221,51 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
       }
       if (!ok) H.pair_rec64.clear();
     }
+    // ---- large-N sweep tables (only when the state cannot live in LDS)
+    if ((size_t)N * 16 > 160 * 1024) {
+      const int64_t P = H.n_pairs();
+      const int32_t Hh = 10000;                       // hub species resident in LDS (2 x 80 kB)
+      std::vector<int64_t> cnt(N, 0);
+      for (int64_t p = 0; p < P; p++) {
+        const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1];
+        const uint32_t sl[4] = {s01 & 0xffffu, s01 >> 16, s23 & 0xffffu, s23 >> 16};
+        for (int j = 0; j < 4; j++) if (sl[j] != 0xffffu) cnt[sl[j]]++;
+        const uint32_t ops = H.pair_rec[4 * p + 3];
+        if (ops != 0xffffffffu) { cnt[ops & 0xffffu]++; if ((ops >> 16) != 0xffffu) cnt[ops >> 16]++; }
+      }
+      std::vector<int32_t> order(N);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt[a] > cnt[b]; });
+      std::vector<char> is_hub(N, 0);
+      for (int32_t q = 0; q < Hh; q++) is_hub[order[q]] = 1;
+      std::vector<int32_t> label(N);
+      H.big_spec_of_label.clear();
+      for (int32_t sp = 0; sp < N; sp++) if (is_hub[sp]) { label[sp] = (int32_t)H.big_spec_of_label.size(); H.big_spec_of_label.push_back(sp); }
+      for (int32_t sp = 0; sp < N; sp++) if (!is_hub[sp]) { label[sp] = (int32_t)H.big_spec_of_label.size(); H.big_spec_of_label.push_back(sp); }
+      H.big_H = Hh;
+      H.big_tiles = (int32_t)ceil_div(N, Hh);
+      auto relabel = [&](uint32_t v) { return v == 0xffffu ? 0xffffu : (uint32_t)label[v]; };
+      std::vector<std::vector<int32_t>> buckets(H.big_tiles);
+      H.big_rec.resize((size_t)4 * P);
+      for (int64_t p = 0; p < P; p++) {
+        const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1], ops = H.pair_rec[4 * p + 3];
+        const uint32_t sl[4] = {relabel(s01 & 0xffffu), relabel(s01 >> 16), relabel(s23 & 0xffffu), relabel(s23 >> 16)};
+        H.big_rec[4 * p + 0] = sl[0] | (sl[1] << 16);
+        H.big_rec[4 * p + 1] = sl[2] | (sl[3] << 16);
+        H.big_rec[4 * p + 2] = H.pair_rec[4 * p + 2];
+        H.big_rec[4 * p + 3] = ops == 0xffffffffu ? ops : (relabel(ops & 0xffffu) | (relabel(ops >> 16) << 16));
+        int last = -1;
+        int tl[4];
+        for (int j = 0; j < 4; j++) tl[j] = sl[j] == 0xffffu ? -1 : (int)(sl[j] / (uint32_t)Hh);
+        std::sort(tl, tl + 4);
+        for (int j = 0; j < 4; j++) if (tl[j] >= 1 && tl[j] != last) { buckets[tl[j]].push_back((int32_t)p); last = tl[j]; }
+      }
+      H.big_bucket_ptr.assign(1, 0);
+      for (int t = 0; t < H.big_tiles; t++) {
+        H.big_bucket.insert(H.big_bucket.end(), buckets[t].begin(), buckets[t].end());
+        H.big_bucket_ptr.push_back((int32_t)H.big_bucket.size());
+      }
+    }
   }
 
   // species-major CSR

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <functional>
 #include <limits>
 
 #include "lu.hpp"
@@ -67,6 +68,9 @@ struct Solver {
   double fail_score = 0.0;   // leaky count of rejected attempts (history reset at 3, see reset_history)
   kin_stats st{};
   int64_t iters_left = 0;
+  // continuous-rate solves: called with the segment-local time of every step attempt BEFORE the
+  // corrector runs, re-evaluates the rate constants at the conditions of that time
+  std::function<void(double)> pre_attempt;
 
   explicit Solver(kin_network* hh) : h(hh), N((int)hh->host.N), s(hh->stream) {
     const NetworkHost& H = h->host;
@@ -221,6 +225,7 @@ struct Solver {
       const double hh = t_new - t;
       h_abs = std::fabs(hh);
       const double c = hh / cf.alpha[order];
+      if (pre_attempt) pre_attempt(t_new);
       bool converged = false;
       for (;;) {
         if (!lu_valid) {
@@ -366,7 +371,8 @@ void apply_rates(kin_network* h, const double* T_stops, bool have_table, int64_t
 }  // namespace
 
 int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
-                const double* k_table, int64_t n_stops, kin_stats* stats) {
+                const double* k_table, int64_t n_stops, kin_stats* stats, const double* t_nodes, const double* T_nodes,
+                int64_t n_nodes) {
   auto wall0 = std::chrono::steady_clock::now();
   const int64_t N = h->host.N, R = h->host.R;
   // ---- validation (ODESimulationParams constructor, params.jl:77-104)
@@ -383,6 +389,14 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     if (has_save && p.save_interval > p.solve_chunkstep) throw KinError(ERR_INVALID_ARG, "Solution save interval must be less than chunkwise simulation step size");
     if (has_save && !(p.save_interval > 0)) throw KinError(ERR_INVALID_ARG, "save_interval must be positive");
   }
+  const bool continuous = n_nodes > 0;
+  if (continuous) {
+    if (n_stops > 0) throw KinError(ERR_INVALID_ARG, "continuous and discrete rate updates are mutually exclusive");
+    if (!t_nodes || !T_nodes || n_nodes < 2) throw KinError(ERR_INVALID_ARG, "need >= 2 (t, T) nodes");
+    if (!h->has_arrhenius) throw KinError(ERR_STATE, "continuous rates need the Arrhenius parameters");
+    for (int64_t i = 1; i < n_nodes; i++)
+      if (!(t_nodes[i] >= t_nodes[i - 1])) throw KinError(ERR_INVALID_ARG, "t_nodes must be non-decreasing");
+  }
   const bool variable = n_stops > 0;
   if (variable) {
     if (!tstops) throw KinError(ERR_INVALID_ARG, "tstops is null");
@@ -390,7 +404,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     if (!k_table && !h->has_arrhenius) throw KinError(ERR_STATE, "T_stops given but Arrhenius parameters were never set");
     for (int64_t i = 1; i < n_stops; i++)
       if (!(tstops[i] > tstops[i - 1])) throw KinError(ERR_INVALID_ARG, "tstops must be strictly increasing");
-  } else if (!h->has_rates) {
+  } else if (!continuous && !h->has_rates) {
     throw KinError(ERR_STATE, "rates were never set");
   }
   if (!h->solver) h->solver.reset(new Solver(h));
@@ -428,6 +442,25 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   if (chunks) sb.reserve((L - 1) * n_chunks + 1);
   else sb.reserve(has_save ? L : 1024);
 
+  // continuous rates: T(t) = linear interpolation of the profile solution (what the DiffEqArray
+  // functor of src/utils.jl:135-139 does), k = calculator(T(t)) re-evaluated on the device
+  auto T_of = [&](double tg) {
+    if (tg <= t_nodes[0]) return T_nodes[0];
+    if (tg >= t_nodes[n_nodes - 1]) return T_nodes[n_nodes - 1];
+    const int64_t i = std::upper_bound(t_nodes, t_nodes + n_nodes, tg) - t_nodes;   // t_nodes[i-1] <= tg < t_nodes[i]
+    const double dt = t_nodes[i] - t_nodes[i - 1];
+    const double th = dt > 0 ? (tg - t_nodes[i - 1]) / dt : 1.0;
+    return (1.0 - th) * T_nodes[i - 1] + th * T_nodes[i];
+  };
+  double seg_origin = 0.0;   // global time of the current segment's tau = 0
+  if (continuous) {
+    S.pre_attempt = [&](double tau) {
+      launch_arrhenius(R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, T_of(seg_origin + tau), h->k.p, s);
+    };
+    h->has_rates = true;
+  } else {
+    S.pre_attempt = nullptr;
+  }
   // initial state
   S.y.upload(u0, N, s);
   int64_t next_stop = 0;      // first tstop not yet applied
@@ -503,6 +536,8 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
           // time variable - the underflow the reference's chunking exists to avoid
           // (docs/src/development/implementation-details.md:5-28) but re-creates at tstops > 0.
           const double seg_len = seg_end - t_seg;
+          seg_origin = t_seg + shift;
+          if (continuous) S.pre_attempt(0.0);   // rates at the segment start for f0 / J of the restart
           if (have_history && !cold_restarts) S.resume(rates_changed);
           else if (!S.restart(0.0, seg_len)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
           have_history = true;
@@ -556,6 +591,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     }
   }
   KIN_HIP(hipStreamSynchronize(s));
+  S.pre_attempt = nullptr;   // the lambda captures locals of this call
   S.st.final_abstol = abstol;
   S.st.final_reltol = reltol;
   S.st.lu_dense_dim = S.lu.m; S.st.lu_sparse_rows = S.lu.ns; S.st.lu_rounds = S.lu.nrounds;

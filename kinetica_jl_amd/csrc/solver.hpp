@@ -8,7 +8,8 @@ namespace kin {
 // Runs the whole solve (chunk loop, discrete rate updates, retry loop); stores the solution in
 // the handle; returns the final KIN_RETCODE_*.
 int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops,
-                const double* T_stops, const double* k_table, int64_t n_stops, kin_stats* stats);
+                const double* T_stops, const double* k_table, int64_t n_stops, kin_stats* stats,
+                const double* t_nodes = nullptr, const double* T_nodes = nullptr, int64_t n_nodes = 0);
 // max over saved times per species, reduced on the device
 void solution_max(kin_network* h, double* out_umax);
 // diagnostic: (I - c J(u)) x = b through the solver's LU

@@ -383,10 +383,6 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
     variable = isinstance(method, VariableODESolve)
     if variable:
         solve_variable_conditions(conditions, pars)
-        if not conditions.discrete_updates:
-            raise NotImplementedError("continuous rate updates (methods.jl:363-653) are not part of the accelerated path; "
-                                      "pass ts_update to ConditionSet for discrete updates (recommended for large CRNs, "
-                                      "docs/src/tutorials/ode-solution.md:85-91)")
     mask = get_filter_mask(method.filter, sd_a, rd_a)
     rd_a.splice(np.nonzero(mask)[0])
     setup_network(sd_a, rd_a, calc)
@@ -399,10 +395,22 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
         if arr:
             h.set_arrhenius(calc.Ea, calc.A, calc.k_max, calc.t_mult)
         sol_k = None
-        if not variable:
+        sol_vcs = None
+        if not variable or (not conditions.discrete_updates and not arr):
+            # static rates (a Dummy calculator is constant under continuous updates as well)
             k0 = get_initial_rates(conditions, calc)
             h.set_rates(k0)
             t, u, rc, st, status = h.solve(pars.to_kin_params(), u0)
+        elif not conditions.discrete_updates:
+            # continuous rate updates (methods.jl:363-653): k(t) = calculator(T(t)) evaluated on the device at
+            # every step; T(t) = the profile solution, linearly interpolated (src/utils.jl:135-139)
+            prof = conditions.profiles[conditions.symbols.index("T")]
+            if isstatic(prof):
+                nodes_t, nodes_T = np.array([pars.tspan[0], pars.tspan[1]]), np.array([prof.value, prof.value], dtype=float)
+            else:
+                nodes_t, nodes_T = prof.sol.t, prof.sol.u
+            t, u, rc, st, status = h.solve_continuous(pars.to_kin_params(), u0, nodes_t, nodes_T)
+            sol_vcs = {"T": np.interp(t, nodes_t, nodes_T)}      # ODESolutionVC's condition traces (solutions.jl:1-21)
         else:
             tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
             sol_k = DiscreteRates(tstops, table)
@@ -417,4 +425,4 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
     finally:
         h.close()
     sol = ODESolution(t, u, capi.RETCODE_NAMES[rc], k=sol_k, stats=st)
-    return ODESolveOutput(sd_a, rd_a, sol, sol_k, None, pars, conditions)
+    return ODESolveOutput(sd_a, rd_a, sol, sol_k, sol_vcs, pars, conditions)

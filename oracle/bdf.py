@@ -76,6 +76,7 @@ class OracleBDF:
                           n_restarts=0)
         self.I = sp.identity(n, format="csc")
         self.iters_left = 0
+        self.pre_attempt = None   # continuous rates: called with the local time of every step attempt
 
     def set_tols(self, atol, rtol):
         self.atol, self.rtol = atol, rtol
@@ -191,6 +192,8 @@ class OracleBDF:
             scale = self.atol + self.rtol * np.abs(y_pred)
             psi = np.dot(D[1:order + 1].T, GAMMA[1:order + 1]) / ALPHA[order]
             c = h / ALPHA[order]
+            if self.pre_attempt is not None:
+                self.pre_attempt(t_new)
             converged = False
             while True:
                 if self.LU is None:
@@ -297,7 +300,7 @@ class OracleBDF:
         return self.D[0] + np.dot(self.D[1:order + 1].T, p)
 
 
-def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None, k_of_stop=None):
+def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None, k_of_stop=None, k_of_time=None):
     """CPU restatement of the solve orchestration. `fun_of_k(k)(y)`, `jac_of_k(k)(y)`;
     `k_of_stop(i)` gives the rate vector in force from tstops[i] on (zero-order hold,
     solve_utils.jl:435-509). params: dict with the kin_params fields. Returns
@@ -337,6 +340,12 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
     state = {"k": None if k0 is None else np.array(k0, dtype=float)}
     bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
                     dtmin=0.0, ban_negatives=params.get("ban_negatives", False))
+    # continuous rate updates (methods.jl:363-653): k re-evaluated at the global time of every step attempt
+    seg_origin = [0.0]
+    if k_of_time is not None:
+        def _hook(tau):
+            state["k"] = k_of_time(seg_origin[0] + tau)
+        bdf.pre_attempt = _hook
     out_t, out_u = [], []
     y = np.array(u0, dtype=float)
     next_stop = 0
@@ -383,6 +392,9 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                 if seg_end > t_seg:
                     # segment-local time (see solver.cpp): restart at tau = 0, integrate to seg_len
                     seg_len = seg_end - t_seg
+                    seg_origin[0] = t_seg + shift
+                    if bdf.pre_attempt is not None:
+                        bdf.pre_attempt(0.0)
                     if have_history and not cold_restarts:
                         bdf.resume(rates_changed)
                     elif not bdf.restart(0.0, y, seg_len):

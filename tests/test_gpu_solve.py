@@ -351,3 +351,39 @@ def test_ban_negatives_rejects_negative_states():
     assert rc == 0 and u.min() >= 0.0
     np.testing.assert_allclose(u[-1], [0.5, 0.0, 0.5], atol=1e-4)
     h.close()
+
+
+def test_continuous_rate_updates_n3():
+    """Continuous-rate VariableODESolve (methods.jl:363-653): k(t) = Arrhenius(T(t)) re-evaluated every step.
+    A -> B: A(t) = exp(-int_0^t k(T(s)) ds), checked against quadrature and against the oracle."""
+    from scipy.integrate import quad
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    Ea, A = np.array([8.0e4]), np.array([1.0e-17])         # k(T) = A exp(-Ea/RT) N_A : 0.03 /s at 500 K, 6 /s at 700 K
+    sd = S.SpeciesData.from_names(["A", "B"])
+    rd = S.RxData(1, [[1]], [[2]], [[1]], [[1]])
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A)
+    cs = C.ConditionSet({"T": C.LinearGradientProfile(rate=100.0, X_start=500.0, X_end=700.0)})   # no ts_update -> continuous
+    pars = S.ODESimulationParams(tspan=(0.0, 2.0), u0=[1.0, 0.0], solve_chunkstep=0.5, save_interval=0.25, low_k_cutoff="none")
+    res = S.solve_network(S.VariableODESolve(pars, cs, calc), sd, rd)
+    assert res.sol.retcode == "Success" and res.sol_k is None and len(res.sol.t) == 9
+    kfun = lambda t: float(orc.arrhenius(Ea, A, 500.0 + 100.0 * t)[0])
+    truth = np.array([np.exp(-quad(kfun, 0.0, tt, epsabs=1e-13, epsrel=1e-13)[0]) for tt in res.sol.t])
+    assert errscale(res.sol.u[:, 0], truth) < 100
+    np.testing.assert_allclose(res.sol_vcs["T"], 500.0 + 100.0 * res.sol.t, rtol=1e-12)
+    assert res.sol.stats["n_restarts"] == 4                 # one per chunk, none inside
+    # oracle with the same k(t)
+    net = from_lists(2, [[(0, 1)]], [[(1, 1)]])
+    on = orc.OracleNetwork.from_flat(net)
+    to, uo, rco, sto = obdf.solve_network_oracle(lambda kk: (lambda y: on.rhs(kk, y)), lambda kk: (lambda y: on.jac(kk, y)), 2,
+                                                 dict(tspan=(0.0, 2.0), solve_chunks=True, solve_chunkstep=0.5, save_interval=0.25),
+                                                 [1.0, 0.0], k_of_time=lambda tg: orc.arrhenius(Ea, A, 500.0 + 100.0 * tg))
+    assert errscale(res.sol.u, uo) < 10
+    # a static T in a VariableODESolve-style continuous set behaves like the static solve
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A)
+    t, u, rc, st, _ = h.solve_continuous(kp((0.0, 1.0), True, 0.5, 0.25), [1.0, 0.0], [0.0, 1.0], [600.0, 600.0])
+    assert errscale(u[:, 0], np.exp(-kfun(1.0) * t)) < 100   # kfun(1.0) = k(600 K)
+    with pytest.raises(capi.KineticaHipError):
+        h.solve_continuous(kp((0.0, 1.0), True, 0.5), [1.0, 0.0], [0.0], [600.0])
+    h.close()
