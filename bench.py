@@ -45,11 +45,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal knobs (a one-GPU box can run 2 ranks on the same card over gloo): never set by the driver
+    if os.environ.get("BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from kinetica_jl_amd import capi
     from kinetica_jl_amd.synth import synthetic_crn
@@ -100,7 +107,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     from kinetica_jl_amd.distributed import max_over_ranks
-    elapsed = max_over_ranks(elapsed, dist, dev)
+    elapsed = max_over_ranks(elapsed, dist, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     out = None
