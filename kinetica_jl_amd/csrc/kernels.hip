@@ -191,7 +191,9 @@ void launch_drates(int64_t R, const double* k, const double* u, const int32_t* x
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double arrhenius_one(double Ea, double A, double RT, int has_kmax, double inv_kmax, double t_mult) {
   const double kr = A * exp(-Ea / RT) * 6.02214076e23 * t_mult;
-  return has_kmax ? 1.0 / (inv_kmax + (1.0 / kr)) : kr;
+  // 1/(1/k_max + 1/k) evaluated as k / (1 + k/k_max): one IEEE division instead of two (the table
+  // kernel is FP64-VALU bound, not HBM bound); agrees with the two-division form to ~2 ulp
+  return has_kmax ? kr / fma(kr, inv_kmax, 1.0) : kr;
 }
 
 __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __restrict__ Ea, const double* __restrict__ A,

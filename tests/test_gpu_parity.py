@@ -210,3 +210,41 @@ def test_full_size_properties_c5_tiled_sweep():
     Jo = on.jac(k, U[0])
     assert abs(Jd - Jo).max() <= TOL * abs(Jo).max()
     h.close()
+
+
+def test_batched_sweep_general_record_layouts():
+    """The sweep's other code paths: reverse reactions listed in a separate block (the order
+    duplicate_reverse produces, cde.jl:299-309 -> index-based k loads), unpaired reactions, a collider
+    on both sides (explicit operands), 2A / A->2B stoichiometries."""
+    rng = np.random.default_rng(21)
+    # block order: forwards 0..3, reverses 4..7, plus an unpaired reaction and a collider reaction
+    fwd = [([(0, 1)], [(1, 1), (2, 1)]), ([(0, 1), (1, 1)], [(3, 1), (4, 1)]), ([(2, 2)], [(3, 1), (5, 1)]), ([(4, 1)], [(5, 2)])]
+    reacs = [r for r, p in fwd] + [p for r, p in fwd] + [[(5, 1)], [(0, 1), (6, 1)]]
+    prods = [p for r, p in fwd] + [r for r, p in fwd] + [[(6, 1)], [(1, 1), (6, 1)]]
+    net = from_lists(7, reacs, prods)
+    h = capi.HipNetwork.from_flat(net)
+    on = orc.OracleNetwork.from_flat(net)
+    k = rng.uniform(0.5, 2.0, net.n_reactions)
+    h.set_rates(k)
+    B = 9
+    U = rng.uniform(0.1, 1.0, (B, 7))
+    K = k[None, :] * rng.uniform(0.5, 2.0, (B, 1))
+    for got, kk in ((h.rhs_batched(U), None), (h.rhs_batched(U, K), K)):
+        for b in range(B):
+            kb = k if kk is None else kk[b]
+            np.testing.assert_allclose(got[b], on.rhs(kb, U[b]), rtol=1e-13, atol=1e-14)
+    h.close()
+    # odd number of reactions / large batch with ragged tail on the 300-species network in block order
+    net2, Ea, A = synthetic_crn(300, 1500)
+    order = list(range(0, 1500, 2)) + list(range(1, 1500, 2))       # all forwards, then all reverses
+    blk = net2.subset(order)
+    h = capi.HipNetwork.from_flat(blk)
+    on = orc.OracleNetwork.from_flat(blk)
+    k = orc.arrhenius(Ea[order], A[order], 900.0, k_max=1e12)
+    h.set_rates(k)
+    U = np.stack([_state(300, 70 + b) for b in range(33)])
+    got = h.rhs_batched(U)
+    for b in (0, 17, 32):
+        sc = on.abs_rhs(k, U[b]) + 1e-300
+        assert (np.abs(got[b] - on.rhs(k, U[b])) / sc).max() < TOL
+    h.close()
