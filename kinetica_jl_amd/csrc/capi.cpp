@@ -19,10 +19,11 @@ void kin_network::rhs_dev(const double* d_u, double* d_du) {
 }
 
 void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, double* d_du, hipStream_t s) {
-  if (host.big_H > 0)
-    launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, host.big_tiles, big_rec.p, sweep_k.p,
-                     big_spec.p, big_bptr.p, big_bucket.p, d_u, d_k, k.p, d_du, s);
-  else
+  if (host.big_H > 0) {
+    big_scratch.alloc((size_t)launch_sweep_big_grid(B) * (size_t)(host.N - host.big_H + host.n_pairs()));
+    launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, (int32_t)host.big_tail_ptr.size() - 1,
+                     big_rec.p, sweep_k.p, big_spec.p, big_tptr.p, big_tent.p, big_scratch.p, d_u, d_k, k.p, d_du, s);
+  } else
     launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, sweep_rec.p, sweep_k.p,
                  host.pair_rec64.empty() ? nullptr : sweep_rec64.p, d_u, d_k, k.p, d_du, s);
 }
@@ -88,7 +89,7 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     if (!N.pair_rec64.empty()) h->sweep_rec64.upload(N.pair_rec64, s);
     if (N.big_H > 0) {
       h->big_rec.upload(N.big_rec, s); h->big_spec.upload(N.big_spec_of_label, s);
-      h->big_bptr.upload(N.big_bucket_ptr, s); h->big_bucket.upload(N.big_bucket, s);
+      h->big_tptr.upload(N.big_tail_ptr, s); h->big_tent.upload(N.big_tail_ent, s);
     }
     h->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);
     h->jac_plan.upload(build_seg_plan(N.nnz(), N.jc_ptr.data(), nullptr, N.jc_src.data(), nullptr, N.jc_coef.data(), false), s);

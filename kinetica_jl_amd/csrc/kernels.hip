@@ -494,131 +494,192 @@ static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B
 }
 
 // ------------------------------------------------------------------------------------------
-// Large-N variant (the state does not fit LDS, e.g. 50k species): species are relabelled by how
-// often the records reference them; the H most popular ones ("hubs", ~90 % of all slot references
-// under a Zipf popularity) keep their u in LDS for the whole state. Pass 0 streams every record once
-// (coalesced double2 k) and accumulates the hubs' du in LDS; pass t >= 1 re-visits only the records
-// that touch tail tile t (precomputed bucket lists, ~5 % of the records each) and accumulates that
-// tile's du in the same LDS array. Tail operands are read through L2. No global atomics.
+// Large-N sweep (2 x 8N bytes exceed the LDS; C5: N = 50k). Species are relabelled by popularity:
+// the H most referenced species ("hubs", ~81 % of all slot references under the Zipf wiring) keep
+// u and du in LDS exactly as above. Per state, one workgroup
+//   1. gathers u into label order: hubs -> LDS, tail -> its private global scratch row `ut`
+//      (written and read by the same CU: served by L2 / Infinity Cache, not HBM);
+//   2. streams the records (16 B, shared by all states) and the state's k (coalesced double2) once,
+//      accumulates the hubs' du with LDS atomics and stores every record's net rate to its private
+//      `netbuf` row (coalesced 8 B/lane);
+//   3. writes the hubs' du out, then re-uses the whole LDS as accumulator for the tail, tile by tile:
+//      a precomputed list of (record, local label, coefficient) entries per tail tile, sorted by
+//      record, gathers coef * netbuf[record] into LDS; the tile is then written out.
+// (FP64 L2 atomics for the tail were measured first: 80 M global_atomic_add_f64 per launch cost
+// 1.3 ms of 2.5 ms.) HBM traffic per state is the algorithmic one: k[b][:] + u[b][:] in, du[b][:] out.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double big_u(uint32_t label, int H, const double* u_s, const double* __restrict__ ub,
-                                        const int32_t* __restrict__ spec_of_label) {
-  return (int)label < H ? u_s[label] : ub[spec_of_label[label]];
-}
-
-__device__ __forceinline__ double big_net(const SweepRec& q, double kf, double kr, int H, const double* u_s,
-                                          const double* __restrict__ ub, const int32_t* __restrict__ spec_of_label,
-                                          uint32_t sl[4], int cf[4]) {
-  sl[0] = q.s01 & 0xffffu; sl[1] = q.s01 >> 16; sl[2] = q.s23 & 0xffffu; sl[3] = q.s23 >> 16;
-#pragma unroll
-  for (int j = 0; j < 4; j++) cf[j] = (int)(int8_t)((uint32_t)q.coef >> (8 * j));
-  if (q.ops == 0xffffffffu) {
-    double uf = 1.0, ur = 1.0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (sl[j] != 0xffffu) {
-        const double v = big_u(sl[j], H, u_s, ub, spec_of_label);
-        const double v2 = (cf[j] == 2 || cf[j] == -2) ? v * v : v;
-        if (cf[j] < 0) uf *= v2; else ur *= v2;
-      }
-    }
-    return kf * uf - kr * ur;
-  }
-  const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
-  double net = kf * big_u(a, H, u_s, ub, spec_of_label);
-  if (c != 0xffffu) net *= big_u(c, H, u_s, ub, spec_of_label);
-  return net;
+__device__ __forceinline__ double big_u(uint32_t label, int H, const double* u_s, const double* __restrict__ ut) {
+  return (int)label < H ? u_s[label] : ut[(int)label - H];
 }
 
 template <bool ADJ>
-__global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, int B, int H, int n_tiles,
+__global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, int B, int H, int n_tail_tiles,
                                                          const SweepRec* __restrict__ rec, const int2* __restrict__ pair_k,
                                                          const int32_t* __restrict__ spec_of_label,
-                                                         const int32_t* __restrict__ bucket_ptr, const int32_t* __restrict__ bucket,
-                                                         const double* __restrict__ u, const double* __restrict__ k_b,
-                                                         const double* __restrict__ k_1, double* __restrict__ du) {
+                                                         const int32_t* __restrict__ tail_ptr, const uint2* __restrict__ tail_ent,
+                                                         double* __restrict__ scratch, const double* __restrict__ u,
+                                                         const double* __restrict__ k_b, const double* __restrict__ k_1,
+                                                         double* __restrict__ du) {
   extern __shared__ double lds[];
   double* du_s = lds;
   double* u_s = lds + H;
   const int tid = threadIdx.x;
-  constexpr int ILP = 4;
+  const int NT = N - H, TT = 2 * H;
+  double* ut = scratch + (size_t)blockIdx.x * ((size_t)NT + P);
+  double* netbuf = ut + NT;
+  constexpr int ILP = 4, PERM_ILP = 8;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const double* ub = u + (size_t)b * N;
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
     double* dub = du + (size_t)b * N;
-    for (int l = tid; l < H; l += 1024) u_s[l] = ub[spec_of_label[l]];
-    for (int t = 0; t < n_tiles; t++) {
-      const int lo = t * H, hi = min(N, lo + H);
-      for (int i = tid; i < hi - lo; i += 1024) du_s[i] = 0.0;
-      __syncthreads();
-      const int q0 = t == 0 ? 0 : bucket_ptr[t], q1 = t == 0 ? P : bucket_ptr[t + 1];
-      for (int qq = q0 + tid; qq < q1; qq += 1024 * ILP) {
-        SweepRec q[ILP];
-        double kf[ILP], kr[ILP];
-        int pidx[ILP];
+    // 1. permuting gather, PERM_ILP independent element chains per thread in flight
+    for (int l0 = tid; l0 < N; l0 += 1024 * PERM_ILP) {
+      int sp[PERM_ILP];
+      double v[PERM_ILP];
 #pragma unroll
-        for (int x = 0; x < ILP; x++) {
-          const int i = qq + x * 1024;
-          pidx[x] = i < q1 ? (t == 0 ? i : bucket[i]) : -1;
-        }
+      for (int x = 0; x < PERM_ILP; x++) { const int l = l0 + x * 1024; sp[x] = l < N ? spec_of_label[l] : -1; }
 #pragma unroll
-        for (int x = 0; x < ILP; x++) {
-          if (pidx[x] >= 0) {
-            q[x] = rec[pidx[x]];
-            if (ADJ) {
-              const double2 kk = *reinterpret_cast<const double2*>(kb + 2 * (size_t)pidx[x]);
-              kf[x] = kk.x; kr[x] = kk.y;
-            } else {
-              const int2 kk = pair_k[pidx[x]];
-              kf[x] = kb[kk.x]; kr[x] = kk.y >= 0 ? kb[kk.y] : 0.0;
-            }
+      for (int x = 0; x < PERM_ILP; x++) v[x] = sp[x] >= 0 ? ub[sp[x]] : 0.0;
+#pragma unroll
+      for (int x = 0; x < PERM_ILP; x++) {
+        const int l = l0 + x * 1024;
+        if (l < H) { u_s[l] = v[x]; du_s[l] = 0.0; }
+        else if (l < N) ut[l - H] = v[x];
+      }
+    }
+    __syncthreads();   // workgroup-scope release/acquire: the scratch row is visible to every wave of this CU
+    // 2. record stream
+    for (int qq = tid; qq < P; qq += 1024 * ILP) {
+      SweepRec q[ILP];
+      double kf[ILP], kr[ILP];
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        const int p = qq + x * 1024;
+        if (p < P) {
+          q[x] = rec[p];
+          if (ADJ) {
+            const double2 kk = *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
+            kf[x] = kk.x; kr[x] = kk.y;
+          } else {
+            const int2 kk = pair_k[p];
+            kf[x] = kb[kk.x]; kr[x] = kk.y >= 0 ? kb[kk.y] : 0.0;
           }
-        }
-#pragma unroll
-        for (int x = 0; x < ILP; x++) {
-          if (pidx[x] >= 0) {
-            uint32_t sl[4]; int cf[4];
-            const double net = big_net(q[x], kf[x], kr[x], H, u_s, ub, spec_of_label, sl, cf);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int sp = (int)sl[j];
-              if (sp != 0xffff && sp >= lo && sp < hi)
-                __hip_atomic_fetch_add(du_s + (sp - lo), (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
+        } else {
+          q[x] = SweepRec{0xffffffffu, 0xffffffffu, 0, 0xffffffffu};
+          kf[x] = kr[x] = 0.0;
         }
       }
-      __syncthreads();
-      for (int i = tid; i < hi - lo; i += 1024) dub[spec_of_label[lo + i]] = du_s[i];
-      __syncthreads();
+      // all operand loads of the ILP records are issued before the first product
+      uint32_t sl[ILP][4];
+      double uv[ILP][4];
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        sl[x][0] = q[x].s01 & 0xffffu; sl[x][1] = q[x].s01 >> 16; sl[x][2] = q[x].s23 & 0xffffu; sl[x][3] = q[x].s23 >> 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) uv[x][j] = sl[x][j] != 0xffffu ? big_u(sl[x][j], H, u_s, ut) : 1.0;
+      }
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        int cf[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) cf[j] = (int)(int8_t)((uint32_t)q[x].coef >> (8 * j));
+        double net;
+        if (q[x].ops == 0xffffffffu) {
+          double uf = 1.0, ur = 1.0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (sl[x][j] != 0xffffu) {
+              const double v = uv[x][j];
+              const double v2 = (cf[j] == 2 || cf[j] == -2) ? v * v : v;
+              if (cf[j] < 0) uf *= v2; else ur *= v2;
+            }
+          }
+          net = kf[x] * uf - kr[x] * ur;
+        } else {   // explicit operands (a species on both sides of the reaction)
+          const uint32_t a = q[x].ops & 0xffffu, c = q[x].ops >> 16;
+          net = kf[x] * big_u(a, H, u_s, ut);
+          if (c != 0xffffu) net *= big_u(c, H, u_s, ut);
+        }
+        const int p = qq + x * 1024;
+        if (p < P) netbuf[p] = net;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int lb = (int)sl[x][j];
+          if (lb < H) __hip_atomic_fetch_add(du_s + lb, (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
     }
+    __syncthreads();
+    // 3a. hubs out
+    for (int l0 = tid; l0 < H; l0 += 1024 * PERM_ILP) {
+      int sp[PERM_ILP];
+#pragma unroll
+      for (int x = 0; x < PERM_ILP; x++) { const int l = l0 + x * 1024; sp[x] = l < H ? spec_of_label[l] : -1; }
+#pragma unroll
+      for (int x = 0; x < PERM_ILP; x++) if (sp[x] >= 0) dub[sp[x]] = du_s[l0 + x * 1024];
+    }
+    // 3b. tail tiles: the whole LDS (u_s is dead now) accumulates TT = 2H labels per pass
+    for (int t = 0; t < n_tail_tiles; t++) {
+      __syncthreads();
+      for (int i = tid; i < TT; i += 1024) lds[i] = 0.0;
+      __syncthreads();
+      const int e0 = tail_ptr[t], e1 = tail_ptr[t + 1];
+      for (int ee = e0 + tid; ee < e1; ee += 1024 * PERM_ILP) {
+        uint2 en[PERM_ILP];
+        double nv[PERM_ILP];
+#pragma unroll
+        for (int x = 0; x < PERM_ILP; x++) { const int e = ee + x * 1024; en[x] = e < e1 ? tail_ent[e] : make_uint2(0xffffffffu, 0u); }
+#pragma unroll
+        for (int x = 0; x < PERM_ILP; x++) nv[x] = en[x].x != 0xffffffffu ? netbuf[en[x].x] : 0.0;
+#pragma unroll
+        for (int x = 0; x < PERM_ILP; x++)
+          if (en[x].x != 0xffffffffu)
+            __hip_atomic_fetch_add(lds + (en[x].y & 0xffffffu), (double)((int)en[x].y >> 24) * nv[x], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
+      const int base = H + t * TT, cnt = min(TT, N - base);
+      for (int l0 = tid; l0 < cnt; l0 += 1024 * PERM_ILP) {
+        int sp[PERM_ILP];
+#pragma unroll
+        for (int x = 0; x < PERM_ILP; x++) { const int l = l0 + x * 1024; sp[x] = l < cnt ? spec_of_label[base + l] : -1; }
+#pragma unroll
+        for (int x = 0; x < PERM_ILP; x++) if (sp[x] >= 0) dub[sp[x]] = lds[l0 + x * 1024];
+      }
+    }
+    __syncthreads();
   }
 }
 
+int launch_sweep_big_grid(int64_t B) {
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0; hipDeviceProp_t pr; KIN_HIP(hipGetDevice(&dev)); KIN_HIP(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
+  return (int)std::min<int64_t>(B, n_cu);
+}
+
 template <bool ADJ>
-static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tiles, const void* rec, const void* pair_k,
-                               const int32_t* spec_of_label, const int32_t* bucket_ptr, const int32_t* bucket, const double* u,
-                               const double* k_b, const double* k_1, double* du, hipStream_t s) {
+static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tail_tiles, const void* rec, const void* pair_k,
+                               const int32_t* spec_of_label, const int32_t* tail_ptr, const void* tail_ent, double* scratch,
+                               const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     KIN_HIP(hipFuncSetAttribute((const void*)sweep_big_kernel<ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * H * 8, s, N, R, P, B, H, n_tiles,
-                     (const SweepRec*)rec, (const int2*)pair_k, spec_of_label, bucket_ptr, bucket, u, k_b, k_1, du);
+  hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * H * 8, s, N, R, P, B, H, n_tail_tiles,
+                     (const SweepRec*)rec, (const int2*)pair_k, spec_of_label, tail_ptr, (const uint2*)tail_ent, scratch, u, k_b,
+                     k_1, du);
 }
 
-void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tiles, const void* rec,
-                      const void* pair_k, const int32_t* spec_of_label, const int32_t* bucket_ptr, const int32_t* bucket,
-                      const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+// `scratch` holds launch_sweep_big_grid(B) rows of (N - H) + P doubles
+void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec,
+                      const void* pair_k, const int32_t* spec_of_label, const int32_t* tail_ptr, const void* tail_ent,
+                      double* scratch, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
-  int dev = 0; hipDeviceProp_t pr;
-  static int n_cu = 0;
-  if (!n_cu) { KIN_HIP(hipGetDevice(&dev)); KIN_HIP(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
-  const int grid = (int)std::min<int64_t>(B, n_cu);
+  const int grid = launch_sweep_big_grid(B);
   const bool adj = adjacent && ((((uintptr_t)(k_b ? k_b : k_1)) & 15) == 0);
-  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tiles, rec, pair_k, spec_of_label, bucket_ptr, bucket, u, k_b, k_1, du, s);
-  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tiles, rec, pair_k, spec_of_label, bucket_ptr, bucket, u, k_b, k_1, du, s);
+  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
+  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
   KIN_HIP(hipGetLastError());
 }
 

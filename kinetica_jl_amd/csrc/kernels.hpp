@@ -53,9 +53,11 @@ void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const doubl
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
                   const void* rec64, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
 
-// large-N sweep (state too large for LDS): hub-resident LDS + tail bucket passes
-void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tiles, const void* rec,
-                      const void* pair_k, const int32_t* spec_of_label, const int32_t* bucket_ptr, const int32_t* bucket,
-                      const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
+// large-N sweep (state too large for LDS): hubs in LDS, tail via a per-workgroup scratch row and tail-entry lists;
+// `scratch` holds launch_sweep_big_grid(B) rows of (N - H) + P doubles
+int launch_sweep_big_grid(int64_t B);
+void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec,
+                      const void* pair_k, const int32_t* spec_of_label, const int32_t* tail_ptr, const void* tail_ent,
+                      double* scratch, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
 
 }  // namespace kin

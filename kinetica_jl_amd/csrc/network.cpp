@@ -243,10 +243,10 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
       for (int32_t sp = 0; sp < N; sp++) if (is_hub[sp]) { label[sp] = (int32_t)H.big_spec_of_label.size(); H.big_spec_of_label.push_back(sp); }
       for (int32_t sp = 0; sp < N; sp++) if (!is_hub[sp]) { label[sp] = (int32_t)H.big_spec_of_label.size(); H.big_spec_of_label.push_back(sp); }
       H.big_H = Hh;
-      H.big_tiles = (int32_t)ceil_div(N, Hh);
       auto relabel = [&](uint32_t v) { return v == 0xffffu ? 0xffffu : (uint32_t)label[v]; };
-      std::vector<std::vector<int32_t>> buckets(H.big_tiles);
       H.big_rec.resize((size_t)4 * P);
+      const int32_t TT = 2 * Hh;                      // tail labels accumulated per pass (the whole LDS)
+      std::vector<std::vector<std::pair<uint32_t, uint32_t>>> tail(ceil_div(N - Hh, TT));
       for (int64_t p = 0; p < P; p++) {
         const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1], ops = H.pair_rec[4 * p + 3];
         const uint32_t sl[4] = {relabel(s01 & 0xffffu), relabel(s01 >> 16), relabel(s23 & 0xffffu), relabel(s23 >> 16)};
@@ -254,16 +254,17 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
         H.big_rec[4 * p + 1] = sl[2] | (sl[3] << 16);
         H.big_rec[4 * p + 2] = H.pair_rec[4 * p + 2];
         H.big_rec[4 * p + 3] = ops == 0xffffffffu ? ops : (relabel(ops & 0xffffu) | (relabel(ops >> 16) << 16));
-        int last = -1;
-        int tl[4];
-        for (int j = 0; j < 4; j++) tl[j] = sl[j] == 0xffffu ? -1 : (int)(sl[j] / (uint32_t)Hh);
-        std::sort(tl, tl + 4);
-        for (int j = 0; j < 4; j++) if (tl[j] >= 1 && tl[j] != last) { buckets[tl[j]].push_back((int32_t)p); last = tl[j]; }
+        for (int j = 0; j < 4; j++) {
+          if (sl[j] == 0xffffu || (int32_t)sl[j] < Hh) continue;
+          const int32_t off = (int32_t)sl[j] - Hh;
+          const uint32_t cf = (H.pair_rec[4 * p + 2] >> (8 * j)) & 0xffu;     // signed byte coefficient
+          tail[off / TT].push_back({(uint32_t)p, (uint32_t)(off % TT) | (cf << 24)});
+        }
       }
-      H.big_bucket_ptr.assign(1, 0);
-      for (int t = 0; t < H.big_tiles; t++) {
-        H.big_bucket.insert(H.big_bucket.end(), buckets[t].begin(), buckets[t].end());
-        H.big_bucket_ptr.push_back((int32_t)H.big_bucket.size());
+      H.big_tail_ptr.assign(1, 0);
+      for (auto& tl : tail) {
+        for (auto& e : tl) { H.big_tail_ent.push_back(e.first); H.big_tail_ent.push_back(e.second); }
+        H.big_tail_ptr.push_back((int32_t)(H.big_tail_ent.size() / 2));
       }
     }
   }

@@ -67,12 +67,13 @@ struct NetworkHost {
   std::vector<uint32_t> pair_rec64; // 2 words per record (14-bit slots + 2-bit codes); only when N < 16383 and pairs_adjacent
   // Large-N sweep (state does not fit LDS): species are relabelled so that the `big_H` most
   // frequently referenced ones ("hubs") come first (each group kept in species-id order); records
-  // carry labels; pass 0 walks all records with the hubs' u and du in LDS, pass t >= 1 walks only the
-  // records that touch tail tile t (labels [t*H, (t+1)*H)) via `big_bucket`.
-  int32_t big_H = 0, big_tiles = 0;
+  // carry labels. Hubs keep u and du in LDS; tail rates are gathered per tile of 2 * big_H labels from
+  // `big_tail_ent` = (record, local label | coef << 24) pairs, sorted by record inside each tile.
+  int32_t big_H = 0;
   std::vector<int32_t> big_spec_of_label;    // N
   std::vector<uint32_t> big_rec;             // 4 words per record, slots = labels
-  std::vector<int32_t> big_bucket_ptr, big_bucket;   // tiles+1 ; record indices per tail tile (tile 0 unused)
+  std::vector<int32_t> big_tail_ptr;         // tail tiles + 1 (entry offsets)
+  std::vector<uint32_t> big_tail_ent;        // 2 words per entry
   bool pairs_adjacent = false;     // record p pairs reactions (2p, 2p+1): k streams as double2, no index load
   int64_t n_pairs() const { return (int64_t)pair_k.size() / 2; }
   // species-major CSR: du[i] = sum_e sp_coef[e] * rate[sp_rxn[e]]

@@ -204,6 +204,14 @@ def test_full_size_properties_c5_tiled_sweep():
     sc = on.abs_rhs(k, U[2]) + 1e-300
     assert (np.abs(single - shared) / sc).max() < TOL
     assert (np.abs(single - on.rhs(k, U[2])) / sc).max() < TOL
+    # more states than workgroups (shared k): every workgroup re-uses its scratch row for several
+    # states, so a stale tail-u / net-rate value from the previous state would show up here
+    B2 = 600
+    U2 = np.stack([_state(50000, 100 + (b % 7)) * (1.0 + 0.001 * b) for b in range(B2)])
+    got2 = h.rhs_batched(U2)
+    for b in (0, 255, 256, 511, 512, B2 - 1):
+        sc = on.abs_rhs(k, U2[b]) + 1e-300
+        assert (np.abs(got2[b] - on.rhs(k, U2[b])) / sc).max() < TOL
     # Jacobian at this size: oracle comparison
     rowptr, col = h.jac_pattern()
     Jd = sp.csr_matrix((h.jac_values(U[0]), col, rowptr), shape=(50000, 50000))
