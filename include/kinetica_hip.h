@@ -153,6 +153,19 @@ int kin_solve(kin_network* h, const kin_params* params, const double* u0,
  * (src/utils.jl:135-139). Chunking / save grid / retry semantics as kin_solve; no restarts at all. */
 int kin_solve_continuous(kin_network* h, const kin_params* params, const double* u0, const double* t_nodes,
                          const double* T_nodes, int64_t n_nodes, int64_t* n_saved, int32_t* retcode, kin_stats* stats);
+/* N1: return_integrator=true (methods.jl:105-106, 175-178, 242-246, 706-709): `init(oprob, solver; kwargs...)`
+ * without solve!. The integrator spans the whole tspan (solve_chunks = 0) or the first chunk
+ * [0, solve_chunkstep] (solve_chunks = 1, what the reference hands back); tstops / T_stops / k_table as
+ * in kin_solve (n_stops = 0: the rates set on the handle). Save grid and the tolerance retry loop are
+ * not part of an integrator (they belong to adaptive_solve!, solve_utils.jl:376-424). */
+int kin_integrator_init(kin_network* h, const kin_params* params, const double* u0, const double* tstops,
+                        const double* T_stops, const double* k_table, int64_t n_stops);
+/* step!(integ) x max_steps accepted steps (max_steps <= 0: solve!(integ), run to the end of the span);
+ * rate updates fire when the time reaches a tstop (solve_utils.jl:435-509). steps_taken < max_steps
+ * means the end of the span was reached or the integrator failed (see kin_integrator_state). */
+int kin_integrator_step(kin_network* h, int64_t max_steps, int64_t* steps_taken);
+/* integ.t, integ.u[N], the integrator's KIN_RETCODE_* and counters; any pointer may be NULL. */
+int kin_integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, kin_stats* stats);
 int kin_solution_size(const kin_network* h, int64_t* n_saved, int64_t* n_species);
 /* out_t[n_saved], out_u[n_saved][N] (sol.t / sol.u of ODESolveOutput, analysis/io.jl:3-11). */
 int kin_solution_copy(const kin_network* h, double* out_t, double* out_u);

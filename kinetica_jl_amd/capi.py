@@ -23,7 +23,8 @@ SYMBOLS = [
     "kin_set_rates", "kin_get_rates", "kin_set_arrhenius", "kin_rates_at", "kin_arrhenius_eval",
     "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev",
     "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solve_continuous", "kin_solution_size",
-    "kin_solution_copy", "kin_solution_max", "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
+    "kin_solution_copy", "kin_solution_max", "kin_integrator_init", "kin_integrator_step", "kin_integrator_state",
+    "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
 ]
 
 
@@ -85,6 +86,9 @@ def lib():
                                 POINTER(KinStats)]
         L.kin_solve_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64, P64, POINTER(c_int32),
                                            POINTER(KinStats)]
+        L.kin_integrator_init.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64]
+        L.kin_integrator_step.argtypes = [c_void_p, c_int64, P64]
+        L.kin_integrator_state.argtypes = [c_void_p, PD, PD, POINTER(c_int32), POINTER(KinStats)]
         L.kin_solution_size.argtypes = [c_void_p, P64, P64]
         L.kin_solution_copy.argtypes = [c_void_p, PD, PD]
         L.kin_solution_max.argtypes = [c_void_p, PD]
@@ -262,6 +266,32 @@ class HipNetwork:
         if n_saved.value:
             self._chk(lib().kin_solution_copy(self._h, _pd(t), _pd(u)))
         return t, u, rc.value, stats.as_dict(), st
+
+    def integrator_init(self, params: KinParams, u0, tstops=None, T_stops=None, k_table=None):
+        """kin_integrator_init: init(oprob, solver; kwargs...) without solve! (return_integrator=true)."""
+        u0 = _f64(u0)
+        assert len(u0) == self.n
+        n_stops = 0
+        if tstops is not None:
+            tstops = _f64(tstops)
+            n_stops = len(tstops)
+            T_stops = _f64(T_stops) if T_stops is not None else None
+            k_table = _f64(k_table) if k_table is not None else None
+        self._chk(lib().kin_integrator_init(self._h, ctypes.byref(params), _pd(u0), _pd(tstops), _pd(T_stops),
+                                            _pd(k_table), n_stops))
+
+    def integrator_step(self, max_steps=1):
+        """step!(integ) x max_steps (<= 0: solve!(integ)); returns the number of accepted steps taken."""
+        n = c_int64(0)
+        self._chk(lib().kin_integrator_step(self._h, int(max_steps), ctypes.byref(n)))
+        return n.value
+
+    def integrator_state(self, with_u=True):
+        """(integ.t, integ.u or None, retcode, stats dict)."""
+        t, rc, stats = c_double(0.0), c_int32(0), KinStats()
+        u = np.empty(self.n) if with_u else None
+        self._chk(lib().kin_integrator_state(self._h, ctypes.byref(t), _pd(u), ctypes.byref(rc), ctypes.byref(stats)))
+        return t.value, u, rc.value, stats.as_dict()
 
     def newton_solve(self, c, u, b):
         """(I - c J(u)) x = b through the solver's on-device LU (diagnostic)."""

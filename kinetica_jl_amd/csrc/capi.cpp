@@ -295,6 +295,31 @@ int kin_solve_continuous(kin_network* h, const kin_params* params, const double*
   KIN_CATCH(h)
 }
 
+int kin_integrator_init(kin_network* h, const kin_params* params, const double* u0, const double* tstops,
+                        const double* T_stops, const double* k_table, int64_t n_stops) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(params && u0, ERR_INVALID_ARG, "params / u0 is null");
+  require(n_stops >= 0, ERR_INVALID_ARG, "n_stops < 0");
+  integrator_init(h, *params, u0, tstops, T_stops, k_table, n_stops);
+  KIN_CATCH(h)
+}
+
+int kin_integrator_step(kin_network* h, int64_t max_steps, int64_t* steps_taken) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  const int64_t n = integrator_step(h, max_steps);
+  if (steps_taken) *steps_taken = n;
+  KIN_CATCH(h)
+}
+
+int kin_integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, kin_stats* stats) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  integrator_state(h, t, u, retcode, stats);
+  KIN_CATCH(h)
+}
+
 int kin_solution_size(const kin_network* h, int64_t* n_saved, int64_t* n_species) {
   if (!h) return KIN_ERR_INVALID_ARG;
   if (n_saved) *n_saved = h->n_saved;

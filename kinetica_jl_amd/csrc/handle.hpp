@@ -7,7 +7,7 @@
 #include "kernels.hpp"
 #include "network.hpp"
 
-namespace kin { struct Solver; }
+namespace kin { struct Solver; struct IntegratorState; }
 
 struct kin_network {
   kin::NetworkHost host;
@@ -40,6 +40,7 @@ struct kin_network {
 
   // solver + stored solution (solver.cpp)
   std::unique_ptr<kin::Solver> solver;
+  std::unique_ptr<kin::IntegratorState> integ;   // return_integrator=true stepping state
   std::vector<double> sol_t, sol_u;
   kin::DevBuf<double> d_sol_u;   // saved states on the device, [n_saved][N]
   int64_t n_saved = 0;

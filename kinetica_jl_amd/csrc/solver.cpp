@@ -601,6 +601,122 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   return retcode;
 }
 
+// ------------------------------------------------------------------------------------------
+// return_integrator=true (methods.jl:175-178, 242-246, 706-709): the initialised integrator is
+// handed back instead of being solved; the caller advances it with step!(integ) / solve!(integ)
+// and reads integ.t / integ.u. It spans what the reference's integrator spans: the whole tspan for
+// solve_chunks=false, the first chunk [0, solve_chunkstep] otherwise; discrete rate updates
+// (tstops inside that span) fire when the time reaches them, as the PresetTimeCallback /
+// DiscreteCallback of solve_utils.jl:435-509 do.
+// ------------------------------------------------------------------------------------------
+struct IntegratorState {
+  bool active = false, in_segment = false, have_table = false;
+  double t_loc0 = 0, t_loc1 = 0, t_seg = 0, seg_end = 0;
+  bool ends_at_stop = false;
+  std::vector<double> tstops, T_stops;
+  int64_t stop_i = 0;
+  int retcode = KIN_RETCODE_SUCCESS;
+};
+
+void integrator_init(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
+                     const double* k_table, int64_t n_stops) {
+  const int64_t N = h->host.N, R = h->host.R;
+  if (!(p.tspan0 < p.tspan1)) throw KinError(ERR_INVALID_ARG, "Invalid time span");
+  if (!(p.abstol > 0) || !(p.reltol > 0)) throw KinError(ERR_INVALID_ARG, "tolerances must be positive");
+  const bool chunks = p.solve_chunks != 0;
+  if (chunks) {
+    if (!(p.solve_chunkstep > 0)) throw KinError(ERR_INVALID_ARG, "solve_chunkstep must be positive");
+    const double q = p.tspan1 / p.solve_chunkstep;
+    if (q != std::floor(q) || q < 1) throw KinError(ERR_INVALID_ARG, "Simulation timespan is not divisible by requested chunkwise simulation step size");
+  }
+  const bool variable = n_stops > 0;
+  if (variable) {
+    if (!tstops) throw KinError(ERR_INVALID_ARG, "tstops is null");
+    if (!k_table && !T_stops) throw KinError(ERR_INVALID_ARG, "need k_table or T_stops with tstops");
+    if (!k_table && !h->has_arrhenius) throw KinError(ERR_STATE, "T_stops given but Arrhenius parameters were never set");
+    for (int64_t i = 1; i < n_stops; i++)
+      if (!(tstops[i] > tstops[i - 1])) throw KinError(ERR_INVALID_ARG, "tstops must be strictly increasing");
+  } else if (!h->has_rates) {
+    throw KinError(ERR_STATE, "rates were never set");
+  }
+  if (!h->solver) h->solver.reset(new Solver(h));
+  if (!h->integ) h->integ.reset(new IntegratorState());
+  Solver& S = *h->solver;
+  IntegratorState& I = *h->integ;
+  hipStream_t s = h->stream;
+  S.st = kin_stats{};
+  S.ban_negatives = p.ban_negatives != 0;
+  S.set_tols(p.abstol, p.reltol);
+  S.pre_attempt = nullptr;
+  S.iters_left = p.maxiters;
+  I = IntegratorState{};
+  I.have_table = variable && k_table != nullptr;
+  if (I.have_table) { h->table.upload(k_table, (size_t)n_stops * R, s); h->table_rows = n_stops; }
+  if (variable) {
+    I.tstops.assign(tstops, tstops + n_stops);
+    if (T_stops) I.T_stops.assign(T_stops, T_stops + n_stops);
+  }
+  I.t_loc0 = chunks ? 0.0 : p.tspan0;
+  I.t_loc1 = chunks ? p.solve_chunkstep : p.tspan1;
+  I.t_seg = I.t_loc0;
+  S.y.upload(u0, N, s);
+  // rates in force at the start: the last stop at or before it, else the initial conditions (stop 0)
+  const double t_start_global = chunks ? 0.0 : p.tspan0;
+  while (variable && I.stop_i < n_stops && I.tstops[I.stop_i] <= t_start_global) I.stop_i++;
+  if (variable) apply_rates(h, I.T_stops.data(), I.have_table, I.stop_i > 0 ? I.stop_i - 1 : 0);
+  I.active = true;
+  S.t = 0.0;
+  KIN_HIP(hipStreamSynchronize(s));
+}
+
+// up to max_steps accepted steps (max_steps <= 0: to the end of the span); returns the number taken
+int64_t integrator_step(kin_network* h, int64_t max_steps) {
+  if (!h->integ || !h->integ->active) throw KinError(ERR_STATE, "no integrator: call kin_integrator_init first");
+  Solver& S = *h->solver;
+  IntegratorState& I = *h->integ;
+  hipStream_t s = h->stream;
+  const int64_t N = h->host.N;
+  int64_t taken = 0;
+  while (I.retcode == KIN_RETCODE_SUCCESS && I.t_seg < I.t_loc1 && (max_steps <= 0 || taken < max_steps)) {
+    if (!I.in_segment) {
+      I.seg_end = I.t_loc1;
+      I.ends_at_stop = false;
+      if (I.stop_i < (int64_t)I.tstops.size() && I.tstops[I.stop_i] < I.t_loc1) { I.seg_end = I.tstops[I.stop_i]; I.ends_at_stop = true; }
+      if (!S.restart(0.0, I.seg_end - I.t_seg)) { I.retcode = KIN_RETCODE_UNSTABLE; break; }
+      I.in_segment = true;
+    }
+    const double seg_len = I.seg_end - I.t_seg;
+    StepStatus ss = S.step(seg_len);
+    if (S.iters_left < 0) { I.retcode = KIN_RETCODE_MAXITERS; break; }
+    if (ss == STEP_DT_MIN) { I.retcode = KIN_RETCODE_DTLESSTHANMIN; break; }
+    if (ss == STEP_UNSTABLE) { I.retcode = KIN_RETCODE_UNSTABLE; break; }
+    S.select_order();
+    taken++;
+    if (S.t >= seg_len) {   // segment finished: state = D[0]; switch the rates at a tstop
+      KIN_HIP(hipMemcpyAsync(S.y.p, S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+      I.t_seg = I.seg_end;
+      I.in_segment = false;
+      S.t = 0.0;
+      if (I.ends_at_stop) { apply_rates(h, I.T_stops.data(), I.have_table, I.stop_i); I.stop_i++; }
+    }
+  }
+  KIN_HIP(hipStreamSynchronize(s));
+  return taken;
+}
+
+void integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, kin_stats* stats) {
+  if (!h->integ || !h->integ->active) throw KinError(ERR_STATE, "no integrator: call kin_integrator_init first");
+  Solver& S = *h->solver;
+  IntegratorState& I = *h->integ;
+  if (t) *t = I.in_segment ? I.t_seg + S.t : I.t_seg;
+  if (u) {
+    (I.in_segment ? S.D : S.y).download(u, h->host.N, h->stream);   // D[0] = state after the last accepted step
+    KIN_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (retcode) *retcode = I.retcode;
+  if (stats) { *stats = S.st; stats->final_abstol = S.atol; stats->final_reltol = S.rtol; }
+}
+
 void solution_max(kin_network* h, double* out_umax) {
   if (!h->solver) throw KinError(ERR_STATE, "no solution stored");
   Solver& S = *h->solver;
@@ -638,6 +754,7 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
 
 kin_network::kin_network() {}
 kin_network::~kin_network() {
+  integ.reset();
   solver.reset();
   if (stream) (void)hipStreamDestroy(stream);
 }

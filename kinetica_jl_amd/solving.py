@@ -369,15 +369,58 @@ class ODESolveOutput:
 
 
 # ---- solve_network (src/solving/methods.jl:105-130, 330-360) ----------------------------------------------
+class HipIntegrator:
+    """What `solve_network(...; return_integrator=true)` hands back (methods.jl:98-100, 175-178): the
+    initialised integrator, living on the device. `step()` = step!(integ), `solve()` = solve!(integ),
+    `t` / `u` = integ.t / integ.u. It spans the whole tspan (solve_chunks=false) or the first chunk
+    (solve_chunks=true: "integrators for chunkwise solutions require significant work to fully solve
+    outside of their intended solution methods", methods.jl:244). Close it (or use `with`) to free the GPU."""
+
+    def __init__(self, handle, sd, rd, pars):
+        self._h, self.sd, self.rd, self.pars = handle, sd, rd, pars
+
+    def step(self, n=1):
+        """n accepted steps; returns how many were taken (fewer at the end of the span / on failure)."""
+        return self._h.integrator_step(max(int(n), 1))
+
+    def solve(self):
+        self._h.integrator_step(0)
+        return self
+
+    @property
+    def t(self):
+        return self._h.integrator_state(with_u=False)[0]
+
+    @property
+    def u(self):
+        return self._h.integrator_state()[1]
+
+    @property
+    def retcode(self):
+        return capi.RETCODE_NAMES[self._h.integrator_state(with_u=False)[2]]
+
+    @property
+    def stats(self):
+        return self._h.integrator_state(with_u=False)[3]
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
     """Solve a network with static or variable kinetics on the MI355X.
 
     Pipeline order as in the reference: deepcopy -> [variable: solve condition
     profiles] -> filter -> splice -> setup_network! -> low-k cutoff (mutates the copies AND the
     caller's calculator) -> rates -> u0 -> solve -> ODESolveOutput with the REDUCED network."""
-    if return_integrator:
-        raise NotImplementedError("return_integrator=true (manual stepping of the SciML integrator, methods.jl:175-178) "
-                                  "has no counterpart: the integrator lives on the device")
     pars, conditions, calc = method.pars, method.conditions, method.calculator
     sd_a, rd_a = (copy.deepcopy(sd), copy.deepcopy(rd)) if copy_network else (sd, rd)
     variable = isinstance(method, VariableODESolve)
@@ -396,6 +439,22 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
             h.set_arrhenius(calc.Ea, calc.A, calc.k_max, calc.t_mult)
         sol_k = None
         sol_vcs = None
+        if return_integrator:
+            # methods.jl:175-178, 242-246, 706-709: hand back the initialised integrator instead of solving
+            if variable and not conditions.discrete_updates and arr:
+                raise NotImplementedError("return_integrator with continuous rate updates: use solve_network, or a "
+                                          "ConditionSet with ts_update (discrete updates)")
+            if not variable or not conditions.discrete_updates:
+                h.set_rates(get_initial_rates(conditions, calc))
+                h.integrator_init(pars.to_kin_params(), u0)
+            else:
+                tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
+                if arr:
+                    h.integrator_init(pars.to_kin_params(), u0, tstops=tstops, T_stops=T)
+                else:
+                    h.integrator_init(pars.to_kin_params(), u0, tstops=tstops, k_table=table)
+            integ, h = HipIntegrator(h, sd_a, rd_a, pars), None      # the integrator owns the handle now
+            return integ
         if not variable or (not conditions.discrete_updates and not arr):
             # static rates (a Dummy calculator is constant under continuous updates as well)
             k0 = get_initial_rates(conditions, calc)
@@ -423,6 +482,7 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
         if pars.update_tols and st["final_abstol"] != pars.abstol:
             pars.abstol, pars.reltol = st["final_abstol"], st["final_reltol"]   # solve_utils.jl:397-401
     finally:
-        h.close()
+        if h is not None:
+            h.close()
     sol = ODESolution(t, u, capi.RETCODE_NAMES[rc], k=sol_k, stats=st)
     return ODESolveOutput(sd_a, rd_a, sol, sol_k, sol_vcs, pars, conditions)

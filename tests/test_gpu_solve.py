@@ -387,3 +387,69 @@ def test_continuous_rate_updates_n3():
     with pytest.raises(capi.KineticaHipError):
         h.solve_continuous(kp((0.0, 1.0), True, 0.5), [1.0, 0.0], [0.0], [600.0])
     h.close()
+
+
+def test_return_integrator_n1(golden_dir):
+    """return_integrator=true (methods.jl:175-178, 242-246, 706-709): the initialised integrator is
+    stepped by the caller. Same kernels and step logic as kin_solve, so manual stepping reproduces
+    kin_solve's every-step output exactly."""
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    net, Ea, A = synthetic_crn(60, 300, seed=11)
+    u0 = np.zeros(60); u0[0] = 1.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e3)
+    k = orc.arrhenius(Ea, A, 900.0, k_max=1e3)
+    h.set_rates(k)
+    # (a) static, complete timespan: saveat = [] makes kin_solve store every accepted step
+    t, u, rc, st, _ = h.solve(kp((0.0, 1.0), chunks=False), u0)
+    h.integrator_init(kp((0.0, 1.0), chunks=False), u0)
+    t0, uu, rc0, _ = h.integrator_state()
+    assert t0 == 0.0 and rc0 == 0 and np.array_equal(uu, u0)
+    ts = []
+    while h.integrator_step(1) == 1:
+        ts.append(h.integrator_state(with_u=False)[0])
+    assert np.array_equal(np.array(ts), t[1:])
+    tf, uf, rcf, stf = h.integrator_state()
+    assert tf == 1.0 and rcf == 0 and np.array_equal(uf, u[-1]) and stf["n_steps"] == st["n_steps"]
+    assert h.integrator_step(5) == 0                      # already at the end of the span
+    # several steps per call, then solve!(integ)
+    h.integrator_init(kp((0.0, 1.0), chunks=False), u0)
+    assert h.integrator_step(7) == 7
+    assert h.integrator_state(with_u=False)[0] == t[7]
+    h.integrator_step(0)
+    assert np.array_equal(h.integrator_state()[1], u[-1])
+    # (b) discrete rate updates, complete timespan: the tstops fire during manual stepping
+    z = np.load(os.path.join(golden_dir, "truth_small.npz"))
+    tst, T = np.arange(8) * 0.125, z["ramp_T"]
+    t3, u3, rc3, st3, _ = h.solve(kp((0.0, 1.0), False), u0, tstops=tst, T_stops=T)
+    h.integrator_init(kp((0.0, 1.0), False), u0, tstops=tst, T_stops=T)
+    n = h.integrator_step(0)
+    tf, uf, rcf, stf = h.integrator_state()
+    assert n == st3["n_steps"] and tf == 1.0 and np.array_equal(uf, u3[-1]) and stf["n_restarts"] == 8
+    assert errscale(uf, z["ramp_u"][-1]) < 100
+    # (c) chunkwise: the integrator spans the first chunk only
+    t4, u4, rc4, st4, _ = h.solve(kp((0.0, 1.0), True, 0.25), u0, tstops=tst, T_stops=T)
+    h.integrator_init(kp((0.0, 1.0), True, 0.25), u0, tstops=tst, T_stops=T)
+    h.integrator_step(0)
+    tf, uf, _, _ = h.integrator_state()
+    assert tf == 0.25 and np.array_equal(uf, u4[1])
+    # errors: stepping without init on a fresh handle, invalid span
+    h2 = capi.HipNetwork.from_flat(net)
+    with pytest.raises(capi.KineticaHipError):
+        h2.integrator_step(1)
+    h2.set_rates(k)
+    with pytest.raises(capi.KineticaHipError):
+        h2.integrator_init(kp((1.0, 0.0), chunks=False), u0)
+    h2.close(); h.close()
+    # (d) host interface: solve_network(...; return_integrator=true)
+    sd = S.SpeciesData.from_names([f"S{i}" for i in range(60)])
+    rd = S.RxData.from_flat(net)
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e3)
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0={"S0": 1.0}, solve_chunks=False, low_k_cutoff="none")
+    with S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 900.0}), calc), sd, rd, return_integrator=True) as integ:
+        assert isinstance(integ, S.HipIntegrator) and integ.t == 0.0
+        # (the calculator's rates differ from orc.arrhenius in the last bits, so no bitwise comparison here)
+        assert integ.step(3) == 3 and abs(integ.t - t[3]) < 1e-6 * t[3]
+        integ.solve()
+        assert integ.t == 1.0 and integ.retcode == "Success" and errscale(integ.u, u[-1]) < 1
