@@ -452,6 +452,18 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
     un[x] = (b < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)b * N + i) : make_double2(0.0, 0.0);
   }
   for (int i = tid * 2; i < N; i += 2048) *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
+  // the first batch of rate constants of a state is requested before the previous state's barrier /
+  // write-out / staging, so the k stream does not drain at state boundaries
+  constexpr bool KPRE = TR >= ILP;
+  double2 k0[KPRE ? ILP : 1];
+  if (KPRE) {
+    const double* kb = k_b ? k_b + (size_t)b * R : k_1;
+#pragma unroll
+    for (int x = 0; x < ILP; x++) {
+      const int p = tid + x * 1024;
+      k0[x] = (b < B && p < P) ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+    }
+  }
   for (; b < B; b += gridDim.x) {
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
     double* dub = du + (size_t)b * N;
@@ -474,7 +486,8 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
         const int p = tid + (i0 + x) * 1024;
-        kk[x] = p < P ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+        if (KPRE && i0 == 0) kk[x] = k0[x];
+        else kk[x] = p < P ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
@@ -498,6 +511,14 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) sweep_apply(w[x], kk[x], u_s, du_s);
+    }
+    if (KPRE) {
+      const double* kn = k_b ? k_b + (size_t)bn * R : k_1;
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        const int p = tid + x * 1024;
+        k0[x] = (bn < B && p < P) ? *reinterpret_cast<const double2*>(kn + 2 * (size_t)p) : make_double2(0.0, 0.0);
+      }
     }
     __syncthreads();
     for (int i = tid * 2; i < N; i += 2048) {
