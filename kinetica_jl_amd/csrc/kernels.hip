@@ -30,13 +30,26 @@ SegPlanView SegPlanDev::view() const {
 // ------------------------------------------------------------------------------------------
 // deterministic segmented gather-sum
 // ------------------------------------------------------------------------------------------
+// The store operands that do not depend on the sum (old value, pivot, psi, d) are loaded by seg_pre
+// BEFORE the gather loop: these kernels are a chain of dependent global loads on a few thousand rows,
+// so every load taken off the critical path is ~1 us per launch. The same goes for the skip flag
+// (blind-enqueued Newton iterations): it is loaded first but only tested right before the store.
+struct SegPre { double o, a, b; };
 template <int OP>
-__device__ __forceinline__ void seg_store(double* out, const double* src, int32_t dst, int32_t aux, double acc,
-                                          const SegExtra& ex) {
+__device__ __forceinline__ SegPre seg_pre(const double* out, const double* src, int32_t dst, int32_t aux, const SegExtra& ex) {
+  SegPre q{0.0, 0.0, 0.0};
+  if (dst < 0) return q;
+  if (OP == SEG_PROD_SUB) q.o = out[dst];
+  else if (OP == SEG_PROD_SUB_DIV) { q.o = out[dst]; q.a = src[aux]; }
+  else if (OP == SEG_COEF_BDF) { q.a = ex.psi[aux]; q.b = ex.d[aux]; }
+  return q;
+}
+template <int OP>
+__device__ __forceinline__ void seg_store(double* out, int32_t dst, double acc, const SegPre& q, const SegExtra& ex) {
   if (OP == SEG_COEF_SET) out[dst] = acc;
-  else if (OP == SEG_PROD_SUB) out[dst] -= acc;
-  else if (OP == SEG_PROD_SUB_DIV) out[dst] = (out[dst] - acc) / src[aux];
-  else out[dst] = ex.cscal * acc - ex.psi[aux] - ex.d[aux];
+  else if (OP == SEG_PROD_SUB) out[dst] = q.o - acc;
+  else if (OP == SEG_PROD_SUB_DIV) out[dst] = (q.o - acc) / q.a;
+  else out[dst] = ex.cscal * acc - q.a - q.b;
 }
 template <int OP> struct seg_is_prod { static constexpr bool v = (OP == SEG_PROD_SUB || OP == SEG_PROD_SUB_DIV); };
 
@@ -49,12 +62,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 template <int OP>
 __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
-  if (ex.skip && *ex.skip) return;
+  const int skip = ex.skip ? *ex.skip : 0;
   const int lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (task < p.G) {
     const int32_t dst = p.grp_dst[task * 64 + lane];
+    const int32_t aux = p.grp_aux[task * 64 + lane];
     const int32_t c0 = p.grp_off[task], c1 = p.grp_off[task + 1];
+    const SegPre pre = seg_pre<OP>(out, src, dst, aux, ex);
     double acc = 0.0;
     for (int32_t col = c0; col < c1; col += 4) {
       // issue the index loads of up to four columns, then their gathers, then accumulate in order
@@ -78,10 +93,12 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
         else acc += (double)c[x] * va[x];
       }
     }
-    if (dst >= 0) seg_store<OP>(out, src, dst, p.grp_aux[task * 64 + lane], acc, ex);
+    if (dst >= 0 && !skip) seg_store<OP>(out, dst, acc, pre, ex);
   } else if (task < p.G + p.S) {
     const int sidx = task - p.G;
     const int32_t e0 = p.seg_beg[sidx], e1 = p.seg_end[sidx];
+    const int32_t sdst = p.seg_dst[sidx];
+    const SegPre pre = seg_pre<OP>(out, src, lane == 0 ? sdst : -1, sdst >= 0 ? p.seg_aux[sidx] : 0, ex);
     // SEG_LEN = 256: at most four entries per lane, all loads in flight together
     float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
 #pragma unroll
@@ -104,22 +121,23 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
       else acc += (double)c[x] * va[x];
     }
     acc = wave_sum(acc);
-    if (lane == 0) {
-      const int32_t dst = p.seg_dst[sidx];
-      if (dst >= 0) seg_store<OP>(out, src, dst, p.seg_aux[sidx], acc, ex);
-      else p.partials[-dst - 1] = acc;
+    if (lane == 0 && !skip) {
+      if (sdst >= 0) seg_store<OP>(out, sdst, acc, pre, ex);
+      else p.partials[-sdst - 1] = acc;
     }
   }
 }
 
 template <int OP>
 __global__ void segsum_fix_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
-  if (ex.skip && *ex.skip) return;
+  const int skip = ex.skip ? *ex.skip : 0;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= p.F) return;
+  const int32_t dst = p.fix_dst[f];
+  const SegPre pre = seg_pre<OP>(out, src, dst, p.fix_aux[f], ex);
   double acc = 0.0;
   for (int32_t q = p.fix_ptr[f]; q < p.fix_ptr[f + 1]; q++) acc += p.partials[q];
-  seg_store<OP>(out, src, p.fix_dst[f], p.fix_aux[f], acc, ex);
+  if (!skip) seg_store<OP>(out, dst, acc, pre, ex);
 }
 
 void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* out, const SegExtra& ex, hipStream_t s) {

@@ -213,7 +213,7 @@ double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, h
 // x = S[0:m, 0:m] * y : one wavefront per row
 __global__ __launch_bounds__(256) void gemv_kernel(const double* __restrict__ S, int ld, int m, const double* __restrict__ y,
                                                    double* __restrict__ x, const int* skip) {
-  if (skip && *skip) return;
+  const int sk = skip ? *skip : 0;   // tested at the store only: keeps the flag load off the critical path
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const double* __restrict__ S,
   for (int j = lane; j < m; j += 64) acc += a[j] * y[j];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) x[row] = acc;
+  if (lane == 0 && !sk) x[row] = acc;
 }
 
 void launch_gemv(const double* S, int32_t ld, int32_t m, const double* y, double* x, const int* skip, hipStream_t s) {
@@ -458,12 +458,13 @@ __global__ __launch_bounds__(256) void colmax_kernel(int N, long long M, const d
 __global__ __launch_bounds__(256) void rates_skip_kernel(int R, const double* __restrict__ k, const double* __restrict__ u,
                                                          const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
                                                          double* __restrict__ rate, const int* skip) {
-  if (skip && *skip) return;
+  const int sk = skip ? *skip : 0;
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= R) return;
   const int32_t a = x0[r], b = x1[r];
   const double ub = b >= 0 ? u[b] : 1.0;
-  rate[r] = k[r] * u[a] * ub;
+  const double v = k[r] * u[a] * ub;
+  if (!sk) rate[r] = v;
 }
 
 #define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)

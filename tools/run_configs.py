@@ -1,6 +1,6 @@
 """Runs the BASELINE.json configurations C2..C5 on one MI355X and prints one JSON
 record per configuration: kernel timings (HIP events via torch), achieved GB/s against the
-algorithmic bytes of SURVEY 8(d), solver statistics. Usage: python tools/run_configs.py [c2 c3 c4 c5 table]"""
+algorithmic bytes of SURVEY 8(d), solver statistics. Usage: python tools/run_configs.py [c2 c3 c4 c5 c5sweep table]"""
 import json
 import os
 import sys
@@ -70,6 +70,8 @@ def main():
         h.close()
     if "c3" in which:
         out.append(sweep_record("C3", 10000, 50000, 4096))
+    if "c5sweep" in which:   # the C5 sweep alone (profiling passes)
+        out.append(sweep_record("C5", 50000, 250000, 1024))
     if "c5" in which:     # C5: 50k / 250k: tiled sweep path + single-state kernels + a short solve
         out.append(sweep_record("C5", 50000, 250000, 1024))
         net, Ea, A = synthetic_crn(50000, 250000)

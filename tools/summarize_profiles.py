@@ -47,3 +47,31 @@ summary = {
 summary["traffic_over_algorithmic"] = summary["hbm_bytes_per_launch_corrected"] / summary["algorithmic_bytes_per_launch"]
 json.dump(summary, open(os.path.join(dst, f"{tag}_sweep_pmc.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "bench_line_under_profiler"}, indent=1))
+
+
+# ---- C5 large-N sweep and the C4-size rate table (tools/run_configs.py c5sweep table)
+def pmc_of(sub, name, kernel):
+    f = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+
+
+cfg_stats = glob.glob(os.path.join(out, "cfg_stats", "**", "*kernel_stats.csv"), recursive=True)
+if cfg_stats:
+    crow = list(csv.DictReader(open(cfg_stats[0])))
+    recs = [json.loads(l) for l in open(os.path.join(out, "cfg_stats.log")) if l.startswith("{")]
+    cfg = {"command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python3 tools/run_configs.py c5sweep table",
+           "records_under_profiler": recs, "kernels": []}
+    for kern, alg in (("kin::sweep_big_kernel", 20 * 250000 + 1024 * (8 * 250000 + 16 * 50000)),
+                      ("kin::rate_table_kernel", 16 * 50000 + 8 * 14001 + 8 * 14001 * 50000)):
+        row = [r for r in crow if kern in r["Name"]][0]
+        fe, wr = pmc_of("cfg_fetch", "FETCH_SIZE", kern), pmc_of("cfg_write", "WRITE_SIZE", kern)
+        hbm = (2.0 * sum(fe) / len(fe) + sum(wr) / len(wr)) * 1024.0
+        avg_ns = float(row["AverageNs"])
+        cfg["kernels"].append({"kernel": kern, "calls": int(row["Calls"]), "avg_ns_rocprof": avg_ns,
+                               "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / avg_ns,
+                               "frac_of_8TBps": alg / avg_ns / 8000.0,
+                               "FETCH_SIZE_KiB_avg": sum(fe) / len(fe), "WRITE_SIZE_KiB_avg": sum(wr) / len(wr),
+                               "hbm_bytes_per_launch_corrected": hbm, "traffic_over_algorithmic": hbm / alg})
+    json.dump(cfg, open(os.path.join(dst, f"{tag}_c5_table_pmc.json"), "w"), indent=1)
+    print(json.dumps(cfg["kernels"], indent=1))
