@@ -171,11 +171,16 @@ def main():
                                                          lambda kk: (lambda y: on.jac(kk, y)), N, pars, u0, k0=k1000)
             cpu_wall = time.perf_counter() - t1
             nck = args.cpu_solve_chunks
-            dev_vs_cpu = float((np.abs(us[:nck + 1] - uo) / (1e-10 + 1e-8 * np.abs(uo))).max())
+            dev = np.abs(us[:nck + 1] - uo) / (1e-10 + 1e-8 * np.abs(uo))
+            dev_vs_cpu = float(dev.max())
+            # the integrator controls the RMS norm over the N species (so a single species may sit sqrt(N) x
+            # further out than the norm): report the controlled quantity next to the per-species maximum
+            dev_rms = float(np.sqrt((dev ** 2).mean(axis=1)).max())
             out["solve_network"].update({"cpu_wall_s": cpu_wall, "cpu_chunks": nck, "cpu_s_per_chunk": cpu_wall / nck,
                                          "cpu_kind": "port (oracle BDF + SuperLU, 1 core)",
                                          "speedup_per_chunk": (cpu_wall / nck) / (gpu_wall / args.solve_chunks),
-                                         "max_dev_vs_cpu_in_tol_units": dev_vs_cpu, "cpu_stats": sto})
+                                         "max_dev_vs_cpu_in_tol_units": dev_vs_cpu,
+                                         "rms_dev_vs_cpu_in_tol_units": dev_rms, "cpu_stats": sto})
 
     # ---- CPU baseline for the headline metric: oracle RHS, 1 core, bounded sample
     if rank == 0 and not args.no_cpu:
