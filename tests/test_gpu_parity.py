@@ -260,3 +260,38 @@ def test_batched_sweep_general_record_layouts():
         sc = on.abs_rhs(k, U[b]) + 1e-300
         assert (np.abs(got[b] - on.rhs(k, U[b])) / sc).max() < TOL
     h.close()
+
+
+def test_large_n_sweep_with_explicit_operands_and_block_order():
+    """The large-N sweep (state too large for LDS) on a network that also holds colliders on both sides
+    (explicit operands, slow path), unpaired reactions and an odd reaction count (index-based k loads);
+    more states than workgroups so every workgroup re-uses its scratch rows."""
+    net, Ea, A = synthetic_crn(12000, 60000, seed=3)
+    reacs = [net.reaction(r)[0] for r in range(net.n_reactions)]
+    prods = [net.reaction(r)[1] for r in range(net.n_reactions)]
+    # colliders: a rarely referenced (tail) species and a hub on both sides; an unpaired decay; 2A -> B + C
+    extra = [([(7, 1), (11999, 1)], [(8, 1), (11999, 1)]), ([(11998, 1), (0, 1)], [(11997, 1), (0, 1)]),
+             ([(11990, 1)], [(11991, 1)]), ([(11980, 2)], [(11981, 1), (3, 1)]), ([(5, 1), (11970, 1)], [(11970, 2)])]
+    for r, p in extra:
+        reacs.append(r); prods.append(p)
+    net2 = from_lists(12000, reacs, prods)
+    assert net2.n_reactions % 2 == 1
+    h = capi.HipNetwork.from_flat(net2)
+    on = orc.OracleNetwork.from_flat(net2)
+    rng = np.random.default_rng(5)
+    k = rng.uniform(0.5, 2.0, net2.n_reactions)
+    h.set_rates(k)
+    B = 300
+    U = np.stack([_state(12000, 200 + (b % 5)) * (1.0 + 0.01 * b) for b in range(B)])
+    got = h.rhs_batched(U)
+    for b in (0, 1, 255, 256, 257, B - 1):
+        sc = on.abs_rhs(k, U[b]) + 1e-300
+        assert (np.abs(got[b] - on.rhs(k, U[b])) / sc).max() < TOL
+    K = k[None, :] * rng.uniform(0.5, 2.0, (4, 1))
+    got = h.rhs_batched(U[:4], K)
+    for b in range(4):
+        sc = on.abs_rhs(K[b], U[b]) + 1e-300
+        assert (np.abs(got[b] - on.rhs(K[b], U[b])) / sc).max() < TOL
+    sc = on.abs_rhs(k, U[0]) + 1e-300
+    assert (np.abs(h.rhs(U[0]) - on.rhs(k, U[0])) / sc).max() < TOL
+    h.close()
