@@ -161,7 +161,7 @@ def main():
                                             f"({args.solve_chunks} chunks), abstol 1e-10, reltol 1e-8",
                                 "gpu_wall_s": gpu_wall, "gpu_s_per_chunk": gpu_wall / args.solve_chunks, "retcode": rc,
                                 "stats": st}
-        if not args.no_cpu and args.cpu_solve_chunks > 0:
+        if not args.no_cpu and args.cpu_solve_chunks > 0 and world == 1:   # CPU legs: rank 0 at N=1 only
             from oracle import bdf as obdf
             from oracle import oracle as orc
             on = orc.OracleNetwork.from_flat(net)
@@ -183,7 +183,7 @@ def main():
                                          "rms_dev_vs_cpu_in_tol_units": dev_rms, "cpu_stats": sto})
 
     # ---- CPU baseline for the headline metric: oracle RHS, 1 core, bounded sample
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:
         from oracle import oracle as orc
         on = orc.OracleNetwork.from_flat(net)
         u1 = 10.0 ** np.random.default_rng(0).uniform(-12, 0, N)
