@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
     const int32_t c0 = p.grp_off[task], c1 = p.grp_off[task + 1];
     const SegPre pre = seg_pre<OP>(out, src, dst, aux, ex);
     double acc = 0.0;
-    for (int32_t col = c0; col < c1; col += 4) {
-      // issue the index loads of up to four columns, then their gathers, then accumulate in order
-      float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
+    for (int32_t col = c0; col < c1; col += 8) {
+      // issue the index loads of up to eight columns (a whole ELL group: rows have <= 8 entries), then
+      // their gathers, then accumulate in order: two dependent loads on the critical path, not four
+      float c[8]; int32_t ia[8], ib[8]; double va[8], vb[8];
 #pragma unroll
-      for (int x = 0; x < 4; x++) {
+      for (int x = 0; x < 8; x++) {
         const size_t idx = (size_t)(col + x) * 64 + lane;
         const bool ok = col + x < c1;
         c[x] = ok ? p.ell_c[idx] : 0.0f;
@@ -83,12 +84,12 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.ell_b[idx] : 0;
       }
 #pragma unroll
-      for (int x = 0; x < 4; x++) {
+      for (int x = 0; x < 8; x++) {
         va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
         vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
       }
 #pragma unroll
-      for (int x = 0; x < 4; x++) {
+      for (int x = 0; x < 8; x++) {
         if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
         else acc += (double)c[x] * va[x];
       }

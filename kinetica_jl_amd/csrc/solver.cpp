@@ -105,9 +105,12 @@ struct Solver {
     newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, 0.05);
   }
 
+  double sync_wait_s = 0.0;   // host time spent blocked in sync_ctrl (diagnostic, KIN_TIMING=1)
   void sync_ctrl() {
     KIN_HIP(hipMemcpyAsync(hc, ctrl.p, sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
+    auto t0 = std::chrono::steady_clock::now();
     KIN_HIP(hipStreamSynchronize(s));
+    sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
 
   void rhs(const double* u, double* out) { h->rhs_dev(u, out); st.n_rhs++; }
@@ -411,6 +414,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   Solver& S = *h->solver;
   hipStream_t s = h->stream;
   S.st = kin_stats{};
+  S.sync_wait_s = 0.0;
   S.ban_negatives = p.ban_negatives != 0;
   double abstol = p.abstol, reltol = p.reltol;
   S.set_tols(abstol, reltol);
@@ -597,6 +601,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   S.st.lu_dense_dim = S.lu.m; S.st.lu_sparse_rows = S.lu.ns; S.st.lu_rounds = S.lu.nrounds;
   S.st.lu_nnz = 2 * S.lu.nnzU + S.lu.ns + (int64_t)S.lu.m * S.lu.m;
   S.st.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+  if (getenv("KIN_TIMING"))
+    fprintf(stderr, "[kin_solve] wall %.4f s, of which blocked in step syncs %.4f s (the rest is host-side enqueue)\n",
+            S.st.wall_seconds, S.sync_wait_s);
   if (stats) *stats = S.st;
   return retcode;
 }
