@@ -106,6 +106,7 @@ struct Solver {
   }
 
   double sync_wait_s = 0.0;   // host time spent blocked in sync_ctrl (diagnostic, KIN_TIMING=1)
+  int64_t iter_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // corrector iterations executed per converged attempt (diagnostic)
   void sync_ctrl() {
     KIN_HIP(hipMemcpyAsync(hc, ctrl.p, sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
     auto t0 = std::chrono::steady_clock::now();
@@ -267,6 +268,7 @@ struct Solver {
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
       }
+      iter_hist[std::min(hc->n_iter, 7)]++;
       safety = 0.9 * (2.0 * BDF_NEWTON_MAXITER + 1.0) / (2.0 * BDF_NEWTON_MAXITER + hc->n_iter);
       err_norm = hc->err_norm;
       if (err_norm > 1.0) {
@@ -415,6 +417,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   hipStream_t s = h->stream;
   S.st = kin_stats{};
   S.sync_wait_s = 0.0;
+  std::fill(S.iter_hist, S.iter_hist + 8, 0);
   S.ban_negatives = p.ban_negatives != 0;
   double abstol = p.abstol, reltol = p.reltol;
   S.set_tols(abstol, reltol);
@@ -604,6 +607,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   if (getenv("KIN_TIMING"))
     fprintf(stderr, "[kin_solve] wall %.4f s, of which blocked in step syncs %.4f s (the rest is host-side enqueue)\n",
             S.st.wall_seconds, S.sync_wait_s);
+  if (getenv("KIN_TIMING"))
+    fprintf(stderr, "[kin_solve] corrector iterations per converged attempt: 1:%lld 2:%lld 3:%lld 4:%lld\n", (long long)S.iter_hist[1],
+            (long long)S.iter_hist[2], (long long)S.iter_hist[3], (long long)S.iter_hist[4]);
   if (stats) *stats = S.st;
   return retcode;
 }
