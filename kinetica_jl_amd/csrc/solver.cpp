@@ -57,7 +57,7 @@ struct Solver {
   hipStream_t s;
   SparseLU lu;
   SegPlanDev resid_plan;                  // Newton residual written straight into the permuted solve vector
-  DevBuf<double> D, y, psi, d, scale, f0, f1, ytmp, jv, umax;
+  DevBuf<double> D, y, psi, d, scale, f0, f1, ytmp, jv, umax, red;
   DevBuf<BdfCtrl> ctrl;
   BdfCtrl* hc = nullptr;                  // pinned host mirror
   BdfCoef cf;
@@ -89,6 +89,8 @@ struct Solver {
     y.alloc(N); psi.alloc(N); d.alloc(N); scale.alloc(N); f0.alloc(N); f1.alloc(N); ytmp.alloc(N); umax.alloc(N);
     jv.alloc(H.nnz());
     ctrl.alloc(1);
+    red.alloc((size_t)5 * bdf_reduce_blocks(N));
+    KIN_HIP(hipMemsetAsync(ctrl.p, 0, sizeof(BdfCtrl), s));
     KIN_HIP(hipHostMalloc((void**)&hc, sizeof(BdfCtrl), hipHostMallocDefault));
     cf.gamma[0] = 0.0;
     for (int j = 1; j <= BDF_MAX_ORDER; j++) cf.gamma[j] = cf.gamma[j - 1] + 1.0 / j;
@@ -198,7 +200,7 @@ struct Solver {
     ex.psi = psi.p; ex.d = d.p; ex.cscal = c; ex.skip = skip;
     launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, lu.W.p, ex, s);
     lu.solve(skip, s);
-    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, lu.W.p, scale.p, y.p, d.p, ctrl.p, s);
+    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, lu.W.p, scale.p, y.p, d.p, ctrl.p, red.p, s);
     st.n_rhs++; st.n_linsolve++;
   }
 
@@ -237,23 +239,22 @@ struct Solver {
           lu_valid = true;
           st.n_factor++;
         }
-        launch_bdf_ctrl_reset(ctrl.p, s);
-        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, s);
+        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
         newton_iteration(0, c);
         newton_iteration(1, c);
-        launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, s);
+        launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, s);
         sync_ctrl();
         if (!hc->newton_done) {
           newton_iteration(2, c);
           newton_iteration(3, c);
-          launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, s);
+          launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, s);
           sync_ctrl();
         }
         converged = hc->newton_done && hc->converged && !hc->nonfinite;
         if (converged) break;
         st.n_newton_fail++;
         if (jac_current) break;
-        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, s);
+        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
         eval_jac(y.p);
         jac_current = true;
       }

@@ -254,8 +254,14 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
 __global__ __launch_bounds__(256) void bdf_predict_kernel(int N, int order, const double* __restrict__ D, BdfCoef cf,
                                                           double atol, double rtol, double* __restrict__ y,
                                                           double* __restrict__ psi, double* __restrict__ d,
-                                                          double* __restrict__ scale) {
+                                                          double* __restrict__ scale, BdfCtrl* ctrl) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // the predictor opens a corrector attempt: it also clears the attempt's control block (what a
+  // separate one-thread launch used to do)
+  if (i == 0) {
+    ctrl->newton_done = 0; ctrl->converged = 0; ctrl->n_iter = 0; ctrl->nonfinite = 0; ctrl->any_negative = 0; ctrl->ticket = 0;
+    ctrl->dy_norm_old = 0.0; ctrl->dy_norm = 0.0; ctrl->err_norm = 0.0; ctrl->err_m_norm = 0.0; ctrl->err_p_norm = 0.0;
+  }
   if (i >= N) return;
   double yp = D[i], ps = 0.0;
   for (int j = 1; j <= order; j++) {
@@ -269,56 +275,85 @@ __global__ __launch_bounds__(256) void bdf_predict_kernel(int N, int order, cons
   scale[i] = atol + rtol * fabs(yp);
 }
 
-// One Newton update, a single 1024-thread workgroup so that the norm, the convergence
-// decision and the update need no second launch.
-__global__ __launch_bounds__(1024) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
-                                                          const double* __restrict__ W, const double* __restrict__ scale,
-                                                          double* __restrict__ y, double* __restrict__ d, BdfCtrl* ctrl) {
-  __shared__ double sh[17];
+// Reductions over the state are spread over ceil(N / 1024) workgroups of 256 threads (four elements per
+// thread, all loads in flight): each workgroup stores its partial sums, the last one to arrive (ticket in
+// BdfCtrl) adds them in workgroup order - bitwise reproducible - and takes the decision. A single
+// 1024-thread workgroup walking the whole state took 17 us at N = 10k, most of it load latency.
+constexpr int RED_ELEMS = 1024;   // elements per workgroup
+
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// true in exactly one workgroup per launch: the one that arrives last, after every partial is visible
+__device__ __forceinline__ bool last_block_arrives(BdfCtrl* ctrl, int* flag) {
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int t = atomicAdd(&ctrl->ticket, 1);
+    *flag = (t == (int)gridDim.x - 1);
+    if (*flag) { ctrl->ticket = 0; __threadfence(); }
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+__device__ __forceinline__ double sum_partials(const double* part, int n) {
+  double t = 0.0;
+  for (int g = 0; g < n; g++) t += __hip_atomic_load(part + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past this CU's L1
+  return t;
+}
+
+// One Newton update: y += dy, d += dy, ||dy||, convergence decision. The update is applied
+// unconditionally: when the decision is "diverged" the attempt is abandoned and y, d are rebuilt by the
+// next predictor, so the stale update is never read.
+__global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
+                                                         const double* __restrict__ W, const double* __restrict__ scale,
+                                                         double* __restrict__ y, double* __restrict__ d, BdfCtrl* ctrl,
+                                                         double* __restrict__ part) {
+  __shared__ double sh[4];
+  __shared__ int last;
   if (ctrl->newton_done) return;
-  const double old = ctrl->dy_norm_old;   // read before any thread can reach the final write
+  const int G = gridDim.x;
   double s = 0.0;
   int bad = 0;
-  // four elements per trip with all (dependent) loads in flight: this kernel is pure latency
-  for (int i0 = threadIdx.x; i0 < N; i0 += 4096) {
-    int32_t xl[4]; double dy[4], sc[4];
+  {
+    const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
+    int32_t xl[4]; double dy[4], sc[4], yy[4], dd[4];
 #pragma unroll
-    for (int x = 0; x < 4; x++) { const int i = i0 + 1024 * x; xl[x] = i < N ? xloc[i] : -1; sc[x] = i < N ? scale[i] : 1.0; }
+    for (int x = 0; x < 4; x++) {
+      const int i = i0 + 256 * x;
+      xl[x] = i < N ? xloc[i] : -1; sc[x] = i < N ? scale[i] : 1.0;
+      yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
+    }
 #pragma unroll
     for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? W[xl[x]] : 0.0;
 #pragma unroll
     for (int x = 0; x < 4; x++) {
+      const int i = i0 + 256 * x;
       if (!isfinite(dy[x])) bad = 1;
       const double q = dy[x] / sc[x];
       s += q * q;
+      if (i < N) { y[i] = yy[x] + dy[x]; d[i] = dd[x] + dy[x]; }
     }
   }
-  const double tot = block_sum_1024(s, sh);
-  const double nbad = block_sum_1024((double)bad, sh);
-  const double dy_norm = sqrt(tot / (double)N);
-  const bool have_rate = iter > 0;
-  const double rate = have_rate ? dy_norm / old : 0.0;
-  bool diverged = (nbad > 0.0) || !isfinite(dy_norm);
-  if (!diverged && have_rate && (rate >= 1.0 || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
-  if (!diverged) {
-    for (int i0 = threadIdx.x; i0 < N; i0 += 4096) {
-      int32_t xl[4]; double dy[4], yy[4], dd[4];
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        const int i = i0 + 1024 * x;
-        xl[x] = i < N ? xloc[i] : -1;
-        yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? W[xl[x]] : 0.0;
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        const int i = i0 + 1024 * x;
-        if (i < N) { y[i] = yy[x] + dy[x]; d[i] = dd[x] + dy[x]; }
-      }
-    }
-  }
+  const double ps = block_sum_256(s, sh);
+  const double pb = block_sum_256((double)bad, sh);
+  if (threadIdx.x == 0) { part[blockIdx.x] = ps; part[G + blockIdx.x] = pb; }
+  if (!last_block_arrives(ctrl, &last)) return;
   if (threadIdx.x == 0) {
+    const double tot = sum_partials(part, G), nbad = sum_partials(part + G, G);
+    const double old = ctrl->dy_norm_old;
+    const double dy_norm = sqrt(tot / (double)N);
+    const bool have_rate = iter > 0;
+    const double rate = have_rate ? dy_norm / old : 0.0;
+    bool diverged = (nbad > 0.0) || !isfinite(dy_norm);
+    if (!diverged && have_rate && (rate >= 1.0 || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
     ctrl->n_iter = iter + 1;
     ctrl->dy_norm = dy_norm;
     if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nbad > 0.0; }
@@ -332,36 +367,51 @@ __global__ __launch_bounds__(1024) void bdf_newton_kernel(int N, int iter, int m
   }
 }
 
-// local error estimate of the step and the estimates one order down / up (all three before
-// the differences are updated: D_new[order] = D[order] + d, D_new[order+2] = d - D[order+1])
-__global__ __launch_bounds__(1024) void bdf_error_kernel(int N, int order, const double* __restrict__ D, const double* __restrict__ y,
-                                                         const double* __restrict__ d, double atol, double rtol, BdfCoef cf,
-                                                         BdfCtrl* ctrl) {
-  __shared__ double sh[17];
+__global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const double* __restrict__ D, const double* __restrict__ y,
+                                                        const double* __restrict__ d, double atol, double rtol, BdfCoef cf,
+                                                        BdfCtrl* ctrl, double* __restrict__ part) {
+  __shared__ double sh[4];
+  __shared__ int last;
   if (!ctrl->newton_done || !ctrl->converged) return;
+  const int G = gridDim.x;
   double se = 0.0, sm = 0.0, sp = 0.0;
   int neg = 0, bad = 0;
-  for (int i = threadIdx.x; i < N; i += 1024) {
-    const double yi = y[i], di = d[i];
-    if (yi < 0.0) neg = 1;
-    if (!isfinite(yi)) bad = 1;
-    const double sc = atol + rtol * fabs(yi);
-    const double e = cf.error_const[order] * di / sc;
-    se += e * e;
-    if (order > 1) { const double em = cf.error_const[order - 1] * (D[(size_t)order * N + i] + di) / sc; sm += em * em; }
-    if (order < 5) { const double ep = cf.error_const[order + 1] * (di - D[(size_t)(order + 1) * N + i]) / sc; sp += ep * ep; }
+  {
+    const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
+    double yi[4], di[4], dm[4], dp[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      const int i = i0 + 256 * x;
+      const bool ok = i < N;
+      yi[x] = ok ? y[i] : 0.0; di[x] = ok ? d[i] : 0.0;
+      dm[x] = (ok && order > 1) ? D[(size_t)order * N + i] : 0.0;
+      dp[x] = (ok && order < 5) ? D[(size_t)(order + 1) * N + i] : 0.0;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      if (i0 + 256 * x >= N) continue;
+      if (yi[x] < 0.0) neg = 1;
+      if (!isfinite(yi[x])) bad = 1;
+      const double sc = atol + rtol * fabs(yi[x]);
+      const double e = cf.error_const[order] * di[x] / sc;
+      se += e * e;
+      if (order > 1) { const double em = cf.error_const[order - 1] * (dm[x] + di[x]) / sc; sm += em * em; }
+      if (order < 5) { const double ep = cf.error_const[order + 1] * (di[x] - dp[x]) / sc; sp += ep * ep; }
+    }
   }
-  const double te = block_sum_1024(se, sh);
-  const double tm = block_sum_1024(sm, sh);
-  const double tp = block_sum_1024(sp, sh);
-  const double tn = block_sum_1024((double)neg, sh);
-  const double tb = block_sum_1024((double)bad, sh);
+  const double pe = block_sum_256(se, sh), pm = block_sum_256(sm, sh), pp = block_sum_256(sp, sh);
+  const double pn = block_sum_256((double)neg, sh), pb = block_sum_256((double)bad, sh);
   if (threadIdx.x == 0) {
-    ctrl->err_norm = sqrt(te / (double)N);
-    ctrl->err_m_norm = sqrt(tm / (double)N);
-    ctrl->err_p_norm = sqrt(tp / (double)N);
-    ctrl->any_negative = tn > 0.0;
-    if (tb > 0.0) ctrl->nonfinite = 1;
+    part[blockIdx.x] = pe; part[G + blockIdx.x] = pm; part[2 * G + blockIdx.x] = pp;
+    part[3 * G + blockIdx.x] = pn; part[4 * G + blockIdx.x] = pb;
+  }
+  if (!last_block_arrives(ctrl, &last)) return;
+  if (threadIdx.x == 0) {
+    ctrl->err_norm = sqrt(sum_partials(part, G) / (double)N);
+    ctrl->err_m_norm = sqrt(sum_partials(part + G, G) / (double)N);
+    ctrl->err_p_norm = sqrt(sum_partials(part + 2 * G, G) / (double)N);
+    ctrl->any_negative = sum_partials(part + 3 * G, G) > 0.0;
+    if (sum_partials(part + 4 * G, G) > 0.0) ctrl->nonfinite = 1;
   }
 }
 
@@ -440,11 +490,6 @@ __global__ __launch_bounds__(1024) void bdf_norms_kernel(int N, const double* __
   }
 }
 
-__global__ void bdf_ctrl_reset_kernel(BdfCtrl* ctrl) {
-  ctrl->newton_done = 0; ctrl->converged = 0; ctrl->n_iter = 0; ctrl->nonfinite = 0; ctrl->any_negative = 0;
-  ctrl->dy_norm_old = 0.0; ctrl->dy_norm = 0.0; ctrl->err_norm = 0.0; ctrl->err_m_norm = 0.0; ctrl->err_p_norm = 0.0;
-}
-
 // per-species running maximum over saved states (identify_next_seeds' reduction)
 __global__ __launch_bounds__(256) void colmax_kernel(int N, long long M, const double* __restrict__ U, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -470,16 +515,17 @@ __global__ __launch_bounds__(256) void rates_skip_kernel(int R, const double* __
 #define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
-                        double* d, double* scale, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_predict_kernel, GRID1(N), 0, s, N, order, D, cf, atol, rtol, y, psi, d, scale);
+                        double* d, double* scale, BdfCtrl* ctrl, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_predict_kernel, GRID1(N), 0, s, N, order, D, cf, atol, rtol, y, psi, d, scale, ctrl);
 }
+int bdf_reduce_blocks(int N) { return (int)ceil_div(N, RED_ELEMS); }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, BdfCtrl* ctrl, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_newton_kernel, dim3(1), dim3(1024), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, ctrl);
+                       double* y, double* d, BdfCtrl* ctrl, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, ctrl, part);
 }
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
-                      const BdfCoef& cf, BdfCtrl* ctrl, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_error_kernel, dim3(1), dim3(1024), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl);
+                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl, part);
 }
 void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s) {
   hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d);
@@ -499,7 +545,6 @@ void launch_axpy_out(int N, const double* a, double sc, const double* b, double*
 void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s) {
   hipLaunchKernelGGL(bdf_norms_kernel, dim3(1), dim3(1024), 0, s, N, y0, f0, f1, atol, rtol, ctrl);
 }
-void launch_bdf_ctrl_reset(BdfCtrl* ctrl, hipStream_t s) { hipLaunchKernelGGL(bdf_ctrl_reset_kernel, dim3(1), dim3(1), 0, s, ctrl); }
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s) {
   hipLaunchKernelGGL(colmax_kernel, GRID1(N), 0, s, N, (long long)M, U, out);
 }

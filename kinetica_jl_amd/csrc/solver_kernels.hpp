@@ -21,22 +21,24 @@ struct BdfCtrl {
   double dy_norm_old, dy_norm;
   double err_norm, err_m_norm, err_p_norm;
   double scratch[3];
-  int newton_done, converged, n_iter, nonfinite, any_negative, pad;
+  int newton_done, converged, n_iter, nonfinite, any_negative;
+  int ticket;   // arrival counter of the multi-workgroup reductions (back to 0 when a launch ends)
 };
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
-                        double* d, double* scale, hipStream_t s);
+                        double* d, double* scale, BdfCtrl* ctrl, hipStream_t s);   // also clears *ctrl
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, BdfCtrl* ctrl, hipStream_t s);
+                       double* y, double* d, BdfCtrl* ctrl, double* part, hipStream_t s);
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
-                      const BdfCoef& cf, BdfCtrl* ctrl, hipStream_t s);
+                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, hipStream_t s);
+// `part`: 5 * bdf_reduce_blocks(N) doubles of partial sums shared by the two reductions above
+int bdf_reduce_blocks(int N);
 void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s);
 void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s);
 void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, double h, double* D, hipStream_t s);
 void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s);
 void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s);
 void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s);
-void launch_bdf_ctrl_reset(BdfCtrl* ctrl, hipStream_t s);
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s);
 void launch_rates_skip(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate,
                        const int* skip, hipStream_t s);
