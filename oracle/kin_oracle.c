@@ -49,6 +49,18 @@ void orc_rhs(int64_t n, int64_t nr,
   }
 }
 
+/* B independent states at once (state-major u[b][n], k[b][nr] or one shared k when k_stride == 0):
+ * the ensemble form of the same evaluation, one state per OpenMP thread. Only bench.py's all-core
+ * CPU baseline uses it (the reference's solve path itself is single-threaded). */
+void orc_rhs_many(int64_t n, int64_t nr,
+                  const int64_t* reac_ptr, const int64_t* reac_idx, const int64_t* reac_sto,
+                  const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
+                  int64_t B, const double* k, int64_t k_stride, const double* u, double* du) {
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < B; b++)
+    orc_rhs(n, nr, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto, k + b * k_stride, u + b * n, du + b * n);
+}
+
 /* Per-reaction rates only (used by tests of the rate kernel). */
 void orc_rates(int64_t nr, const int64_t* reac_ptr, const int64_t* reac_idx, const int64_t* reac_sto,
                const double* k, const double* u, double* rate) {

@@ -83,6 +83,16 @@ class OracleNetwork:
         _lib().orc_rhs(ctypes.c_int64(self.n), ctypes.c_int64(self.nr), *self._topo(), _pf(k), _pf(u), _pf(du))
         return du
 
+    def rhs_many(self, k, U):
+        """B states at once, one per OpenMP thread (k: [nr] shared or [B][nr]); the all-core CPU baseline."""
+        U = _c(U, np.float64)
+        k = _c(k, np.float64)
+        B = U.shape[0]
+        DU = np.empty_like(U)
+        _lib().orc_rhs_many(ctypes.c_int64(self.n), ctypes.c_int64(self.nr), *self._topo(), ctypes.c_int64(B), _pf(k),
+                            ctypes.c_int64(self.nr if k.ndim == 2 else 0), _pf(U), _pf(DU))
+        return DU
+
     def rates(self, k, u):
         k, u = _c(k, np.float64), _c(u, np.float64)
         out = np.empty(self.nr)

@@ -191,3 +191,17 @@ def test_synthetic_crn_is_seeded_and_valid():
     # detailed balance before the cap: k_f / k_r = exp(-dG / RT) with a common prefactor
     assert np.array_equal(A1[0::2], A1[1::2]) and np.all(np.minimum(Ea1[0::2], Ea1[1::2]) >= 0)
     assert np.all((Ea1[0::2] == 0) | (Ea1[1::2] == 0) | (np.minimum(Ea1[0::2], Ea1[1::2]) > 0))
+
+
+def test_ensemble_rhs_equals_single_state_rhs():
+    """orc_rhs_many (OpenMP over states, bench.py's all-core CPU baseline) = orc_rhs state by state."""
+    from kinetica_jl_amd.synth import synthetic_crn
+    net, Ea, A = synthetic_crn(200, 1000, seed=2)
+    on = orc.OracleNetwork.from_flat(net)
+    k = orc.arrhenius(Ea, A, 900.0, k_max=1e12)
+    rng = np.random.default_rng(3)
+    U = 10.0 ** rng.uniform(-12, 0, (17, 200))
+    K = k[None, :] * rng.uniform(0.5, 2.0, (17, 1))
+    for kk, D in ((k, on.rhs_many(k, U)), (K, on.rhs_many(K, U))):
+        for b in range(17):
+            assert np.array_equal(D[b], on.rhs(kk if kk.ndim == 1 else kk[b], U[b]))
