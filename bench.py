@@ -199,12 +199,12 @@ def main():
                                          f"(scalar C, -O2) in {dt:.1f} s"}
         # the same evaluation over an ensemble of states, one state per OpenMP thread (every host core the
         # process may use): what the CPU can do for the batched sweep; the reference itself is single-threaded
-        cores = len(os.sched_getaffinity(0))
+        cores = orc.usable_cores()
         Ub = 10.0 ** np.random.default_rng(1).uniform(-12, 0, (8 * cores, N))
-        on.rhs_many(k1000, Ub)
+        on.rhs_many(k1000, Ub, cores)
         n_eval, t1 = 0, time.perf_counter()
         while time.perf_counter() - t1 < 5.0:
-            on.rhs_many(k1000, Ub)
+            on.rhs_many(k1000, Ub, cores)
             n_eval += Ub.shape[0]
         dt = time.perf_counter() - t1
         out["cpu_baseline_all_cores"] = {"value": n_eval / dt, "unit": "RHS evals/s", "cores": cores, "kind": "port",

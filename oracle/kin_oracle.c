@@ -55,8 +55,8 @@ void orc_rhs(int64_t n, int64_t nr,
 void orc_rhs_many(int64_t n, int64_t nr,
                   const int64_t* reac_ptr, const int64_t* reac_idx, const int64_t* reac_sto,
                   const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
-                  int64_t B, const double* k, int64_t k_stride, const double* u, double* du) {
-#pragma omp parallel for schedule(static)
+                  int64_t B, const double* k, int64_t k_stride, const double* u, double* du, int n_threads) {
+#pragma omp parallel for schedule(static) num_threads(n_threads)
   for (int64_t b = 0; b < B; b++)
     orc_rhs(n, nr, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto, k + b * k_stride, u + b * n, du + b * n);
 }

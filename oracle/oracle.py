@@ -59,6 +59,24 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    for quota_f, period_f in (("/sys/fs/cgroup/cpu.max", None),
+                              ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_f is None:
+                quota, period = open(quota_f).read().split()
+            else:
+                quota, period = open(quota_f).read().strip(), open(period_f).read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(-(-int(quota) // int(period)))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 class OracleNetwork:
     """Flat CRN topology (RxData's four ragged vectors, src/exploration/network.jl:193-203)."""
 
@@ -83,14 +101,15 @@ class OracleNetwork:
         _lib().orc_rhs(ctypes.c_int64(self.n), ctypes.c_int64(self.nr), *self._topo(), _pf(k), _pf(u), _pf(du))
         return du
 
-    def rhs_many(self, k, U):
+    def rhs_many(self, k, U, n_threads=None):
         """B states at once, one per OpenMP thread (k: [nr] shared or [B][nr]); the all-core CPU baseline."""
+        n_threads = int(n_threads or usable_cores())
         U = _c(U, np.float64)
         k = _c(k, np.float64)
         B = U.shape[0]
         DU = np.empty_like(U)
         _lib().orc_rhs_many(ctypes.c_int64(self.n), ctypes.c_int64(self.nr), *self._topo(), ctypes.c_int64(B), _pf(k),
-                            ctypes.c_int64(self.nr if k.ndim == 2 else 0), _pf(U), _pf(DU))
+                            ctypes.c_int64(self.nr if k.ndim == 2 else 0), _pf(U), _pf(DU), ctypes.c_int(n_threads))
         return DU
 
     def rates(self, k, u):
