@@ -413,33 +413,24 @@ __global__ __launch_bounds__(1024) void sweep_lds_kernel(int N, int R, int P, in
 }
 
 // ------------------------------------------------------------------------------------------
-// Register-resident variant (adjacent pairs, N < 16383, state fits LDS): the reaction records a
-// thread works on are the same for every state, so they are loaded ONCE into registers (64-bit
-// packing: 4 x 14-bit species slots + 4 x 2-bit stoichiometry codes) and the only per-state
-// global traffic left is the algorithmic one: k[b] streamed as double2, u[b] in, du[b] out.
-// T = records per thread (compile time, fully unrolled so the record array stays in VGPRs).
+// Register-resident variant (adjacent pairs, state fits LDS): the reaction records a thread works on
+// are the same for every state, so they are loaded ONCE into registers and the only per-state global
+// traffic left is the algorithmic one: k[b] streamed as double2, u[b] in, du[b] out.
+// Record = four 14-bit species labels with fixed roles (fields 0, 1: reactant instances of the forward
+// reaction, fields 2, 3: its product instances; network.cpp) - no coefficients, no side flags, no
+// branches: SQ counters of the previous format (2-bit codes per slot, empty-slot tests) showed ~100
+// VALU + ~50 SALU instructions per record and the VALU 47 % busy next to a 54 % busy LDS. Unused fields
+// point at a per-lane dummy entry (u = 1, du discarded) behind the N real ones.
 // ------------------------------------------------------------------------------------------
-// one packed record: decode, 4 LDS reads, net rate, <= 4 LDS atomics
+constexpr int SWEEP_DUMMY = 64;   // dummy entries behind u_s / du_s, one per lane
 __device__ __forceinline__ void sweep_apply(uint2 w, double2 kk, const double* u_s, double* du_s) {
-  const uint32_t sl[4] = {w.x & 0x3fffu, (w.x >> 14) & 0x3fffu, (w.x >> 28) | ((w.y & 0x3ffu) << 4), (w.y >> 10) & 0x3fffu};
-  const uint32_t codes = w.y >> 24;
-  double uf = 1.0, ur = 1.0;
-  int cf[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int c2 = (codes >> (2 * j)) & 3;            // 0,1,2,3 -> -2,-1,+1,+2
-    cf[j] = c2 < 2 ? c2 - 2 : c2 - 1;
-    if (sl[j] != 0x3fffu) {
-      const double v = u_s[sl[j]];
-      const double v2 = (c2 == 0 || c2 == 3) ? v * v : v;
-      if (c2 < 2) uf *= v2; else ur *= v2;
-    }
-  }
+  const uint32_t l0 = w.x & 0x3fffu, l1 = (w.x >> 14) & 0x3fffu, l2 = (w.x >> 28) | ((w.y & 0x3ffu) << 4), l3 = (w.y >> 10) & 0x3fffu;
+  const double uf = u_s[l0] * u_s[l1], ur = u_s[l2] * u_s[l3];
   const double net = kk.x * uf - kk.y * ur;
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-    if (sl[j] != 0x3fffu)
-      __hip_atomic_fetch_add(du_s + sl[j], (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(du_s + l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(du_s + l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(du_s + l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(du_s + l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // TR = records per thread kept in registers (compile time, fully unrolled); records beyond
@@ -454,7 +445,11 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   double* u_s = lds + tile;
   const int tid = threadIdx.x;
   constexpr int UPT = 5;            // double2 per thread of the staged state (N <= 10240)
-  constexpr uint2 EMPTY = {0xffffffffu, 0x00ffffffu};
+  // padding record of this lane: all four fields on the lane's dummy entry
+  const uint64_t dl = (uint64_t)N + (uint64_t)(tid & 63);
+  const uint64_t ew = dl | (dl << 14) | (dl << 28) | (dl << 42);
+  const uint2 EMPTY = {(uint32_t)ew, (uint32_t)(ew >> 32)};
+  if (tid < SWEEP_DUMMY) { u_s[N + tid] = 1.0; du_s[N + tid] = 0.0; }
   uint2 rc[TR > 0 ? TR : 1];
 #pragma unroll
   for (int i = 0; i < TR; i++) {
@@ -781,9 +776,13 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, con
     const size_t smem = (size_t)(tile + N) * 8;
     static int use_reg = -1;
     if (use_reg < 0) { const char* e = getenv("KIN_SWEEP_REG"); use_reg = e ? atoi(e) : 8; }
-    if (adj && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 && N <= 10240) {
+    // register-resident path: both LDS arrays carry SWEEP_DUMMY extra entries (per-lane dummy species)
+    if (adj && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 &&
+        (size_t)(2 * (N + SWEEP_DUMMY)) * 8 <= lds_max) {
       const int64_t T = P / 1024;   // full record rows available for residency
-#define KIN_REG_GO(TT, II) launch_sweep_reg_t<TT, II>(grid, smem, (int)N, (int)R, (int)P, (int)B, tile, rec64, u, k_b, k_1, du, s)
+      const int rtile = (int)N + SWEEP_DUMMY;
+      const size_t rsmem = (size_t)2 * rtile * 8;
+#define KIN_REG_GO(TT, II) launch_sweep_reg_t<TT, II>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, u, k_b, k_1, du, s)
       const int want = (int)std::min<int64_t>(use_reg, T);
       if (want >= 16) KIN_REG_GO(16, 4);
       else if (want >= 12) KIN_REG_GO(12, 4);

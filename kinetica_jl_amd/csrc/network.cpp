@@ -199,23 +199,33 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
     H.pairs_adjacent = (R % 2 == 0) && (H.n_pairs() * 2 == R);
     for (int64_t p = 0; p < H.n_pairs() && H.pairs_adjacent; p++)
       if (H.pair_k[2 * p] != 2 * p || H.pair_k[2 * p + 1] != 2 * p + 1) H.pairs_adjacent = false;
-    if (H.pairs_adjacent && N < 16383) {
+    // 64-bit records of the register-resident sweep (kernels.hip: sweep_reg_kernel): four 14-bit species
+    // labels with FIXED roles - fields 0, 1 = the forward reaction's reactant instances, fields 2, 3 = its
+    // product instances (2A is listed as A, A) - so the kernel needs no coefficient or side decoding at
+    // all: net = kf u0 u1 - kr u2 u3, du[0,1] -= net, du[2,3] += net. An unused field points at a per-lane
+    // dummy entry N + (record index mod 64) whose u is 1.0 and whose du is never written out.
+    if (H.pairs_adjacent && N + 64 <= 16384) {
       bool ok = true;
       for (int64_t p = 0; p < H.n_pairs() && ok; p++) {
-        uint64_t w = 0;
-        uint32_t codes = 0;
         const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1], co = H.pair_rec[4 * p + 2];
         const uint32_t sl[4] = {s01 & 0xffffu, s01 >> 16, s23 & 0xffffu, s23 >> 16};
-        for (int j = 0; j < 4; j++) {
+        uint64_t side[2][2];
+        int cnt[2] = {0, 0};
+        for (int j = 0; j < 4 && ok; j++) {
+          if (sl[j] == 0xffffu) continue;
           const int c = (int)(int8_t)(co >> (8 * j));
-          const uint64_t sp = sl[j] == 0xffffu ? 0x3fffu : sl[j];
-          w |= sp << (14 * j);
-          if (sl[j] != 0xffffu) {
-            if (c < -2 || c > 2 || c == 0) { ok = false; break; }
-            codes |= (uint32_t)(c < 0 ? c + 2 : c + 1) << (2 * j);
+          if (c == 0 || c < -2 || c > 2) { ok = false; break; }
+          const int sd = c < 0 ? 0 : 1;
+          for (int q = 0; q < (c < 0 ? -c : c); q++) {
+            if (cnt[sd] >= 2) { ok = false; break; }
+            side[sd][cnt[sd]++] = sl[j];
           }
         }
-        w |= (uint64_t)codes << 56;
+        if (!ok) break;
+        const uint64_t dummy = (uint64_t)N + (uint64_t)(p & 63);
+        for (int sd = 0; sd < 2; sd++)
+          while (cnt[sd] < 2) side[sd][cnt[sd]++] = dummy;
+        const uint64_t w = side[0][0] | (side[0][1] << 14) | (side[1][0] << 28) | (side[1][1] << 42);
         H.pair_rec64.push_back((uint32_t)w);
         H.pair_rec64.push_back((uint32_t)(w >> 32));
       }

@@ -64,7 +64,7 @@ struct NetworkHost {
   // pair_k[2p+1]'s companion word pair_ops (explicit operands).
   std::vector<uint32_t> pair_rec;  // 4 words per record: s01, s23, coefs, ops (explicit operands for unpaired records)
   std::vector<int32_t> pair_k;     // 2 per record: kf, kr
-  std::vector<uint32_t> pair_rec64; // 2 words per record (14-bit slots + 2-bit codes); only when N < 16383 and pairs_adjacent
+  std::vector<uint32_t> pair_rec64; // 2 words per record (four 14-bit labels with fixed roles, network.cpp); only when pairs_adjacent
   // Large-N sweep (state does not fit LDS): species are relabelled so that the `big_H` most
   // frequently referenced ones ("hubs") come first (each group kept in species-id order); records
   // carry labels. Hubs keep u and du in LDS; tail rates are gathered per tile of 2 * big_H labels from
