@@ -22,7 +22,8 @@ void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, dou
   if (host.big_H > 0) {
     big_scratch.alloc((size_t)launch_sweep_big_grid(B) * (size_t)(host.N - host.big_H + host.n_pairs()));
     launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, (int32_t)host.big_tail_ptr.size() - 1,
-                     big_rec.p, sweep_k.p, big_spec.p, big_tptr.p, big_tent.p, big_scratch.p, d_u, d_k, k.p, d_du, s);
+                     big_rec8.p, big_rec.p, big_expl.p, (int32_t)host.big_expl.size(), sweep_k.p, big_spec.p, big_tptr.p, big_tent.p,
+                     big_scratch.p, d_u, d_k, k.p, d_du, s);
   } else
     launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, sweep_rec.p, sweep_k.p,
                  host.pair_rec64.empty() ? nullptr : sweep_rec64.p, d_u, d_k, k.p, d_du, s);
@@ -88,7 +89,8 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     if (N.N < 65535) { h->sweep_rec.upload(N.pair_rec, s); h->sweep_k.upload(N.pair_k, s); }
     if (!N.pair_rec64.empty()) h->sweep_rec64.upload(N.pair_rec64, s);
     if (N.big_H > 0) {
-      h->big_rec.upload(N.big_rec, s); h->big_spec.upload(N.big_spec_of_label, s);
+      h->big_rec.upload(N.big_rec, s); h->big_rec8.upload(N.big_rec8, s); h->big_expl.upload(N.big_expl, s);
+      h->big_spec.upload(N.big_spec_of_label, s);
       h->big_tptr.upload(N.big_tail_ptr, s); h->big_tent.upload(N.big_tail_ent, s);
     }
     h->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);

@@ -561,35 +561,39 @@ static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B
 // u and du in LDS exactly as above. Per state, one workgroup
 //   1. gathers u into label order: hubs -> LDS, tail -> its private global scratch row `ut`
 //      (written and read by the same CU: served by L2 / Infinity Cache, not HBM);
-//   2. streams the records (16 B, shared by all states) and the state's k (coalesced double2) once,
-//      accumulates the hubs' du with LDS atomics and stores every record's net rate to its private
-//      `netbuf` row (coalesced 8 B/lane);
+//   2. streams the records and the state's k (coalesced double2) once, accumulates the hubs' du with
+//      LDS atomics and stores every record's net rate to its private `netbuf` row (coalesced 8 B/lane).
+//      Records are 8 bytes: four 16-bit labels with fixed roles (fields 0, 1 reactant instances of the
+//      forward reaction, fields 2, 3 its product instances) - no coefficient decoding, as in
+//      sweep_reg_kernel; labels [H, H + 64) are per-lane dummy entries in LDS (u = 1, du discarded),
+//      tail labels start at H + 64. Reactions with a species on both sides (rare) take a slow path;
 //   3. writes the hubs' du out, then re-uses the whole LDS as accumulator for the tail, tile by tile:
 //      a precomputed list of (record, local label, coefficient) entries per tail tile, sorted by
 //      record, gathers coef * netbuf[record] into LDS; the tile is then written out.
 // (FP64 L2 atomics for the tail were measured first: 80 M global_atomic_add_f64 per launch cost
 // 1.3 ms of 2.5 ms.) HBM traffic per state is the algorithmic one: k[b][:] + u[b][:] in, du[b][:] out.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double big_u(uint32_t label, int H, const double* u_s, const double* __restrict__ ut) {
-  return (int)label < H ? u_s[label] : ut[(int)label - H];
-}
-
 template <bool ADJ>
 __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, int B, int H, int n_tail_tiles,
-                                                         const SweepRec* __restrict__ rec, const int2* __restrict__ pair_k,
+                                                         const uint2* __restrict__ rec8, const SweepRec* __restrict__ rec,
+                                                         const int32_t* __restrict__ expl, int n_expl,
+                                                         const int2* __restrict__ pair_k,
                                                          const int32_t* __restrict__ spec_of_label,
                                                          const int32_t* __restrict__ tail_ptr, const uint2* __restrict__ tail_ent,
                                                          double* __restrict__ scratch, const double* __restrict__ u,
                                                          const double* __restrict__ k_b, const double* __restrict__ k_1,
                                                          double* __restrict__ du) {
   extern __shared__ double lds[];
+  const int HL = H + SWEEP_DUMMY;            // LDS entries per array: hubs + per-lane dummies
   double* du_s = lds;
-  double* u_s = lds + H;
+  double* u_s = lds + HL;
   const int tid = threadIdx.x;
   const int NT = N - H, TT = 2 * H;
   double* ut = scratch + (size_t)blockIdx.x * ((size_t)NT + P);
   double* netbuf = ut + NT;
   constexpr int ILP = 4, PERM_ILP = 8;
+  const uint32_t dl = (uint32_t)(H + (tid & 63));
+  const uint2 EMPTY = {dl | (dl << 16), dl | (dl << 16)};
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const double* ub = u + (size_t)b * N;
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
@@ -609,16 +613,17 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
         else if (l < N) ut[l - H] = v[x];
       }
     }
+    if (tid < SWEEP_DUMMY) { u_s[H + tid] = 1.0; du_s[H + tid] = 0.0; }
     __syncthreads();   // workgroup-scope release/acquire: the scratch row is visible to every wave of this CU
     // 2. record stream
     for (int qq = tid; qq < P; qq += 1024 * ILP) {
-      SweepRec q[ILP];
+      uint2 w[ILP];
       double kf[ILP], kr[ILP];
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
         const int p = qq + x * 1024;
         if (p < P) {
-          q[x] = rec[p];
+          w[x] = rec8[p];
           if (ADJ) {
             const double2 kk = *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
             kf[x] = kk.x; kr[x] = kk.y;
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
             kf[x] = kb[kk.x]; kr[x] = kk.y >= 0 ? kb[kk.y] : 0.0;
           }
         } else {
-          q[x] = SweepRec{0xffffffffu, 0xffffffffu, 0, 0xffffffffu};
+          w[x] = EMPTY;
           kf[x] = kr[x] = 0.0;
         }
       }
@@ -636,39 +641,39 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
       double uv[ILP][4];
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        sl[x][0] = q[x].s01 & 0xffffu; sl[x][1] = q[x].s01 >> 16; sl[x][2] = q[x].s23 & 0xffffu; sl[x][3] = q[x].s23 >> 16;
+        sl[x][0] = w[x].x & 0xffffu; sl[x][1] = w[x].x >> 16; sl[x][2] = w[x].y & 0xffffu; sl[x][3] = w[x].y >> 16;
 #pragma unroll
-        for (int j = 0; j < 4; j++) uv[x][j] = sl[x][j] != 0xffffu ? big_u(sl[x][j], H, u_s, ut) : 1.0;
+        for (int j = 0; j < 4; j++) uv[x][j] = (int)sl[x][j] < HL ? u_s[sl[x][j]] : ut[(int)sl[x][j] - HL];
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        int cf[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) cf[j] = (int)(int8_t)((uint32_t)q[x].coef >> (8 * j));
-        double net;
-        if (q[x].ops == 0xffffffffu) {
-          double uf = 1.0, ur = 1.0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (sl[x][j] != 0xffffu) {
-              const double v = uv[x][j];
-              const double v2 = (cf[j] == 2 || cf[j] == -2) ? v * v : v;
-              if (cf[j] < 0) uf *= v2; else ur *= v2;
-            }
-          }
-          net = kf[x] * uf - kr[x] * ur;
-        } else {   // explicit operands (a species on both sides of the reaction)
-          const uint32_t a = q[x].ops & 0xffffu, c = q[x].ops >> 16;
-          net = kf[x] * big_u(a, H, u_s, ut);
-          if (c != 0xffffu) net *= big_u(c, H, u_s, ut);
-        }
+        const double net = kf[x] * (uv[x][0] * uv[x][1]) - kr[x] * (uv[x][2] * uv[x][3]);
         const int p = qq + x * 1024;
         if (p < P) netbuf[p] = net;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int lb = (int)sl[x][j];
-          if (lb < H) __hip_atomic_fetch_add(du_s + lb, (double)cf[j] * net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        for (int j = 0; j < 4; j++)
+          if ((int)sl[x][j] < HL)
+            __hip_atomic_fetch_add(du_s + sl[x][j], j < 2 ? -net : net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    // 2b. reactions with a species on both sides (all-dummy in rec8): net = kf u[a] u[c], coefficients from
+    // the 16-byte record; operands gathered straight from the state
+    if (n_expl > 0) {
+      __syncthreads();   // their netbuf entries were written (with a meaningless value) by the stream above
+      for (int i = tid; i < n_expl; i += 1024) {
+        const int p = expl[i];
+        const SweepRec q = rec[p];
+        const double kf = ADJ ? kb[2 * (size_t)p] : kb[pair_k[p].x];
+        const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
+        double net = kf * ((int)a < H ? u_s[a] : ut[(int)a - H]);
+        if (c != 0xffffu) net *= ((int)c < H ? u_s[c] : ut[(int)c - H]);
+        netbuf[p] = net;
+        const uint32_t sl[4] = {q.s01 & 0xffffu, q.s01 >> 16, q.s23 & 0xffffu, q.s23 >> 16};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((int)sl[j] < H)
+            __hip_atomic_fetch_add(du_s + sl[j], (double)(int)(int8_t)((uint32_t)q.coef >> (8 * j)) * net, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     __syncthreads();
@@ -720,28 +725,30 @@ int launch_sweep_big_grid(int64_t B) {
 }
 
 template <bool ADJ>
-static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tail_tiles, const void* rec, const void* pair_k,
-                               const int32_t* spec_of_label, const int32_t* tail_ptr, const void* tail_ent, double* scratch,
-                               const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tail_tiles, const void* rec8, const void* rec,
+                               const int32_t* expl, int n_expl, const void* pair_k, const int32_t* spec_of_label,
+                               const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
+                               const double* k_1, double* du, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     KIN_HIP(hipFuncSetAttribute((const void*)sweep_big_kernel<ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * H * 8, s, N, R, P, B, H, n_tail_tiles,
-                     (const SweepRec*)rec, (const int2*)pair_k, spec_of_label, tail_ptr, (const uint2*)tail_ent, scratch, u, k_b,
-                     k_1, du);
+  hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * (H + SWEEP_DUMMY) * 8, s, N, R, P, B, H,
+                     n_tail_tiles, (const uint2*)rec8, (const SweepRec*)rec, expl, n_expl, (const int2*)pair_k, spec_of_label,
+                     tail_ptr, (const uint2*)tail_ent, scratch, u, k_b, k_1, du);
 }
 
 // `scratch` holds launch_sweep_big_grid(B) rows of (N - H) + P doubles
-void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec,
-                      const void* pair_k, const int32_t* spec_of_label, const int32_t* tail_ptr, const void* tail_ent,
-                      double* scratch, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
+                      const void* rec, const int32_t* expl, int32_t n_expl, const void* pair_k, const int32_t* spec_of_label,
+                      const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
+                      const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
   const int grid = launch_sweep_big_grid(B);
   const bool adj = adjacent && ((((uintptr_t)(k_b ? k_b : k_1)) & 15) == 0);
-  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
-  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
+  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
+  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
   KIN_HIP(hipGetLastError());
 }
 

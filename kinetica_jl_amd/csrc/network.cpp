@@ -232,7 +232,7 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
       if (!ok) H.pair_rec64.clear();
     }
     // ---- large-N sweep tables (only when the state cannot live in LDS)
-    if ((size_t)N * 16 > 160 * 1024) {
+    if ((size_t)N * 16 > 160 * 1024 && N + 64 < 65535) {
       const int64_t P = H.n_pairs();
       const int32_t Hh = 10000;                       // hub species resident in LDS (2 x 80 kB)
       std::vector<int64_t> cnt(N, 0);
@@ -264,6 +264,27 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
         H.big_rec[4 * p + 1] = sl[2] | (sl[3] << 16);
         H.big_rec[4 * p + 2] = H.pair_rec[4 * p + 2];
         H.big_rec[4 * p + 3] = ops == 0xffffffffu ? ops : (relabel(ops & 0xffffu) | (relabel(ops >> 16) << 16));
+        // 8-byte stream record: four 16-bit labels with fixed roles (fields 0, 1 reactant instances of the
+        // forward reaction, 2, 3 its product instances); labels [Hh, Hh + 64) are the per-lane dummy entries,
+        // tail labels are shifted up by 64. Records with explicit operands are all-dummy here and listed in big_expl.
+        {
+          const uint32_t dummy = (uint32_t)Hh + (uint32_t)(p & 63);
+          uint32_t side[2][2] = {{dummy, dummy}, {dummy, dummy}};
+          int cnt[2] = {0, 0};
+          if (ops == 0xffffffffu) {
+            for (int j = 0; j < 4; j++) {
+              if (sl[j] == 0xffffu) continue;
+              const int c = (int)(int8_t)(H.pair_rec[4 * p + 2] >> (8 * j));
+              const int sd = c < 0 ? 0 : 1;
+              for (int q = 0; q < (c < 0 ? -c : c) && cnt[sd] < 2; q++)
+                side[sd][cnt[sd]++] = (int32_t)sl[j] < Hh ? sl[j] : sl[j] + 64u;
+            }
+          } else {
+            H.big_expl.push_back((int32_t)p);
+          }
+          H.big_rec8.push_back(side[0][0] | (side[0][1] << 16));
+          H.big_rec8.push_back(side[1][0] | (side[1][1] << 16));
+        }
         for (int j = 0; j < 4; j++) {
           if (sl[j] == 0xffffu || (int32_t)sl[j] < Hh) continue;
           const int32_t off = (int32_t)sl[j] - Hh;

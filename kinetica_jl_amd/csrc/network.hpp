@@ -71,7 +71,9 @@ struct NetworkHost {
   // `big_tail_ent` = (record, local label | coef << 24) pairs, sorted by record inside each tile.
   int32_t big_H = 0;
   std::vector<int32_t> big_spec_of_label;    // N
-  std::vector<uint32_t> big_rec;             // 4 words per record, slots = labels
+  std::vector<uint32_t> big_rec;             // 4 words per record, slots = labels (slow path of explicit-operand records)
+  std::vector<uint32_t> big_rec8;            // 2 words per record: the stream format (kernels.hip: sweep_big_kernel)
+  std::vector<int32_t> big_expl;             // records with explicit operands
   std::vector<int32_t> big_tail_ptr;         // tail tiles + 1 (entry offsets)
   std::vector<uint32_t> big_tail_ent;        // 2 words per entry
   bool pairs_adjacent = false;     // record p pairs reactions (2p, 2p+1): k streams as double2, no index load
