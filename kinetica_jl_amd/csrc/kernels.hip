@@ -437,7 +437,8 @@ __device__ __forceinline__ void sweep_apply(uint2 w, double2 kk, const double* u
 // TR*1024 are streamed as 8-byte words. ILP = records whose loads are issued together.
 template <int TR, int ILP>
 __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, int B, int tile,
-                                                         const uint2* __restrict__ rec64, const double* __restrict__ u,
+                                                         const uint2* __restrict__ rec64, const int32_t* __restrict__ copy_species,
+                                                         int n_copy, const double* __restrict__ u,
                                                          const double* __restrict__ k_b, const double* __restrict__ k_1,
                                                          double* __restrict__ du) {
   extern __shared__ double lds[];
@@ -450,6 +451,9 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   const uint64_t ew = dl | (dl << 14) | (dl << 28) | (dl << 42);
   const uint2 EMPTY = {(uint32_t)ew, (uint32_t)(ew >> 32)};
   if (tid < SWEEP_DUMMY) { u_s[N + tid] = 1.0; du_s[N + tid] = 0.0; }
+  // split accumulators of the most referenced species (network.cpp): entry N + 64 + tid mirrors species csp
+  const int csp = tid < n_copy ? copy_species[tid] : -1;
+  if (csp >= 0) du_s[N + SWEEP_DUMMY + tid] = 0.0;
   uint2 rc[TR > 0 ? TR : 1];
 #pragma unroll
   for (int i = 0; i < TR; i++) {
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
     un[x] = (b < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)b * N + i) : make_double2(0.0, 0.0);
   }
   for (int i = tid * 2; i < N; i += 2048) *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
+  double ucn = (csp >= 0 && b < B) ? u[(size_t)b * N + csp] : 0.0;
   // the first batch of rate constants of a state is requested before the previous state's barrier /
   // write-out / staging, so the k stream does not drain at state boundaries
   constexpr bool KPRE = TR >= ILP;
@@ -486,8 +491,10 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       const int i = (tid + x * 1024) * 2;
       if (i < N) *reinterpret_cast<double2*>(u_s + i) = un[x];
     }
+    if (csp >= 0) u_s[N + SWEEP_DUMMY + tid] = ucn;
     __syncthreads();
     const int bn = b + gridDim.x;
+    ucn = (csp >= 0 && bn < B) ? u[(size_t)bn * N + csp] : 0.0;
 #pragma unroll
     for (int x = 0; x < UPT; x++) {
       const int i = (tid + x * 1024) * 2;
@@ -535,6 +542,14 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       }
     }
     __syncthreads();
+    if (n_copy > 0) {   // fold the split accumulators back into their species
+      if (csp >= 0) {
+        const double v = du_s[N + SWEEP_DUMMY + tid];
+        du_s[N + SWEEP_DUMMY + tid] = 0.0;
+        __hip_atomic_fetch_add(du_s + csp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
+    }
     for (int i = tid * 2; i < N; i += 2048) {
       *reinterpret_cast<double2*>(dub + i) = *reinterpret_cast<double2*>(du_s + i);
       *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
@@ -545,14 +560,15 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
 
 template <int TR, int ILP>
 static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B, int tile, const void* rec64,
-                               const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+                               const int32_t* copy_species, int n_copy, const double* u, const double* k_b, const double* k_1,
+                               double* du, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64, u,
-                     k_b, k_1, du);
+  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64,
+                     copy_species, n_copy, u, k_b, k_1, du);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -765,7 +781,8 @@ static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, in
 }
 
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
-                  const void* rec64, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
+                  const void* rec64, const int32_t* copy_species, int n_copy, const double* u, const double* k_b,
+                  const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
   static int n_cu = 0;
   if (!n_cu) {
@@ -785,11 +802,11 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, con
     if (use_reg < 0) { const char* e = getenv("KIN_SWEEP_REG"); use_reg = e ? atoi(e) : 8; }
     // register-resident path: both LDS arrays carry SWEEP_DUMMY extra entries (per-lane dummy species)
     if (adj && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 &&
-        (size_t)(2 * (N + SWEEP_DUMMY)) * 8 <= lds_max) {
+        (size_t)(2 * (N + SWEEP_DUMMY + n_copy)) * 8 <= lds_max && n_copy <= 1024) {
       const int64_t T = P / 1024;   // full record rows available for residency
-      const int rtile = (int)N + SWEEP_DUMMY;
+      const int rtile = (int)N + SWEEP_DUMMY + n_copy + (n_copy & 1);   // even: keeps u_s 16-byte aligned
       const size_t rsmem = (size_t)2 * rtile * 8;
-#define KIN_REG_GO(TT, II) launch_sweep_reg_t<TT, II>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, u, k_b, k_1, du, s)
+#define KIN_REG_GO(TT, II) launch_sweep_reg_t<TT, II>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s)
       const int want = (int)std::min<int64_t>(use_reg, T);
       if (want >= 16) KIN_REG_GO(16, 4);
       else if (want >= 12) KIN_REG_GO(12, 4);

@@ -206,6 +206,7 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
     // dummy entry N + (record index mod 64) whose u is 1.0 and whose du is never written out.
     if (H.pairs_adjacent && N + 64 <= 16384) {
       bool ok = true;
+      std::vector<int32_t> inst((size_t)4 * H.n_pairs());   // LDS entry per field before hub splitting
       for (int64_t p = 0; p < H.n_pairs() && ok; p++) {
         const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1], co = H.pair_rec[4 * p + 2];
         const uint32_t sl[4] = {s01 & 0xffffu, s01 >> 16, s23 & 0xffffu, s23 >> 16};
@@ -225,11 +226,40 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
         const uint64_t dummy = (uint64_t)N + (uint64_t)(p & 63);
         for (int sd = 0; sd < 2; sd++)
           while (cnt[sd] < 2) side[sd][cnt[sd]++] = dummy;
-        const uint64_t w = side[0][0] | (side[0][1] << 14) | (side[1][0] << 28) | (side[1][1] << 42);
-        H.pair_rec64.push_back((uint32_t)w);
-        H.pair_rec64.push_back((uint32_t)(w >> 32));
+        for (int j = 0; j < 4; j++) inst[4 * p + j] = (int32_t)side[j / 2][j % 2];
       }
-      if (!ok) H.pair_rec64.clear();
+      if (ok) {
+        // Split accumulators for the most referenced species: a same-address ds_add_f64 costs ~3 cycles per
+        // lane (tools/lds_bank_probe.hip: 192 cycles for 64 lanes on one address against 13 conflict-free), and
+        // under the Zipf wiring ~8 lanes of every 64-lane instruction hit the top species. Each of the top K
+        // species gets 7 extra LDS entries behind the dummies; an occurrence in record p uses copy p mod 8
+        // (copy 0 = the species' own entry). The kernel fills the copies' u and folds their du back per state.
+        const int64_t P = H.n_pairs();
+        const int64_t spare = (160 * 1024) / 16 - (N + 64);
+        const int K = (int)std::max<int64_t>(0, std::min<int64_t>(32, spare / 7));
+        std::vector<int64_t> refs(N, 0);
+        for (int64_t q = 0; q < 4 * P; q++) if (inst[q] < N) refs[inst[q]]++;
+        std::vector<int32_t> order(N);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return refs[x] > refs[y]; });
+        std::vector<int32_t> rank_of(N, -1);
+        H.sweep_copy_species.clear();
+        for (int r = 0; r < K && r < N && refs[order[r]] >= 64; r++) {
+          rank_of[order[r]] = r;
+          for (int c = 1; c < 8; c++) H.sweep_copy_species.push_back(order[r]);
+        }
+        for (int64_t p = 0; p < P; p++) {
+          uint64_t f[4];
+          for (int j = 0; j < 4; j++) {
+            const int32_t sp = inst[4 * p + j];
+            const int c = (int)(p & 7);
+            f[j] = (sp < N && rank_of[sp] >= 0 && c > 0) ? (uint64_t)(N + 64 + rank_of[sp] * 7 + (c - 1)) : (uint64_t)sp;
+          }
+          const uint64_t w = f[0] | (f[1] << 14) | (f[2] << 28) | (f[3] << 42);
+          H.pair_rec64.push_back((uint32_t)w);
+          H.pair_rec64.push_back((uint32_t)(w >> 32));
+        }
+      }
     }
     // ---- large-N sweep tables (only when the state cannot live in LDS)
     if ((size_t)N * 16 > 160 * 1024 && N + 64 < 65535) {
