@@ -149,7 +149,11 @@ class HipNetwork:
             lib().kin_network_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
     def _chk(self, st):
         if st != KIN_OK:

@@ -25,7 +25,7 @@ void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, dou
                      big_rec8.p, big_rec.p, big_expl.p, (int32_t)host.big_expl.size(), sweep_k.p, big_spec.p, big_tptr.p, big_tent.p,
                      big_scratch.p, d_u, d_k, k.p, d_du, s);
   } else
-    launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, sweep_rec.p, sweep_k.p,
+    launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.pairs_block, sweep_rec.p, sweep_k.p,
                  host.pair_rec64.empty() ? nullptr : sweep_rec64.p, sweep_copy.p, (int)host.sweep_copy_species.size(), d_u, d_k,
                  k.p, d_du, s);
 }

@@ -433,9 +433,18 @@ __device__ __forceinline__ void sweep_apply(uint2 w, double2 kk, const double* u
   __hip_atomic_fetch_add(du_s + l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// rate constants of pair p: adjacent layout = one double2 at k[2p]; block layout (BLK: all forward reactions
+// first, their reverses in the same order behind them - what duplicate_reverse produces, cde.jl:299-309) =
+// k[p] and k[P + p], two coalesced 8-byte streams
+template <bool BLK>
+__device__ __forceinline__ double2 load_kpair(const double* __restrict__ kb, int p, int P) {
+  if (BLK) return make_double2(kb[p], kb[(size_t)P + p]);
+  return *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
+}
+
 // TR = records per thread kept in registers (compile time, fully unrolled); records beyond
 // TR*1024 are streamed as 8-byte words. ILP = records whose loads are issued together.
-template <int TR, int ILP>
+template <int TR, int ILP, bool BLK>
 __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, int B, int tile,
                                                          const uint2* __restrict__ rec64, const int32_t* __restrict__ copy_species,
                                                          int n_copy, const double* __restrict__ u,
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
 #pragma unroll
     for (int x = 0; x < ILP; x++) {
       const int p = tid + x * 1024;
-      k0[x] = (b < B && p < P) ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+      k0[x] = (b < B && p < P) ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
     }
   }
   for (; b < B; b += gridDim.x) {
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       for (int x = 0; x < ILP; x++) {
         const int p = tid + (i0 + x) * 1024;
         if (KPRE && i0 == 0) kk[x] = k0[x];
-        else kk[x] = p < P ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+        else kk[x] = p < P ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       for (int x = 0; x < ILP; x++) {
         const int p = p0 + x * 1024;
         const bool ok = p < P;
-        kk[x] = ok ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+        kk[x] = ok ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
         w[x] = ok ? rec64[p] : EMPTY;
       }
 #pragma unroll
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
         const int p = tid + x * 1024;
-        k0[x] = (bn < B && p < P) ? *reinterpret_cast<const double2*>(kn + 2 * (size_t)p) : make_double2(0.0, 0.0);
+        k0[x] = (bn < B && p < P) ? load_kpair<BLK>(kn, p, P) : make_double2(0.0, 0.0);
       }
     }
     __syncthreads();
@@ -558,16 +567,16 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   }
 }
 
-template <int TR, int ILP>
+template <int TR, int ILP, bool BLK>
 static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B, int tile, const void* rec64,
                                const int32_t* copy_species, int n_copy, const double* u, const double* k_b, const double* k_1,
                                double* du, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64,
+  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP, BLK>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64,
                      copy_species, n_copy, u, k_b, k_1, du);
 }
 
@@ -781,7 +790,7 @@ static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, in
                      (const SweepRec*)rec, (const int2*)pair_k, u, k_b, k_1, du);
 }
 
-void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
+void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
                   const void* rec64, const int32_t* copy_species, int n_copy, const double* u, const double* k_b,
                   const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
@@ -802,12 +811,17 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, con
     static int use_reg = -1;
     if (use_reg < 0) { const char* e = getenv("KIN_SWEEP_REG"); use_reg = e ? atoi(e) : 8; }
     // register-resident path: both LDS arrays carry SWEEP_DUMMY extra entries (per-lane dummy species)
-    if (adj && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 &&
+    // register-resident path: reactions paired as (2p, 2p+1) [adjacent] or (p, P+p) [block]
+    if ((adj || block) && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 &&
         (size_t)(2 * (N + SWEEP_DUMMY + n_copy)) * 8 <= lds_max && n_copy <= 1024) {
       const int64_t T = P / 1024;   // full record rows available for residency
       const int rtile = (int)N + SWEEP_DUMMY + n_copy + (n_copy & 1);   // even: keeps u_s 16-byte aligned
       const size_t rsmem = (size_t)2 * rtile * 8;
-#define KIN_REG_GO(TT, II) launch_sweep_reg_t<TT, II>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s)
+#define KIN_REG_GO(TT, II)                                                                                                             \
+  do {                                                                                                                                 \
+    if (adj) launch_sweep_reg_t<TT, II, false>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s); \
+    else launch_sweep_reg_t<TT, II, true>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s);   \
+  } while (0)
       const int want = (int)std::min<int64_t>(use_reg, T);
       if (want >= 16) KIN_REG_GO(16, 4);
       else if (want >= 12) KIN_REG_GO(12, 4);

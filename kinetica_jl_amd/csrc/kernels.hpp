@@ -50,7 +50,8 @@ void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const doubl
                        double t_mult, const double* T, double* table, hipStream_t s);
 
 // batched sweep over B states, state-major layouts (see kin_rhs_batched_dev); rec = packed 16-byte records
-void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, const void* rec, const void* pair_k,
+// `adjacent`: pair p = reactions (2p, 2p+1); `block`: pair p = reactions (p, P+p) (forwards first, reverses behind)
+void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
                   const void* rec64, const int32_t* copy_species, int n_copy, const double* u, const double* k_b,
                   const double* k_1, double* du, hipStream_t s);
 

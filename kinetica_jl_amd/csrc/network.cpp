@@ -204,7 +204,10 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
     // product instances (2A is listed as A, A) - so the kernel needs no coefficient or side decoding at
     // all: net = kf u0 u1 - kr u2 u3, du[0,1] -= net, du[2,3] += net. An unused field points at a per-lane
     // dummy entry N + (record index mod 64) whose u is 1.0 and whose du is never written out.
-    if (H.pairs_adjacent && N + 64 <= 16384) {
+    H.pairs_block = !H.pairs_adjacent && (H.n_pairs() * 2 == R) && R > 0;
+    for (int64_t p = 0; p < H.n_pairs() && H.pairs_block; p++)
+      if (H.pair_k[2 * p] != p || H.pair_k[2 * p + 1] != H.n_pairs() + p) H.pairs_block = false;
+    if ((H.pairs_adjacent || H.pairs_block) && N + 64 <= 16384) {
       bool ok = true;
       std::vector<int32_t> inst((size_t)4 * H.n_pairs());   // LDS entry per field before hub splitting
       for (int64_t p = 0; p < H.n_pairs() && ok; p++) {

@@ -65,7 +65,7 @@ struct NetworkHost {
   std::vector<uint32_t> pair_rec;  // 4 words per record: s01, s23, coefs, ops (explicit operands for unpaired records)
   std::vector<int32_t> pair_k;     // 2 per record: kf, kr
   std::vector<int32_t> sweep_copy_species;   // species behind every extra accumulator entry (7 per split hub)
-  std::vector<uint32_t> pair_rec64; // 2 words per record (four 14-bit labels with fixed roles, network.cpp); only when pairs_adjacent
+  std::vector<uint32_t> pair_rec64; // 2 words per record (four 14-bit labels with fixed roles, network.cpp); only when pairs_adjacent or pairs_block
   // Large-N sweep (state does not fit LDS): species are relabelled so that the `big_H` most
   // frequently referenced ones ("hubs") come first (each group kept in species-id order); records
   // carry labels. Hubs keep u and du in LDS; tail rates are gathered per tile of 2 * big_H labels from
@@ -78,6 +78,7 @@ struct NetworkHost {
   std::vector<int32_t> big_tail_ptr;         // tail tiles + 1 (entry offsets)
   std::vector<uint32_t> big_tail_ent;        // 2 words per entry
   bool pairs_adjacent = false;     // record p pairs reactions (2p, 2p+1): k streams as double2, no index load
+  bool pairs_block = false;        // record p pairs reactions (p, P+p): forwards first, reverses behind (duplicate_reverse order)
   int64_t n_pairs() const { return (int64_t)pair_k.size() / 2; }
   // species-major CSR: du[i] = sum_e sp_coef[e] * rate[sp_rxn[e]]
   std::vector<int32_t> sp_ptr, sp_rxn;

@@ -295,3 +295,29 @@ def test_large_n_sweep_with_explicit_operands_and_block_order():
     sc = on.abs_rhs(k, U[0]) + 1e-300
     assert (np.abs(h.rhs(U[0]) - on.rhs(k, U[0])) / sc).max() < TOL
     h.close()
+
+
+def test_batched_sweep_block_order_pairs():
+    """Reactions in the order duplicate_reverse produces (cde.jl:299-309): all forward reactions first, their
+    reverses in the same order behind them. The register-resident sweep pairs reaction p with reaction P + p
+    (two coalesced k streams); more states than workgroups so the cross-state pipeline is exercised."""
+    net, Ea, A = synthetic_crn(2000, 10000, seed=4)
+    order = np.concatenate([np.arange(0, 10000, 2), np.arange(1, 10000, 2)])
+    netb = net.subset(order)
+    h = capi.HipNetwork.from_flat(netb)
+    on = orc.OracleNetwork.from_flat(netb)
+    rng = np.random.default_rng(8)
+    k = rng.uniform(0.5, 2.0, 10000)
+    h.set_rates(k)
+    B = 520
+    U = np.stack([_state(2000, 300 + (b % 9)) * (1.0 + 0.002 * b) for b in range(B)])
+    got = h.rhs_batched(U)
+    for b in (0, 1, 255, 256, 300, B - 1):
+        sc = on.abs_rhs(k, U[b]) + 1e-300
+        assert (np.abs(got[b] - on.rhs(k, U[b])) / sc).max() < TOL
+    K = k[None, :] * rng.uniform(0.5, 2.0, (5, 1))
+    got = h.rhs_batched(U[:5], K)
+    for b in range(5):
+        sc = on.abs_rhs(K[b], U[b]) + 1e-300
+        assert (np.abs(got[b] - on.rhs(K[b], U[b])) / sc).max() < TOL
+    h.close()
