@@ -132,7 +132,7 @@ def main():
                                    f"B={B} states per GPU with per-state Arrhenius k (500-1200 K)",
                        "states_per_gpu": B, "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "kernel": "kin::sweep_reg_kernel<8, 4> (N <= 10240, adjacent pairs; else kin::sweep_lds_kernel)",
+                         "traffic": traffic, "kernel": "kin::sweep_reg_kernel<8, 4, BLK> (state fits LDS, reactions paired with their reverses; else kin::sweep_lds_kernel / sweep_big_kernel)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
         }
 
