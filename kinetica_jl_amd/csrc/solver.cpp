@@ -75,6 +75,11 @@ struct Solver {
   explicit Solver(kin_network* hh) : h(hh), N((int)hh->host.N), s(hh->stream) {
     const NetworkHost& H = h->host;
     LUOptions opt;
+    // Larger networks: eliminate more of the tail sparsely (more rounds, more fill allowed) - every Gauss-Jordan
+    // step moves the whole dense block, so its dimension dominates there (C5: 3870 -> 3126, solve -32 %; C3:
+    // 1173 -> 981, -10 %); small networks keep few rounds, their cost is the number of dependent launches
+    // (C2: the loose setting is 15 % slower). Measured with tools/c5_lu_params.py and bench.py.
+    if (N >= 4000) { opt.max_tail_degree = 32; opt.max_rounds = 16; opt.max_degree = 400; }
     if (const char* e = getenv("KIN_LU_HUB_DEGREE")) opt.hub_degree = atoi(e);
     if (const char* e = getenv("KIN_LU_MAX_ROUNDS")) opt.max_rounds = atoi(e);
     if (const char* e = getenv("KIN_LU_MAX_TAIL_DEGREE")) opt.max_tail_degree = atoi(e);
