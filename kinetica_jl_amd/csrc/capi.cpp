@@ -26,8 +26,8 @@ void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, dou
                      big_scratch.p, d_u, d_k, k.p, d_du, s);
   } else
     launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.pairs_block, sweep_rec.p, sweep_k.p,
-                 host.pair_rec64.empty() ? nullptr : sweep_rec64.p, sweep_copy.p, (int)host.sweep_copy_species.size(), d_u, d_k,
-                 k.p, d_du, s);
+                 host.pair_rec64.empty() ? nullptr : sweep_rec64.p, sweep_copy.p, (int)host.sweep_copy_species.size(),
+                 host.gen_rec8.empty() ? nullptr : gen_rec8.p, gen_expl.p, (int)host.gen_expl.size(), d_u, d_k, k.p, d_du, s);
 }
 
 void kin_network::jac_dev(const double* d_u, double* d_vals) {
@@ -88,6 +88,7 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     h->x0.upload(N.x0, s); h->x1.upload(N.x1, s);
     h->sp_ptr.upload(N.sp_ptr, s); h->sp_rxn.upload(N.sp_rxn, s); h->sp_coef.upload(N.sp_coef, s);
     if (N.N < 65535) { h->sweep_rec.upload(N.pair_rec, s); h->sweep_k.upload(N.pair_k, s); }
+    if (!N.gen_rec8.empty()) { h->gen_rec8.upload(N.gen_rec8, s); h->gen_expl.upload(N.gen_expl, s); }
     if (!N.pair_rec64.empty()) { h->sweep_rec64.upload(N.pair_rec64, s); h->sweep_copy.upload(N.sweep_copy_species, s); }
     if (N.big_H > 0) {
       h->big_rec.upload(N.big_rec, s); h->big_rec8.upload(N.big_rec8, s); h->big_expl.upload(N.big_expl, s);

@@ -19,6 +19,8 @@ struct kin_network {
   kin::DevBuf<uint32_t> sweep_rec;   // 4 words per reversible pair (kernels.hip: SweepRec)
   kin::DevBuf<int32_t> sweep_k;      // (kf, kr) per pair
   kin::DevBuf<uint32_t> sweep_rec64; // 64-bit packed records (register-resident sweep)
+  kin::DevBuf<uint32_t> gen_rec8;    // 8-byte fixed-role records of the general LDS sweep
+  kin::DevBuf<int32_t> gen_expl;     // its explicit-operand records (slow path)
   kin::DevBuf<int32_t> sweep_copy;   // species of the split hubs' extra accumulator entries
   kin::DevBuf<uint32_t> big_rec, big_rec8;   // large-N sweep: label-space records (16-byte slow-path and 8-byte stream format)
   kin::DevBuf<int32_t> big_spec, big_tptr, big_expl;

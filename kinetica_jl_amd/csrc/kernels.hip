@@ -581,6 +581,90 @@ static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B
 }
 
 // ------------------------------------------------------------------------------------------
+// General variant for a state that fits LDS but whose reactions are NOT all paired with their reverses in
+// one of the two regular layouts (what the low-k cutoff leaves behind, or hand-written networks): the same
+// fixed-role 8-byte label records (16-bit labels, per-lane dummies), one per forward/reverse pair or single
+// reaction, plus the (kf, kr) reaction indices of the record (kr = -1: no reverse); the rate constants are
+// gathered by index (near-coalesced, the records follow the reaction order). Reactions with a species on both
+// sides are all-dummy in the stream and take the slow path with the 16-byte record. Replaces the coefficient-
+// decoding loop of sweep_lds_kernel for this case (C3 CRN minus a random 30 % of its reactions, B = 4096:
+// 0.66 ms -> 0.52 ms, tools/unpaired_sweep.py).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sweep_gen_kernel(int N, int R, int P, int B, int tile, const uint2* __restrict__ rec8,
+                                                         const int2* __restrict__ pair_k, const SweepRec* __restrict__ rec,
+                                                         const int32_t* __restrict__ expl, int n_expl,
+                                                         const double* __restrict__ u, const double* __restrict__ k_b,
+                                                         const double* __restrict__ k_1, double* __restrict__ du) {
+  extern __shared__ double lds[];
+  double* du_s = lds;
+  double* u_s = lds + tile;
+  const int tid = threadIdx.x;
+  constexpr int ILP = 4;
+  const uint32_t dl = (uint32_t)(N + (tid & 63));
+  const uint2 EMPTY = {dl | (dl << 16), dl | (dl << 16)};
+  if (tid < SWEEP_DUMMY) { u_s[N + tid] = 1.0; du_s[N + tid] = 0.0; }
+  for (int i = tid; i < N; i += 1024) du_s[i] = 0.0;
+  // the next state's u travels HBM -> registers while this state's records are processed (N <= 10176)
+  constexpr int UPT = 10;
+  double un[UPT];
+  int b = blockIdx.x;
+#pragma unroll
+  for (int x = 0; x < UPT; x++) { const int i = tid + x * 1024; un[x] = (b < B && i < N) ? u[(size_t)b * N + i] : 0.0; }
+  for (; b < B; b += gridDim.x) {
+    const double* kb = k_b ? k_b + (size_t)b * R : k_1;
+    double* dub = du + (size_t)b * N;
+#pragma unroll
+    for (int x = 0; x < UPT; x++) { const int i = tid + x * 1024; if (i < N) u_s[i] = un[x]; }
+    __syncthreads();
+    const int bn = b + gridDim.x;
+#pragma unroll
+    for (int x = 0; x < UPT; x++) { const int i = tid + x * 1024; un[x] = (bn < B && i < N) ? u[(size_t)bn * N + i] : 0.0; }
+    for (int qq = tid; qq < P; qq += 1024 * ILP) {
+      uint2 w[ILP];
+      int2 ki[ILP];
+      double kf[ILP], kr[ILP];
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        const int p = qq + x * 1024;
+        w[x] = p < P ? rec8[p] : EMPTY;
+        ki[x] = p < P ? pair_k[p] : make_int2(-1, -1);
+      }
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        kf[x] = ki[x].x >= 0 ? kb[ki[x].x] : 0.0;
+        kr[x] = ki[x].y >= 0 ? kb[ki[x].y] : 0.0;
+      }
+#pragma unroll
+      for (int x = 0; x < ILP; x++) {
+        const uint32_t l0 = w[x].x & 0xffffu, l1 = w[x].x >> 16, l2 = w[x].y & 0xffffu, l3 = w[x].y >> 16;
+        const double net = kf[x] * (u_s[l0] * u_s[l1]) - kr[x] * (u_s[l2] * u_s[l3]);
+        __hip_atomic_fetch_add(du_s + l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(du_s + l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(du_s + l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(du_s + l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    // reactions with a species on both sides: net = kf u[a] u[c], coefficients from the 16-byte record
+    for (int i = tid; i < n_expl; i += 1024) {
+      const int p = expl[i];
+      const SweepRec q = rec[p];
+      const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
+      double net = kb[pair_k[p].x] * u_s[a];
+      if (c != 0xffffu) net *= u_s[c];
+      const uint32_t sl[4] = {q.s01 & 0xffffu, q.s01 >> 16, q.s23 & 0xffffu, q.s23 >> 16};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (sl[j] != 0xffffu)
+          __hip_atomic_fetch_add(du_s + sl[j], (double)(int)(int8_t)((uint32_t)q.coef >> (8 * j)) * net, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) { dub[i] = du_s[i]; du_s[i] = 0.0; }
+    // no barrier needed here: the next trip only touches u_s before its own barrier
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Large-N sweep (2 x 8N bytes exceed the LDS; C5: N = 50k). Species are relabelled by popularity:
 // the H most referenced species ("hubs", ~81 % of all slot references under the Zipf wiring) keep
 // u and du in LDS exactly as above. Per state, one workgroup
@@ -791,8 +875,8 @@ static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, in
 }
 
 void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
-                  const void* rec64, const int32_t* copy_species, int n_copy, const double* u, const double* k_b,
-                  const double* k_1, double* du, hipStream_t s) {
+                  const void* rec64, const int32_t* copy_species, int n_copy, const void* gen_rec8, const int32_t* gen_expl,
+                  int n_gen_expl, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
   static int n_cu = 0;
   if (!n_cu) {
@@ -830,6 +914,18 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, boo
       else if (use_reg == 1) KIN_REG_GO(0, 8);
       else KIN_REG_GO(0, 4);
 #undef KIN_REG_GO
+      KIN_HIP(hipGetLastError());
+      return;
+    }
+    if (gen_rec8 && (size_t)(2 * (N + SWEEP_DUMMY)) * 8 <= lds_max) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        KIN_HIP(hipFuncSetAttribute((const void*)sweep_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+      }
+      const int gtile = (int)N + SWEEP_DUMMY;
+      hipLaunchKernelGGL(sweep_gen_kernel, dim3(grid), dim3(1024), (size_t)2 * gtile * 8, s, (int)N, (int)R, (int)P, (int)B, gtile,
+                         (const uint2*)gen_rec8, (const int2*)pair_k, (const SweepRec*)rec, gen_expl, n_gen_expl, u, k_b, k_1, du);
       KIN_HIP(hipGetLastError());
       return;
     }

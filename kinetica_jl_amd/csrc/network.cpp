@@ -264,6 +264,29 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
         }
       }
     }
+    // ---- general fixed-role records (state fits LDS, pairing irregular): kernels.hip sweep_gen_kernel
+    if (!H.pairs_adjacent && !H.pairs_block && (size_t)(N + 64) * 16 <= 160 * 1024) {
+      const int64_t P = H.n_pairs();
+      for (int64_t p = 0; p < P; p++) {
+        const uint32_t s01 = H.pair_rec[4 * p], s23 = H.pair_rec[4 * p + 1], co = H.pair_rec[4 * p + 2], ops = H.pair_rec[4 * p + 3];
+        const uint32_t sl[4] = {s01 & 0xffffu, s01 >> 16, s23 & 0xffffu, s23 >> 16};
+        const uint32_t dummy = (uint32_t)N + (uint32_t)(p & 63);
+        uint32_t side[2][2] = {{dummy, dummy}, {dummy, dummy}};
+        int cnt[2] = {0, 0};
+        if (ops == 0xffffffffu) {
+          for (int j = 0; j < 4; j++) {
+            if (sl[j] == 0xffffu) continue;
+            const int c = (int)(int8_t)(co >> (8 * j));
+            const int sd = c < 0 ? 0 : 1;
+            for (int q = 0; q < (c < 0 ? -c : c) && cnt[sd] < 2; q++) side[sd][cnt[sd]++] = sl[j];
+          }
+        } else {
+          H.gen_expl.push_back((int32_t)p);
+        }
+        H.gen_rec8.push_back(side[0][0] | (side[0][1] << 16));
+        H.gen_rec8.push_back(side[1][0] | (side[1][1] << 16));
+      }
+    }
     // ---- large-N sweep tables (only when the state cannot live in LDS)
     if ((size_t)N * 16 > 160 * 1024 && N + 64 < 65535) {
       const int64_t P = H.n_pairs();

@@ -64,6 +64,8 @@ struct NetworkHost {
   // pair_k[2p+1]'s companion word pair_ops (explicit operands).
   std::vector<uint32_t> pair_rec;  // 4 words per record: s01, s23, coefs, ops (explicit operands for unpaired records)
   std::vector<int32_t> pair_k;     // 2 per record: kf, kr
+  std::vector<uint32_t> gen_rec8;   // 2 words per record: fixed-role 16-bit labels for the general LDS sweep (state fits LDS)
+  std::vector<int32_t> gen_expl;    // records with explicit operands
   std::vector<int32_t> sweep_copy_species;   // species behind every extra accumulator entry (7 per split hub)
   std::vector<uint32_t> pair_rec64; // 2 words per record (four 14-bit labels with fixed roles, network.cpp); only when pairs_adjacent or pairs_block
   // Large-N sweep (state does not fit LDS): species are relabelled so that the `big_H` most
