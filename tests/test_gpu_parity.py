@@ -321,3 +321,57 @@ def test_batched_sweep_block_order_pairs():
         sc = on.abs_rhs(K[b], U[b]) + 1e-300
         assert (np.abs(got[b] - on.rhs(K[b], U[b])) / sc).max() < TOL
     h.close()
+
+
+def _random_net(rng, n, n_pairs, layout):
+    """Small random CRN on n species: n_pairs forward reactions (A->B, A->B+C, A+B->C+D, 2A->B+C, A->2B) with
+    their reverses, laid out as adjacent pairs, as forward block + reverse block, or with some reverses dropped."""
+    fwd = []
+    while len(fwd) < n_pairs:
+        kind = rng.integers(5)
+        sp = rng.choice(n, size=4, replace=False) if n >= 4 else None
+        if sp is None:
+            a, b = (0, 1) if rng.random() < 0.5 else (1, 0)
+            fwd.append(([(a, 1)], [(b, 1)]))
+            continue
+        a, b, c, d = (int(x) for x in sp)
+        fwd.append([([(a, 1)], [(b, 1)]), ([(a, 1)], sorted([(b, 1), (c, 1)])), (sorted([(a, 1), (b, 1)]), sorted([(c, 1), (d, 1)])),
+                    ([(a, 2)], sorted([(b, 1), (c, 1)])), ([(a, 1)], [(b, 2)])][kind])
+    if layout == "adjacent":
+        reacs = [x for r, p in fwd for x in (r, p)]
+        prods = [x for r, p in fwd for x in (p, r)]
+    elif layout == "block":
+        reacs = [r for r, p in fwd] + [p for r, p in fwd]
+        prods = [p for r, p in fwd] + [r for r, p in fwd]
+    else:   # irregular: adjacent order with every third reverse missing
+        reacs, prods = [], []
+        for i, (r, p) in enumerate(fwd):
+            reacs.append(r); prods.append(p)
+            if i % 3:
+                reacs.append(p); prods.append(r)
+    return from_lists(n, reacs, prods)
+
+
+@pytest.mark.parametrize("layout", ["adjacent", "block", "irregular"])
+def test_batched_sweep_size_boundaries(layout):
+    """Species counts around every dispatch boundary of the batched sweep (LDS capacity of the register-resident
+    and general kernels, odd N, the large-N kernel), few reactions, batch sizes below / above the CU count."""
+    rng = np.random.default_rng({"adjacent": 1, "block": 2, "irregular": 3}[layout])
+    for n in (2, 3, 63, 64, 65, 1023, 1024, 1025, 10111, 10112, 10175, 10176, 10177, 10178, 10239, 10240, 10241, 12001):
+        net = _random_net(rng, n, 150 if n >= 4 else 1, layout)
+        h = capi.HipNetwork.from_flat(net)
+        on = orc.OracleNetwork.from_flat(net)
+        k = rng.uniform(0.5, 2.0, net.n_reactions)
+        h.set_rates(k)
+        for B in (1, 3, 259):
+            U = 10.0 ** rng.uniform(-6, 0, (B, n))
+            got = h.rhs_batched(U)
+            for b in {0, B // 2, B - 1}:
+                sc = on.abs_rhs(k, U[b]) + 1e-300
+                assert (np.abs(got[b] - on.rhs(k, U[b])) / sc).max() < TOL, (layout, n, B, b)
+        K = k[None, :] * rng.uniform(0.5, 2.0, (2, 1))
+        got = h.rhs_batched(U[:2], K)
+        for b in range(2):
+            sc = on.abs_rhs(K[b], U[b]) + 1e-300
+            assert (np.abs(got[b] - on.rhs(K[b], U[b])) / sc).max() < TOL, (layout, n, "per-state k", b)
+        h.close()
