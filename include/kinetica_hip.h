@@ -146,6 +146,13 @@ typedef struct kin_stats {
 int kin_solve(kin_network* h, const kin_params* params, const double* u0,
               const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops,
               int64_t* n_saved, int32_t* retcode, kin_stats* stats);
+/* Same call with an explicit integrator: `pars.solver` may be any SciML algorithm (params.jl:9); BASELINE config 2
+ * exercises the RHS kernel with an explicit one. The pair is Dormand-Prince 5(4) with FSAL and 4th-order dense
+ * output, step-size control as in SciPy's RK45 (which is the oracle, step for step); no Jacobian, no linear solve.
+ * Orchestration (chunks, save grid, discrete rate updates, tolerance retries) is kin_solve's. */
+int kin_solve_explicit(kin_network* h, const kin_params* params, const double* u0, const double* tstops, const double* T_stops,
+                       const double* k_table, int64_t n_stops, int64_t* n_saved, int32_t* retcode, kin_stats* stats);
+
 /* N3: continuous rate updates (reference: methods.jl:363-653, where k(t) = calculator(T(t)) is inlined
  * symbolically into every species ODE). Here the integrator is simply non-autonomous: the Arrhenius
  * rates are re-evaluated on the device at T(t_new) for every step attempt; T(t) is the linear

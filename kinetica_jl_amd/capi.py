@@ -22,7 +22,7 @@ SYMBOLS = [
     "kin_network_create", "kin_network_destroy", "kin_network_sizes", "kin_last_error",
     "kin_set_rates", "kin_get_rates", "kin_set_arrhenius", "kin_rates_at", "kin_arrhenius_eval",
     "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev",
-    "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solve_continuous", "kin_solution_size",
+    "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solve_explicit", "kin_solve_continuous", "kin_solution_size",
     "kin_solution_copy", "kin_solution_max", "kin_integrator_init", "kin_integrator_step", "kin_integrator_state",
     "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
 ]
@@ -83,6 +83,8 @@ def lib():
         L.kin_jac_pattern.argtypes = [c_void_p, P64, P64, c_int]
         L.kin_jac_values.argtypes = [c_void_p, PD, PD]
         L.kin_solve.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64, P64, POINTER(c_int32),
+                                POINTER(KinStats)]
+        L.kin_solve_explicit.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64, P64, POINTER(c_int32),
                                 POINTER(KinStats)]
         L.kin_solve_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64, P64, POINTER(c_int32),
                                            POINTER(KinStats)]
@@ -231,8 +233,9 @@ class HipNetwork:
         return vals
 
     # --- solve -----------------------------------------------------------------------------
-    def solve(self, params: KinParams, u0, tstops=None, T_stops=None, k_table=None):
-        """kin_solve + kin_solution_copy. Returns (t[M], u[M][N], retcode, stats dict)."""
+    def solve(self, params: KinParams, u0, tstops=None, T_stops=None, k_table=None, explicit=False):
+        """kin_solve (explicit=True: kin_solve_explicit, Dormand-Prince 5(4)) + kin_solution_copy.
+        Returns (t[M], u[M][N], retcode, stats dict, status)."""
         u0 = _f64(u0)
         assert len(u0) == self.n
         n_stops = 0
@@ -246,8 +249,9 @@ class HipNetwork:
                 k_table = _f64(k_table)
                 assert k_table.shape == (n_stops, self.nr)
         n_saved, rc, stats = c_int64(0), c_int32(0), KinStats()
-        st = lib().kin_solve(self._h, ctypes.byref(params), _pd(u0), _pd(tstops), _pd(T_stops), _pd(k_table), n_stops,
-                             ctypes.byref(n_saved), ctypes.byref(rc), ctypes.byref(stats))
+        fn = lib().kin_solve_explicit if explicit else lib().kin_solve
+        st = fn(self._h, ctypes.byref(params), _pd(u0), _pd(tstops), _pd(T_stops), _pd(k_table), n_stops,
+                ctypes.byref(n_saved), ctypes.byref(rc), ctypes.byref(stats))
         if st not in (KIN_OK, KIN_ERR_SOLVE_FAILED):
             self._chk(st)
         t = np.empty(n_saved.value)

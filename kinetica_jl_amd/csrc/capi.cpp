@@ -287,6 +287,19 @@ int kin_newton_solve(kin_network* h, double c, const double* u, const double* b,
   KIN_CATCH(h)
 }
 
+int kin_solve_explicit(kin_network* h, const kin_params* params, const double* u0, const double* tstops, const double* T_stops,
+                       const double* k_table, int64_t n_stops, int64_t* n_saved, int32_t* retcode, kin_stats* stats) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(params && u0, ERR_INVALID_ARG, "params / u0 is null");
+  require(n_stops >= 0, ERR_INVALID_ARG, "n_stops < 0");
+  int rc = solve_entry(h, *params, u0, tstops, T_stops, k_table, n_stops, stats, nullptr, nullptr, 0, true);
+  if (n_saved) *n_saved = h->n_saved;
+  if (retcode) *retcode = rc;
+  if (rc != KIN_RETCODE_SUCCESS) throw KinError(ERR_SOLVE_FAILED, "ODE solution failed.");
+  KIN_CATCH(h)
+}
+
 int kin_solve_continuous(kin_network* h, const kin_params* params, const double* u0, const double* t_nodes,
                          const double* T_nodes, int64_t n_nodes, int64_t* n_saved, int32_t* retcode, kin_stats* stats) {
   if (!h) return KIN_ERR_INVALID_ARG;

@@ -68,6 +68,11 @@ struct Solver {
   double fail_score = 0.0;   // leaky count of rejected attempts (history reset at 3, see reset_history)
   kin_stats st{};
   int64_t iters_left = 0;
+  // explicit Dormand-Prince 5(4) mode (kin_solve_explicit; SciPy's RK45 is the oracle): stage array K[7][N],
+  // state before the last step (dense output), FSAL derivative in K[0]
+  bool explicit_mode = false;
+  DevBuf<double> rk_K, rk_yold, rk_ynew;
+  double rk_h_last = 0.0;
   // continuous-rate solves: called with the segment-local time of every step attempt BEFORE the
   // corrector runs, re-evaluates the rate constants at the conditions of that time
   std::function<void(double)> pre_attempt;
@@ -158,8 +163,19 @@ struct Solver {
     sync_ctrl();
     if (hc->nonfinite) return false;
     const double d2 = hc->scratch[2] / h0;
-    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 0.5);
+    // exponent 1 / (order + 1): the BDF starts at order 1, the explicit pair has error order 4 (SciPy select_initial_step)
+    const double ex = explicit_mode ? 0.2 : 0.5;
+    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), ex);
     h_abs = std::min({100.0 * h0, h1, interval});
+    if (explicit_mode) {
+      rk_K.alloc((size_t)7 * N); rk_yold.alloc(N); rk_ynew.alloc(N);
+      KIN_HIP(hipMemcpyAsync(D.p, y.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));          // D[0] = current state
+      KIN_HIP(hipMemcpyAsync(rk_K.p, f0.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));      // FSAL: K[0] = f(y0)
+      KIN_HIP(hipMemcpyAsync(rk_yold.p, y.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+      rk_h_last = 0.0;
+      rk_fsal_pending = false;
+      return true;
+    }
     launch_bdf_init_D(N, BDF_D_ROWS, y.p, f0.p, h_abs, D.p, s);
     order = 1;
     n_equal = 0;
@@ -209,8 +225,81 @@ struct Solver {
     st.n_rhs++; st.n_linsolve++;
   }
 
+  // One accepted explicit step (Dormand & Prince 1980, the RK5(4)7M pair; step-size control as in SciPy's
+  // RK45: SAFETY 0.9, factors in [0.2, 10], no growth right after a rejection, FSAL). The state lives in D[0].
+  StepStatus rk_step(double t_bound) {
+    static const double A[6][5] = {{0, 0, 0, 0, 0},
+                                   {1.0 / 5, 0, 0, 0, 0},
+                                   {3.0 / 40, 9.0 / 40, 0, 0, 0},
+                                   {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+                                   {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+                                   {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+    static const double Bw[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+    static const double E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+    bool rejected = false;
+    for (;;) {
+      if (iters_left-- <= 0) return STEP_OK;   // caller checks iters_left < 0 -> MaxIters
+      const double min_step = std::max(dtmin, 10.0 * (std::nextafter(t, INF) - t));
+      if (h_abs < min_step) {
+        if (rejected) return STEP_DT_MIN;
+        h_abs = min_step;                       // SciPy clips the proposed step to [min_step, max_step] once per step
+      }
+      double t_new = t + h_abs;
+      if (t_new - t_bound > 0.0) t_new = t_bound;
+      const double hh = t_new - t;
+      h_abs = std::fabs(hh);
+      if (pre_attempt) pre_attempt(t_new);
+      RkVec w;
+      for (int st_i = 1; st_i < 6; st_i++) {
+        for (int j = 0; j < 7; j++) w.v[j] = j < st_i ? hh * A[st_i][j] : 0.0;
+        launch_rk_combine(N, st_i, w, D.p, rk_K.p, ytmp.p, s);
+        rhs(ytmp.p, rk_K.p + (size_t)st_i * N);
+      }
+      for (int j = 0; j < 7; j++) w.v[j] = j < 6 ? hh * Bw[j] : 0.0;
+      launch_rk_combine(N, 6, w, D.p, rk_K.p, rk_ynew.p, s);
+      rhs(rk_ynew.p, rk_K.p + (size_t)6 * N);
+      RkVec e;
+      for (int j = 0; j < 7; j++) e.v[j] = hh * E[j];
+      launch_rk_error(N, e, D.p, rk_ynew.p, rk_K.p, atol, rtol, ctrl.p, red.p, s);
+      sync_ctrl();
+      if (hc->nonfinite) {
+        // SciPy would propagate the NaN; here a non-finite stage is treated like a failed step (halve)
+        h_abs *= 0.5; rejected = true; st.n_rejected++;
+        continue;
+      }
+      const double err = hc->err_norm;
+      if (err < 1.0 && !(ban_negatives && hc->any_negative)) {
+        double factor = err == 0.0 ? MAX_FACTOR : std::min(MAX_FACTOR, 0.9 * std::pow(err, -0.2));
+        if (rejected) factor = std::min(1.0, factor);
+        // accept: y_old <- D[0], D[0] <- y_new, K[0] <- K[6] (FSAL)
+        KIN_HIP(hipMemcpyAsync(rk_yold.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        KIN_HIP(hipMemcpyAsync(D.p, rk_ynew.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        rk_h_last = hh;
+        h_abs *= factor;
+        t = t_new;
+        st.n_steps++;
+        return STEP_OK;
+      }
+      h_abs *= (ban_negatives && hc->any_negative && err < 1.0) ? 0.5 : std::max(MIN_FACTOR, 0.9 * std::pow(err, -0.2));
+      rejected = true;
+      st.n_rejected++;
+    }
+  }
+  // the stage derivatives of the accepted step are needed for dense output until the next step starts:
+  // the FSAL copy K[0] <- K[6] is therefore done lazily, at the start of the next step
+  bool rk_fsal_pending = false;
+
   // one accepted step towards t_bound (internally retries rejected attempts)
   StepStatus step(double t_bound) {
+    if (explicit_mode) {
+      if (rk_fsal_pending) {
+        KIN_HIP(hipMemcpyAsync(rk_K.p, rk_K.p + (size_t)6 * N, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        rk_fsal_pending = false;
+      }
+      const StepStatus r = rk_step(t_bound);
+      rk_fsal_pending = true;
+      return r;
+    }
     bool accepted = false, first_attempt = true;
     double safety = 0.9, err_norm = 0.0, t_new = t;
     while (!accepted) {
@@ -311,7 +400,7 @@ struct Solver {
   bool pending_order_change = false;
   double err_m = 0, err_p = 0, err_o = 0, safety_o = 0.9;
   void select_order() {
-    if (!pending_order_change) return;
+    if (explicit_mode || !pending_order_change) return;
     pending_order_change = false;
     const double norms[3] = {err_m, err_o, err_p};
     double best = -1.0;
@@ -333,6 +422,26 @@ struct Solver {
 
   // dense output of the step that ended at t (step size h_abs, differences D of `order`)
   void interpolate(double ts, double* out) {
+    if (explicit_mode) {
+      // SciPy's RkDenseOutput for RK45: y(t) = y_old + h x sum_j K_j (sum_p P[j][p] x^p), x = (t - t_old) / h
+      static const double P[7][4] = {
+          {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+          {0, 0, 0, 0},
+          {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+          {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+          {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+          {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+          {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+      const double x = (ts - (t - rk_h_last)) / rk_h_last;
+      RkVec w;
+      for (int j = 0; j < 7; j++) {
+        double acc = 0.0, xp = x;
+        for (int q = 0; q < 4; q++) { acc += P[j][q] * xp; xp *= x; }
+        w.v[j] = rk_h_last * acc;
+      }
+      launch_rk_combine(N, 7, w, rk_yold.p, rk_K.p, out, s);
+      return;
+    }
     BdfVec p;
     double prod = 1.0;
     for (int j = 0; j < order; j++) {
@@ -383,7 +492,7 @@ void apply_rates(kin_network* h, const double* T_stops, bool have_table, int64_t
 
 int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
                 const double* k_table, int64_t n_stops, kin_stats* stats, const double* t_nodes, const double* T_nodes,
-                int64_t n_nodes) {
+                int64_t n_nodes, bool explicit_solver) {
   auto wall0 = std::chrono::steady_clock::now();
   const int64_t N = h->host.N, R = h->host.R;
   // ---- validation (ODESimulationParams constructor, params.jl:77-104)
@@ -422,6 +531,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   Solver& S = *h->solver;
   hipStream_t s = h->stream;
   S.st = kin_stats{};
+  S.explicit_mode = explicit_solver;
   S.sync_wait_s = 0.0;
   std::fill(S.iter_hist, S.iter_hist + 8, 0);
   S.ban_negatives = p.ban_negatives != 0;
@@ -664,6 +774,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
   IntegratorState& I = *h->integ;
   hipStream_t s = h->stream;
   S.st = kin_stats{};
+  S.explicit_mode = false;
   S.ban_negatives = p.ban_negatives != 0;
   S.set_tols(p.abstol, p.reltol);
   S.pre_attempt = nullptr;

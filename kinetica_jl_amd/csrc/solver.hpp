@@ -9,7 +9,8 @@ namespace kin {
 // the handle; returns the final KIN_RETCODE_*.
 int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops,
                 const double* T_stops, const double* k_table, int64_t n_stops, kin_stats* stats,
-                const double* t_nodes = nullptr, const double* T_nodes = nullptr, int64_t n_nodes = 0);
+                const double* t_nodes = nullptr, const double* T_nodes = nullptr, int64_t n_nodes = 0,
+                bool explicit_solver = false);   // explicit: Dormand-Prince 5(4) instead of the BDF (kin_solve_explicit)
 // return_integrator=true: initialise / advance / inspect the integrator without solving (solver.cpp)
 void integrator_init(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
                      const double* k_table, int64_t n_stops);

@@ -460,6 +460,50 @@ __global__ __launch_bounds__(256) void bdf_interp_kernel(int N, int order, const
   out[i] = v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Explicit Dormand-Prince 5(4) (C2: "RHS kernel only, explicit solver"): stage combination, error norm,
+// dense output. K is the stage array [7][N]; algorithm and step control: solver.cpp (rk_step).
+// ------------------------------------------------------------------------------------------
+// out = y + sum_j w[j] K[j], j < n  (stage argument, new state, dense output: the weights come from the host)
+__global__ __launch_bounds__(256) void rk_combine_kernel(int N, int n, RkVec w, const double* __restrict__ y,
+                                                         const double* __restrict__ K, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double v = 0.0;
+  for (int j = 0; j < n; j++) v += w.v[j] * K[(size_t)j * N + i];
+  out[i] = y[i] + v;
+}
+
+// err_norm = rms( (sum_j e[j] K[j]) / (atol + rtol max(|y|, |y_new|)) ), flags for NaN / negative entries
+__global__ __launch_bounds__(256) void rk_error_kernel(int N, RkVec e, const double* __restrict__ y, const double* __restrict__ y_new,
+                                                       const double* __restrict__ K, double atol, double rtol, BdfCtrl* ctrl,
+                                                       double* __restrict__ part) {
+  __shared__ double sh[4];
+  __shared__ int last;
+  const int G = gridDim.x;
+  double se = 0.0;
+  int neg = 0, bad = 0;
+  for (int x = 0; x < 4; x++) {
+    const int i = blockIdx.x * RED_ELEMS + threadIdx.x + 256 * x;
+    if (i >= N) continue;
+    double err = 0.0;
+    for (int j = 0; j < 7; j++) err += e.v[j] * K[(size_t)j * N + i];
+    const double yn = y_new[i];
+    if (yn < 0.0) neg = 1;
+    if (!isfinite(yn)) bad = 1;
+    const double q = err / (atol + rtol * fmax(fabs(y[i]), fabs(yn)));
+    se += q * q;
+  }
+  const double pe = block_sum_256(se, sh), pn = block_sum_256((double)neg, sh), pb = block_sum_256((double)bad, sh);
+  if (threadIdx.x == 0) { part[blockIdx.x] = pe; part[G + blockIdx.x] = pn; part[2 * G + blockIdx.x] = pb; }
+  if (!last_block_arrives(ctrl, &last)) return;
+  if (threadIdx.x == 0) {
+    ctrl->err_norm = sqrt(sum_partials(part, G) / (double)N);
+    ctrl->any_negative = sum_partials(part + G, G) > 0.0;
+    ctrl->nonfinite = sum_partials(part + 2 * G, G) > 0.0 || !isfinite(ctrl->err_norm);
+  }
+}
+
 // out = a + s*b
 __global__ __launch_bounds__(256) void axpy_out_kernel(int N, const double* __restrict__ a, double s, const double* __restrict__ b, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -538,6 +582,13 @@ void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, dou
 }
 void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s) {
   hipLaunchKernelGGL(bdf_interp_kernel, GRID1(N), 0, s, N, order, D, p, out);
+}
+void launch_rk_combine(int N, int n, const RkVec& w, const double* y, const double* K, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(rk_combine_kernel, GRID1(N), 0, s, N, n, w, y, K, out);
+}
+void launch_rk_error(int N, const RkVec& e, const double* y, const double* y_new, const double* K, double atol, double rtol,
+                     BdfCtrl* ctrl, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(rk_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, e, y, y_new, K, atol, rtol, ctrl, part);
 }
 void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s) {
   hipLaunchKernelGGL(axpy_out_kernel, GRID1(N), 0, s, N, a, sc, b, out);

@@ -15,6 +15,7 @@ struct BdfCoef {  // passed to kernels by value
 };
 struct BdfMat { double v[BDF_MAX_ORDER + 1][BDF_MAX_ORDER + 1]; };
 struct BdfVec { double v[BDF_MAX_ORDER + 1]; };
+struct RkVec { double v[7]; };   // per-stage weights of the explicit Dormand-Prince path
 
 // device-resident control block, copied to the host once per step attempt
 struct BdfCtrl {
@@ -37,6 +38,9 @@ void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t
 void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s);
 void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, double h, double* D, hipStream_t s);
 void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s);
+void launch_rk_combine(int N, int n, const RkVec& w, const double* y, const double* K, double* out, hipStream_t s);
+void launch_rk_error(int N, const RkVec& e, const double* y, const double* y_new, const double* K, double atol, double rtol,
+                     BdfCtrl* ctrl, double* part, hipStream_t s);
 void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s);
 void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s);
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s);

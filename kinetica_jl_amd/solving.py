@@ -195,7 +195,8 @@ def _call_calc(calc, conds: dict):
 class ODESimulationParams:
     tspan: tuple
     u0: Union[Dict[str, float], Sequence[float]]
-    solver: object = None          # accepted for interface parity; the integrator is the library's BDF
+    solver: object = None          # None / "BDF": the library's implicit BDF; "RK45" (or "DP5", "explicit"): its explicit
+                                   # Dormand-Prince 5(4) pair (kin_solve_explicit); the reference takes any SciML algorithm here
     jac: bool = True
     sparse: bool = True
     abstol: float = 1.0e-10
@@ -227,6 +228,15 @@ class ODESimulationParams:
                 raise ValueError("Simulation timespan is not divisible by requested chunkwise simulation step size")
         if self.solve_chunks and self.save_interval is not None and self.save_interval > self.solve_chunkstep:
             raise ValueError("Solution save interval must be less than chunkwise simulation step size")
+
+    @property
+    def explicit(self):
+        """True when `solver` selects the explicit integrator."""
+        if self.solver is None or (isinstance(self.solver, str) and self.solver.upper() in ("BDF", "CVODE_BDF", "IMPLICIT")):
+            return False
+        if isinstance(self.solver, str) and self.solver.upper() in ("RK45", "DP5", "EXPLICIT"):
+            return True
+        raise ValueError(f"solver must be None / 'BDF' or 'RK45' / 'DP5' / 'explicit', got {self.solver!r}")
 
     def to_kin_params(self):
         return capi.KinParams(tspan0=self.tspan[0], tspan1=self.tspan[1], abstol=self.abstol, reltol=self.reltol,
@@ -459,7 +469,7 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
             # static rates (a Dummy calculator is constant under continuous updates as well)
             k0 = get_initial_rates(conditions, calc)
             h.set_rates(k0)
-            t, u, rc, st, status = h.solve(pars.to_kin_params(), u0)
+            t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, explicit=pars.explicit)
         elif not conditions.discrete_updates:
             # continuous rate updates (methods.jl:363-653): k(t) = calculator(T(t)) evaluated on the device at
             # every step; T(t) = the profile solution, linearly interpolated (src/utils.jl:135-139)
@@ -474,9 +484,9 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
             tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
             sol_k = DiscreteRates(tstops, table)
             if arr:
-                t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, T_stops=T)
+                t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, T_stops=T, explicit=pars.explicit)
             else:
-                t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, k_table=table)
+                t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, k_table=table, explicit=pars.explicit)
         if status == capi.KIN_ERR_SOLVE_FAILED:
             raise RuntimeError("ODE solution failed.")      # ErrorException (solve_utils.jl:405-411)
         if pars.update_tols and st["final_abstol"] != pars.abstol:

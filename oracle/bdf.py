@@ -300,6 +300,57 @@ class OracleBDF:
         return self.D[0] + np.dot(self.D[1:order + 1].T, p)
 
 
+class OracleRK45:
+    """The explicit counterpart (kin_solve_explicit): SciPy's own RK45 (Dormand-Prince 5(4), `scipy.integrate.RK45`)
+    behind the interface the driver below expects from an integrator - an independent implementation, so the
+    device path is compared with it step for step. One RK45 object per segment (restart)."""
+
+    def __init__(self, fun, n, atol, rtol):
+        self.fun, self.n = fun, n
+        self.set_tols(atol, rtol)
+        self.stats = dict(n_steps=0, n_rejected=0, n_rhs=0, n_jac=0, n_factor=0, n_linsolve=0, n_newton_fail=0, n_restarts=0)
+        self.iters_left = 0
+        self.pre_attempt = None
+        self.rk = None
+
+    def set_tols(self, atol, rtol):
+        self.atol, self.rtol = atol, rtol
+
+    def _f(self, t, y):
+        self.stats["n_rhs"] += 1
+        return self.fun(y)
+
+    def restart(self, t0, y0, t_bound):
+        from scipy.integrate import RK45
+        self.stats["n_restarts"] += 1
+        y0 = np.array(y0, dtype=float)
+        if not np.all(np.isfinite(self.fun(y0))):
+            return False
+        self.rk = RK45(self._f, t0, y0, t_bound, rtol=self.rtol, atol=self.atol)
+        self.t, self.h_abs = t0, self.rk.h_abs
+        self.D = [y0.copy()]
+        return True
+
+    def step(self, t_bound):
+        self.iters_left -= 1          # (SciPy retries rejected attempts inside step(): counted per accepted step)
+        if self.iters_left < 0:
+            return "maxiters"
+        msg = self.rk.step()
+        if self.rk.status == "failed":
+            return "dtmin"
+        self.stats["n_steps"] += 1
+        self.t = self.rk.t
+        self.D = [self.rk.y.copy()]
+        self._dense = self.rk.dense_output()
+        return "ok"
+
+    def select_order(self):
+        pass
+
+    def interpolate(self, ts):
+        return self._dense(ts)
+
+
 def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None, k_of_stop=None, k_of_time=None):
     """CPU restatement of the solve orchestration. `fun_of_k(k)(y)`, `jac_of_k(k)(y)`;
     `k_of_stop(i)` gives the rate vector in force from tstops[i] on (zero-order hold,
@@ -338,8 +389,11 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
     L = len(save_local) if save_local is not None else 0
 
     state = {"k": None if k0 is None else np.array(k0, dtype=float)}
-    bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
-                    dtmin=0.0, ban_negatives=params.get("ban_negatives", False))
+    if params.get("explicit", False):
+        bdf = OracleRK45(lambda y: fun_of_k(state["k"])(y), n, abstol, reltol)
+    else:
+        bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
+                        dtmin=0.0, ban_negatives=params.get("ban_negatives", False))
     # continuous rate updates (methods.jl:363-653): k re-evaluated at the global time of every step attempt
     seg_origin = [0.0]
     if k_of_time is not None:

@@ -453,3 +453,49 @@ def test_return_integrator_n1(golden_dir):
         assert integ.step(3) == 3 and abs(integ.t - t[3]) < 1e-6 * t[3]
         integ.solve()
         assert integ.t == 1.0 and integ.retcode == "Success" and errscale(integ.u, u[-1]) < 1
+
+
+def test_explicit_solver_matches_scipy_rk45():
+    """kin_solve_explicit (Dormand-Prince 5(4) on the RHS kernels; BASELINE config 2: "RHS kernel only, explicit
+    solver") against SciPy's RK45 behind the same driver: same step sequence, same dense output."""
+    from kinetica_jl_amd.synth import narrow_k_variant
+    # closed form, chunkwise with interpolated saves
+    net = from_lists(2, [[(0, 1)]], [[(1, 1)]])
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates([3.0])
+    t, u, rc, st, status = h.solve(kp((0.0, 1.0), True, 0.25, 0.125), [1.0, 0.0], explicit=True)
+    assert status == capi.KIN_OK and rc == 0 and st["n_factor"] == 0 and st["n_jac"] == 0
+    np.testing.assert_allclose(t, np.arange(9) * 0.125, atol=1e-15)
+    assert errscale(u[:, 0], np.exp(-3.0 * t)) < 100
+    to, uo, rco, sto = oracle_solve(net, dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.25, save_interval=0.125,
+                                              explicit=True), [1.0, 0.0], k0=np.array([3.0]))
+    assert st["n_steps"] == sto["n_steps"] and errscale(u, uo) < 1e-3
+    h.close()
+    # C2-like: synthetic CRN, narrow-k variant (non-stiff), static 1000 K, every accepted step stored
+    net, Ea, A = synthetic_crn(200, 1000, seed=6)
+    k = orc.arrhenius(narrow_k_variant(Ea), A, 1000.0, k_max=1e3)
+    u0 = np.zeros(200); u0[0] = 1.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates(k)
+    t, u, rc, st, status = h.solve(kp((0.0, 0.05), chunks=False, abstol=1e-8, reltol=1e-6), u0, explicit=True)
+    to, uo, rco, sto = oracle_solve(net, dict(tspan=(0.0, 0.05), solve_chunks=False, abstol=1e-8, reltol=1e-6, explicit=True),
+                                    u0, k0=k)
+    assert rc == 0 and rco == 0
+    assert st["n_steps"] == sto["n_steps"] and len(t) == len(to)
+    np.testing.assert_allclose(t, to, rtol=1e-9)
+    assert errscale(u, uo, 1e-8, 1e-6) < 1e-2
+    np.testing.assert_allclose((u * net.mass).sum(axis=1), net.mass[0], rtol=1e-9)     # mass invariant
+    # against the implicit path on the same problem (two different integrators, same tolerance)
+    tb, ub, rcb, stb, _ = h.solve(kp((0.0, 0.05), chunks=False, save=0.01, abstol=1e-8, reltol=1e-6), u0)
+    te, ue, rce, ste, _ = h.solve(kp((0.0, 0.05), chunks=False, save=0.01, abstol=1e-8, reltol=1e-6), u0, explicit=True)
+    np.testing.assert_allclose(tb, te)
+    assert errscale(ue, ub, 1e-8, 1e-6) < 100
+    # discrete rate updates under the explicit integrator
+    tst = np.arange(5) * 0.01
+    ks = np.stack([k * (1.0 + 0.1 * i) for i in range(5)])
+    t, u, rc, st, _ = h.solve(kp((0.0, 0.05), True, 0.025, 0.005, abstol=1e-8, reltol=1e-6), u0, tstops=tst, k_table=ks, explicit=True)
+    to, uo, rco, sto = oracle_solve(net, dict(tspan=(0.0, 0.05), solve_chunks=True, solve_chunkstep=0.025, save_interval=0.005,
+                                              abstol=1e-8, reltol=1e-6, explicit=True), u0, tstops=tst, ks=ks)
+    assert rc == 0 and np.allclose(t, to) and st["n_restarts"] == sto["n_restarts"]
+    assert errscale(u, uo, 1e-8, 1e-6) < 1e-2
+    h.close()

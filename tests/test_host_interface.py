@@ -95,6 +95,17 @@ def test_params_validation():
     assert kp.save_interval == -1.0 and kp.solve_chunks == 1 and kp.maxiters == 100000
 
 
+def test_solver_selection():
+    """`pars.solver` (params.jl:9: any SciML algorithm in the reference): None / "BDF" -> the implicit path,
+    "RK45" / "DP5" / "explicit" -> kin_solve_explicit; anything else is refused, never silently replaced."""
+    assert S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0}).explicit is False
+    assert S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0}, solver="BDF").explicit is False
+    for name in ("RK45", "dp5", "explicit"):
+        assert S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0}, solver=name).explicit is True
+    with pytest.raises(ValueError):
+        S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0}, solver="Rodas5").explicit
+
+
 def test_solve_method_constructors():
     pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0])
     calc = S.PrecalculatedArrheniusCalculator([1.0], [1.0])

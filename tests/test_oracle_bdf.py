@@ -110,3 +110,21 @@ def test_oracle_against_committed_truth(golden_dir):
     np.testing.assert_allclose(t, z["syn_t"])
     err = np.abs(u - z["syn_u"]) / (1e-10 + 1e-8 * np.abs(z["syn_u"]))
     assert err.max() < 100.0
+
+
+def test_explicit_oracle_is_scipy_rk45_behind_the_driver():
+    """The explicit oracle (kin_solve_explicit's reference) = SciPy's RK45 run segment by segment by the same
+    chunk / save-grid driver: closed form A -> B, chunkwise grid, every-step output."""
+    import numpy as np
+    from oracle import bdf as obdf
+    k = 3.0
+    fun = lambda kk: (lambda y: np.array([-kk[0] * y[0], kk[0] * y[0]]))
+    t, u, rc, st = obdf.solve_network_oracle(fun, None, 2, dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.25,
+                                                                save_interval=0.125, explicit=True),
+                                             [1.0, 0.0], k0=np.array([k]))
+    assert rc == obdf.RET_SUCCESS and np.allclose(t, np.arange(9) * 0.125)
+    assert np.max(np.abs(u[:, 0] - np.exp(-k * t)) / (1e-10 + 1e-8 * np.exp(-k * t))) < 100
+    assert st["n_restarts"] == 4 and st["n_factor"] == 0
+    t2, u2, rc2, st2 = obdf.solve_network_oracle(fun, None, 2, dict(tspan=(0.0, 1.0), solve_chunks=False, explicit=True),
+                                                 [1.0, 0.0], k0=np.array([k]))
+    assert rc2 == obdf.RET_SUCCESS and t2[0] == 0.0 and t2[-1] == 1.0 and len(t2) == st2["n_steps"] + 1

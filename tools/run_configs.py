@@ -67,6 +67,11 @@ def main():
         h.solve(kp(2e-3, 1e-3), u0)
         t0 = time.perf_counter(); t, u, rc, st, _ = h.solve(kp(0.02, 1e-3), u0); dt = time.perf_counter() - t0
         out.append({"config": "C2", "kernel": "kin_solve 20 chunks", "wall_s": dt, "retcode": rc, "stats": st})
+        # the configuration's own wording: RHS kernel only, explicit solver (Dormand-Prince 5(4), kin_solve_explicit)
+        h.solve(kp(2e-3, 1e-3), u0, explicit=True)
+        t0 = time.perf_counter(); t, u, rc, st, _ = h.solve(kp(0.02, 1e-3), u0, explicit=True); dt = time.perf_counter() - t0
+        out.append({"config": "C2", "kernel": "kin_solve_explicit 20 chunks", "wall_s": dt, "retcode": rc, "stats": st,
+                    "rhs_evals_per_s": st["n_rhs"] / dt})
         h.close()
     if "c3" in which:
         out.append(sweep_record("C3", 10000, 50000, 4096))
