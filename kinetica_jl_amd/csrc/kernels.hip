@@ -223,23 +223,46 @@ __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __r
   k[i] = arrhenius_one(Ea[i], A[i], 8.314462618 * T, has_kmax, 1.0 / k_max, t_mult);
 }
 
-// Table variant without IEEE divisions (the table kernel is FP64-VALU bound: with two full divisions
-// per element it ran at 2.0 ms for 14001 x 50000, against a 1.0 ms pure-store floor). Ea/RT is a
-// multiply by the row's reciprocal plus one FMA residual correction; the cap k c/(1 + k/k_max) uses
-// v_rcp_f64, two Newton steps and a residual correction (faithfully rounded, <= 1 ulp).
-// Deviation from the two-division form: <= (|Ea/RT| + 6) * 2^-53 relative (one ulp in the argument of
+// Table variant without IEEE divisions and with a lean exp (the table kernel is FP64-VALU bound: with two full
+// divisions and the library exp per element it ran at 2.0 ms for 14001 x 50000, against a 1.0 ms pure-store floor).
+// Ea/RT is a multiply by the row's reciprocal plus one FMA residual correction; exp is range reduction + a
+// degree-13 Taylor polynomial + ldexp with no special-case handling (<= 0.62 ulp on |x| <= 700, checked against
+// long double); the cap 1/(1/k_max + 1/k_r) is evaluated in exactly that form, 1/k_r = exp(+Ea/RT) / (A N_A t_mult),
+// with v_rcp_f64 and two Newton steps - an overflowing exp gives k = 0, the limit of the reference formula.
+// Deviation from the two-division form: <= (2 |Ea/RT| + 8) * 2^-53 relative (one ulp in the argument of
 // exp is amplified by |Ea/RT|), the bound the parity test applies element by element.
-__device__ __forceinline__ double arrhenius_fast(double Ea, double c, double RT, double inv_RT, int has_kmax, double inv_kmax) {
+__device__ __forceinline__ double exp_lean(double x) {
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// c = A N_A t_mult, inv_c = 1 / c
+__device__ __forceinline__ double arrhenius_fast(double Ea, double c, double inv_c, double RT, double inv_RT, int has_kmax,
+                                                 double inv_kmax) {
   double q = Ea * inv_RT;
   q = fma(fma(-q, RT, Ea), inv_RT, q);
-  const double kr = c * exp(-q);
-  if (!has_kmax) return kr;
-  const double x = fma(kr, inv_kmax, 1.0);
+  if (!has_kmax) return c * exp_lean(-q);
+  const double x = fma(inv_c, exp_lean(q), inv_kmax);     // 1/k_max + 1/k_r
   double y = __builtin_amdgcn_rcp(x);
   y = fma(fma(-x, y, 1.0), y, y);
   y = fma(fma(-x, y, 1.0), y, y);
-  const double k = kr * y;
-  return fma(fma(-k, x, kr), y, k);
+  return x < 1e300 ? y : 0.0;
 }
 
 // table[s][r]; one thread produces two consecutive reactions (16-byte stores), grid.y walks
@@ -262,19 +285,19 @@ __global__ __launch_bounds__(256) void rate_table_kernel(int n, int n_stops, con
   const int r = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (r >= n) return;
   const bool pair = (r + 1 < n);
-  const double e0 = Ea[r], c0 = A[r] * 6.02214076e23 * t_mult;
-  const double e1 = pair ? Ea[r + 1] : 0.0, c1 = pair ? A[r + 1] * 6.02214076e23 * t_mult : 1.0;
+  const double e0 = Ea[r], c0 = A[r] * 6.02214076e23 * t_mult, ic0 = 1.0 / c0;
+  const double e1 = pair ? Ea[r + 1] : 0.0, c1 = pair ? A[r + 1] * 6.02214076e23 * t_mult : 1.0, ic1 = 1.0 / c1;
   const double inv_kmax = 1.0 / k_max;
   for (int s = s0; s < s1; s++) {
     const double RT = rt_s[s - s0], inv_RT = irt_s[s - s0];
-    const double v0 = arrhenius_fast(e0, c0, RT, inv_RT, has_kmax, inv_kmax);
+    const double v0 = arrhenius_fast(e0, c0, ic0, RT, inv_RT, has_kmax, inv_kmax);
     double* row = table + (size_t)s * n;
     if (pair && ((n & 1) == 0)) {
-      const double v1 = arrhenius_fast(e1, c1, RT, inv_RT, has_kmax, inv_kmax);
+      const double v1 = arrhenius_fast(e1, c1, ic1, RT, inv_RT, has_kmax, inv_kmax);
       *reinterpret_cast<double2*>(row + r) = make_double2(v0, v1);
     } else {
       row[r] = v0;
-      if (pair) row[r + 1] = arrhenius_fast(e1, c1, RT, inv_RT, has_kmax, inv_kmax);
+      if (pair) row[r + 1] = arrhenius_fast(e1, c1, ic1, RT, inv_RT, has_kmax, inv_kmax);
     }
   }
 }
