@@ -24,7 +24,7 @@ from .synth import FlatNetwork, from_lists
 __all__ = ["SpeciesData", "RxData", "RxFilter", "get_filter_mask", "DummyKineticCalculator",
            "PrecalculatedArrheniusCalculator", "PrecalculatedLindemannCalculator", "allows_continuous",
            "has_conditions", "setup_network", "ODESimulationParams", "StaticODESolve", "VariableODESolve",
-           "solve_network", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
+           "solve_network", "insert_inert", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
            "get_max_rates", "get_initial_rates", "calculate_discrete_rates"]
 
 _T_UNIT = {  # src/utils.jl:77-97
@@ -94,6 +94,34 @@ class RxData:
 
 
 # ---- reaction filters (src/solving/filters.jl) ----------------------------------------------------
+def insert_inert(rd: "RxData", sd: "SpeciesData", inert_species: Sequence[str]):
+    """insert_inert!(rd, sd, inert_species) (src/solving/solve_utils.jl:126-192), topology part: every unimolecular
+    reaction (one reactant with stoichiometry 1) becomes bimolecular with the inert species as a bystander on both
+    sides; with several inert species the reaction is copied once per additional collision partner (new reactions
+    appended, the original modified for the last partner). The reference also builds 3D geometries for new species
+    and re-hashes the reactions (OpenBabel, stable_hash): chemistry metadata the solve path does not read."""
+    ids = []
+    for name in inert_species:
+        if name not in sd.toInt:
+            sd.n += 1
+            sd.toInt[name] = sd.n
+            sd.toStr[sd.n] = name
+        ids.append(sd.toInt[name])
+    uni = [i for i in range(rd.nr) if len(rd.id_reacs[i]) == 1 and rd.stoic_reacs[i][0] == 1]
+    for pos, sid in enumerate(ids):
+        if pos < len(ids) - 1:
+            for rid in uni:
+                rd.id_reacs.append(rd.id_reacs[rid] + [sid]); rd.id_prods.append(rd.id_prods[rid] + [sid])
+                rd.stoic_reacs.append(rd.stoic_reacs[rid] + [1]); rd.stoic_prods.append(rd.stoic_prods[rid] + [1])
+                if rd.dH is not None:
+                    rd.dH.append(rd.dH[rid])
+                rd.nr += 1
+        else:
+            for rid in uni:
+                rd.id_reacs[rid] = rd.id_reacs[rid] + [sid]; rd.id_prods[rid] = rd.id_prods[rid] + [sid]
+                rd.stoic_reacs[rid] = rd.stoic_reacs[rid] + [1]; rd.stoic_prods[rid] = rd.stoic_prods[rid] + [1]
+
+
 class RxFilter:
     def __init__(self, filters: Optional[List[Callable]] = None, keep_filtered: bool = False):
         self.filters = [lambda sd, rd: [False] * rd.nr] if filters is None else filters

@@ -499,3 +499,30 @@ def test_explicit_solver_matches_scipy_rk45():
     assert rc == 0 and np.allclose(t, to) and st["n_restarts"] == sto["n_restarts"]
     assert errscale(u, uo, 1e-8, 1e-6) < 1e-2
     h.close()
+
+
+def test_inert_collision_partner_n4():
+    """insert_inert! then solve: A + M -> B + M with M inert is first-order decay with rate k [M]; M itself must
+    stay exactly constant. The species-on-both-sides records take the kernels' explicit-operand paths."""
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    sd = S.SpeciesData.from_names(["A", "B"])
+    rd = S.RxData(2, [[1], [2]], [[2], [1]], [[1], [1]], [[1], [1]])
+    S.insert_inert(rd, sd, ["Ar"])
+    calc = S.DummyKineticCalculator([2.0, 0.5])
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0={"A": 1.0, "Ar": 3.0}, solve_chunks=False, save_interval=0.125,
+                                 low_k_cutoff="none")
+    res = S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 300.0}), calc), sd, rd)
+    t, u = np.asarray(res.sol.t), np.asarray(res.sol.u)
+    assert res.sol.retcode == "Success" and np.all(u[:, 2] == 3.0)
+    kf, kr = 2.0 * 3.0, 0.5 * 3.0
+    a = kr / (kf + kr) + (1.0 - kr / (kf + kr)) * np.exp(-(kf + kr) * t)
+    assert errscale(u[:, 0], a) < 100
+    # the batched sweep on the same network
+    h = capi.HipNetwork(*rd.flat(sd.n), index_base=1)
+    h.set_rates([2.0, 0.5])
+    U = np.array([[1.0, 0.0, 3.0], [0.3, 0.7, 2.0], [0.0, 1.0, 0.5]])
+    got = h.rhs_batched(U)
+    ref = np.stack([[-2.0 * x[0] * x[2] + 0.5 * x[1] * x[2], 2.0 * x[0] * x[2] - 0.5 * x[1] * x[2], 0.0] for x in U])
+    np.testing.assert_allclose(got, ref, rtol=1e-14, atol=1e-300)
+    h.close()

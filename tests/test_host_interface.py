@@ -162,3 +162,20 @@ def test_dummy_calculator_and_low_k_cutoff_bookkeeping():
     pars_none = S.ODESimulationParams(tspan=(0.0, 10.0), u0=[1.0, 0.0], low_k_cutoff="none")
     assert S.apply_low_k_cutoff(rd, calc, pars_none, cs) == 0
     assert S.tconvert("ms", "s") == 1e-3 and S.tconvert(2.0, "mins", "s") == 120.0
+
+
+def test_insert_inert_topology():
+    """insert_inert! (solve_utils.jl:126-192): unimolecular reactions gain the inert species on both sides; one copy
+    per additional inert species; bimolecular reactions and 2A -> ... are left alone."""
+    sd = S.SpeciesData.from_names(["A", "B", "C"])
+    rd = S.RxData(3, [[1], [1, 2], [1]], [[2], [3], [2, 3]], [[1], [1, 1], [2]], [[1], [1], [1, 1]], dH=[0.1, 0.2, 0.3])
+    S.insert_inert(rd, sd, ["N#N"])
+    assert sd.n == 4 and sd.toInt["N#N"] == 4 and sd.toStr[4] == "N#N"
+    assert rd.nr == 3 and rd.id_reacs == [[1, 4], [1, 2], [1]] and rd.id_prods == [[2, 4], [3], [2, 3]]
+    assert rd.stoic_reacs == [[1, 1], [1, 1], [2]] and rd.stoic_prods == [[1, 1], [1], [1, 1]]
+    # two inert species, one of them already in the network: a copy for the first, the original takes the last
+    sd = S.SpeciesData.from_names(["A", "B", "Ar"])
+    rd = S.RxData(1, [[1]], [[2]], [[1]], [[1]], dH=[0.5])
+    S.insert_inert(rd, sd, ["Ar", "He"])
+    assert sd.n == 4 and rd.nr == 2 and rd.dH == [0.5, 0.5]
+    assert rd.id_reacs == [[1, 4], [1, 3]] and rd.id_prods == [[2, 4], [2, 3]]
