@@ -594,11 +594,8 @@ template <int TR, int ILP, bool BLK>
 static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B, int tile, const void* rec64,
                                const int32_t* copy_species, int n_copy, const double* u, const double* k_b, const double* k_1,
                                double* du, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
+  KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP, BLK>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64,
                      copy_species, n_copy, u, k_b, k_1, du);
 }
@@ -862,11 +859,8 @@ static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int 
                                const int32_t* expl, int n_expl, const void* pair_k, const int32_t* spec_of_label,
                                const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
                                const double* k_1, double* du, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    KIN_HIP(hipFuncSetAttribute((const void*)sweep_big_kernel<ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
+  KIN_HIP(hipFuncSetAttribute((const void*)sweep_big_kernel<ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * (H + SWEEP_DUMMY) * 8, s, N, R, P, B, H,
                      n_tail_tiles, (const uint2*)rec8, (const SweepRec*)rec, expl, n_expl, (const int2*)pair_k, spec_of_label,
                      tail_ptr, (const uint2*)tail_ent, scratch, u, k_b, k_1, du);
@@ -888,11 +882,8 @@ void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent,
 template <bool U_IN_LDS, bool ADJ>
 static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, int tile, int n_tiles, const void* rec,
                            const void* pair_k, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    KIN_HIP(hipFuncSetAttribute((const void*)sweep_lds_kernel<U_IN_LDS, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
+  KIN_HIP(hipFuncSetAttribute((const void*)sweep_lds_kernel<U_IN_LDS, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((sweep_lds_kernel<U_IN_LDS, ADJ>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, n_tiles,
                      (const SweepRec*)rec, (const int2*)pair_k, u, k_b, k_1, du);
 }
@@ -941,11 +932,8 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, boo
       return;
     }
     if (gen_rec8 && (size_t)(2 * (N + SWEEP_DUMMY)) * 8 <= lds_max) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        KIN_HIP(hipFuncSetAttribute((const void*)sweep_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-      }
+      // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
+      KIN_HIP(hipFuncSetAttribute((const void*)sweep_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       const int gtile = (int)N + SWEEP_DUMMY;
       hipLaunchKernelGGL(sweep_gen_kernel, dim3(grid), dim3(1024), (size_t)2 * gtile * 8, s, (int)N, (int)R, (int)P, (int)B, gtile,
                          (const uint2*)gen_rec8, (const int2*)pair_k, (const SweepRec*)rec, gen_expl, n_gen_expl, u, k_b, k_1, du);
