@@ -135,12 +135,21 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
     if (blockIdx.x != 0 || kn >= nblk) return;
     const int n0 = kn * GJ_NB;                           // next pivot block: rows/cols n0..n0+31 (never pivot rows/cols of step kb)
     const int rb = w >> 1, cb = w & 1;
+    // every global operand of this workgroup is requested up front (one load latency instead of two: the
+    // look-ahead is the critical path of the launch)
+    double pa[8], xb[8], xa[8], xd[4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      pa[ks] = pinv[(16 * rb + li) * GJ_NB + 4 * ks + lk];
+      xb[ks] = X[(size_t)(kr0 + 4 * ks + lk) * ld + n0 + 16 * cb + li];
+      xa[ks] = X[(size_t)(n0 + 16 * rb + li) * ld + kr0 + 4 * ks + lk];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) xd[v] = X[(size_t)(n0 + 16 * rb + 4 * v + lk) * ld + n0 + 16 * cb + li];
     {  // RP[0:32][0:32] = P * X[k rows, n0 + cols]
       gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 8; ks++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pinv[(16 * rb + li) * GJ_NB + 4 * ks + lk],
-                                                   X[(size_t)(kr0 + 4 * ks + lk) * ld + n0 + 16 * cb + li], acc, 0, 0, 0);
+      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks], xb[ks], acc, 0, 0, 0);
 #pragma unroll
       for (int v = 0; v < 4; v++) RP[16 * rb + 4 * v + lk][16 * cb + li] = acc[v];
     }
@@ -148,14 +157,9 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
     {  // A[0] = X[n0 rows, n0 cols] - X[n0 rows, k cols] * RP
       gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 8; ks++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(size_t)(n0 + 16 * rb + li) * ld + kr0 + 4 * ks + lk],
-                                                   RP[4 * ks + lk][16 * cb + li], acc, 0, 0, 0);
+      for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], RP[4 * ks + lk][16 * cb + li], acc, 0, 0, 0);
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int i = 16 * rb + 4 * v + lk, j = 16 * cb + li;
-        A[0][i][j] = X[(size_t)(n0 + i) * ld + n0 + j] - acc[v];
-      }
+      for (int v = 0; v < 4; v++) A[0][16 * rb + 4 * v + lk][16 * cb + li] = xd[v] - acc[v];
     }
     __syncthreads();
     gj_invert_block_lds(A, pinv_next);
