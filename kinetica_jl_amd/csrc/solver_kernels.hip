@@ -239,8 +239,17 @@ __global__ __launch_bounds__(256) void gemv_kernel(const double* __restrict__ S,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const double* a = S + (size_t)row * ld;
-  double acc = 0.0;
-  for (int j = lane; j < m; j += 64) acc += a[j] * y[j];
+  // four independent partial sums per lane: all loads of a trip are in flight together (the row is read once,
+  // the kernel is one dependent-latency chain per row otherwise); fixed order -> bitwise reproducible
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  int j = lane;
+  for (; j + 192 < m; j += 256) {
+    const double a0 = a[j], a1 = a[j + 64], a2 = a[j + 128], a3 = a[j + 192];
+    const double y0 = y[j], y1 = y[j + 64], y2 = y[j + 128], y3 = y[j + 192];
+    acc0 += a0 * y0; acc1 += a1 * y1; acc2 += a2 * y2; acc3 += a3 * y3;
+  }
+  for (; j < m; j += 64) acc0 += a[j] * y[j];
+  double acc = (acc0 + acc1) + (acc2 + acc3);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0 && !sk) x[row] = acc;
