@@ -467,8 +467,8 @@ __device__ __forceinline__ double2 load_kpair(const double* __restrict__ kb, int
 
 // TR = records per thread kept in registers (compile time, fully unrolled); records beyond
 // TR*1024 are streamed as 8-byte words. ILP = records whose loads are issued together.
-template <int TR, int ILP, bool BLK>
-__global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, int B, int tile,
+template <int TR, int ILP, bool BLK, int BS>
+__global__ __launch_bounds__(BS) void sweep_reg_kernel(int N, int R, int P, int B, int tile,
                                                          const uint2* __restrict__ rec64, const int32_t* __restrict__ copy_species,
                                                          int n_copy, const double* __restrict__ u,
                                                          const double* __restrict__ k_b, const double* __restrict__ k_1,
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   double* du_s = lds;
   double* u_s = lds + tile;
   const int tid = threadIdx.x;
-  constexpr int UPT = 5;            // double2 per thread of the staged state (N <= 10240)
+  constexpr int UPT = 5;            // double2 per thread of the staged state (N <= BS0)
   // padding record of this lane: all four fields on the lane's dummy entry
   const uint64_t dl = (uint64_t)N + (uint64_t)(tid & 63);
   const uint64_t ew = dl | (dl << 14) | (dl << 28) | (dl << 42);
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   uint2 rc[TR > 0 ? TR : 1];
 #pragma unroll
   for (int i = 0; i < TR; i++) {
-    const int p = tid + i * 1024;
+    const int p = tid + i * BS;
     rc[i] = p < P ? rec64[p] : EMPTY;
   }
   // software pipeline over states: the next state's u travels HBM -> registers while this state's
@@ -498,10 +498,10 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   int b = blockIdx.x;
 #pragma unroll
   for (int x = 0; x < UPT; x++) {
-    const int i = (tid + x * 1024) * 2;
+    const int i = (tid + x * BS) * 2;
     un[x] = (b < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)b * N + i) : make_double2(0.0, 0.0);
   }
-  for (int i = tid * 2; i < N; i += 2048) *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
+  for (int i = tid * 2; i < N; i += (2 * BS)) *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
   double ucn = (csp >= 0 && b < B) ? u[(size_t)b * N + csp] : 0.0;
   // the first batch of rate constants of a state is requested before the previous state's barrier /
   // write-out / staging, so the k stream does not drain at state boundaries
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
 #pragma unroll
     for (int x = 0; x < ILP; x++) {
-      const int p = tid + x * 1024;
+      const int p = tid + x * BS;
       k0[x] = (b < B && p < P) ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
     }
   }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
     double* dub = du + (size_t)b * N;
 #pragma unroll
     for (int x = 0; x < UPT; x++) {
-      const int i = (tid + x * 1024) * 2;
+      const int i = (tid + x * BS) * 2;
       if (i < N) *reinterpret_cast<double2*>(u_s + i) = un[x];
     }
     if (csp >= 0) u_s[N + SWEEP_DUMMY + tid] = ucn;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
     ucn = (csp >= 0 && bn < B) ? u[(size_t)bn * N + csp] : 0.0;
 #pragma unroll
     for (int x = 0; x < UPT; x++) {
-      const int i = (tid + x * 1024) * 2;
+      const int i = (tid + x * BS) * 2;
       un[x] = (bn < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)bn * N + i) : make_double2(0.0, 0.0);
     }
     // register-resident records
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       double2 kk[ILP];
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        const int p = tid + (i0 + x) * 1024;
+        const int p = tid + (i0 + x) * BS;
         if (KPRE && i0 == 0) kk[x] = k0[x];
         else kk[x] = p < P ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
       }
@@ -552,12 +552,12 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       }
     }
     // streamed records
-    for (int p0 = tid + TR * 1024; p0 < P; p0 += 1024 * ILP) {
+    for (int p0 = tid + TR * BS; p0 < P; p0 += BS * ILP) {
       double2 kk[ILP];
       uint2 w[ILP];
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        const int p = p0 + x * 1024;
+        const int p = p0 + x * BS;
         const bool ok = p < P;
         kk[x] = ok ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
         w[x] = ok ? rec64[p] : EMPTY;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       const double* kn = k_b ? k_b + (size_t)bn * R : k_1;
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        const int p = tid + x * 1024;
+        const int p = tid + x * BS;
         k0[x] = (bn < B && p < P) ? load_kpair<BLK>(kn, p, P) : make_double2(0.0, 0.0);
       }
     }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
       }
       __syncthreads();
     }
-    for (int i = tid * 2; i < N; i += 2048) {
+    for (int i = tid * 2; i < N; i += (2 * BS)) {
       *reinterpret_cast<double2*>(dub + i) = *reinterpret_cast<double2*>(du_s + i);
       *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
     }
@@ -590,13 +590,13 @@ __global__ __launch_bounds__(1024) void sweep_reg_kernel(int N, int R, int P, in
   }
 }
 
-template <int TR, int ILP, bool BLK>
+template <int TR, int ILP, bool BLK, int BS>
 static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B, int tile, const void* rec64,
                                const int32_t* copy_species, int n_copy, const double* u, const double* k_b, const double* k_1,
                                double* du, hipStream_t s) {
   // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
-  KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP, BLK>), dim3(grid), dim3(1024), smem, s, N, R, P, B, tile, (const uint2*)rec64,
+  KIN_HIP(hipFuncSetAttribute((const void*)sweep_reg_kernel<TR, ILP, BLK, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((sweep_reg_kernel<TR, ILP, BLK, BS>), dim3(grid), dim3(BS), smem, s, N, R, P, B, tile, (const uint2*)rec64,
                      copy_species, n_copy, u, k_b, k_1, du);
 }
 
@@ -912,15 +912,22 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, boo
     // register-resident path: reactions paired as (2p, 2p+1) [adjacent] or (p, P+p) [block]
     if ((adj || block) && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 &&
         (size_t)(2 * (N + SWEEP_DUMMY + n_copy)) * 8 <= lds_max && n_copy <= 1024) {
-      const int64_t T = P / 1024;   // full record rows available for residency
       const int rtile = (int)N + SWEEP_DUMMY + n_copy + (n_copy & 1);   // even: keeps u_s 16-byte aligned
       const size_t rsmem = (size_t)2 * rtile * 8;
-#define KIN_REG_GO(TT, II)                                                                                                             \
-  do {                                                                                                                                 \
-    if (adj) launch_sweep_reg_t<TT, II, false>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s); \
-    else launch_sweep_reg_t<TT, II, true>(grid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s);   \
+      // smaller states run in smaller workgroups, several per CU (LDS permitting): more states in flight per CU and
+      // enough records per thread to keep them register-resident (C2, N = 1000: 0.073 -> 0.050 ms)
+      const int bs = (N <= 2560 && n_copy <= 256) ? 256 : ((N <= 5120 && n_copy <= 512) ? 512 : 1024);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / bs, lds_max / rsmem));
+      const int rgrid = (int)std::min<int64_t>(B, (int64_t)n_cu * per_cu);
+      const int64_t Tr = P / bs;   // full record rows available for residency
+#define KIN_REG_ARGS rgrid, rsmem, (int)N, (int)R, (int)P, (int)B, rtile, rec64, copy_species, n_copy, u, k_b, k_1, du, s
+#define KIN_REG_GO(TT, II)                                                                   \
+  do {                                                                                       \
+    if (bs == 256) { if (adj) launch_sweep_reg_t<TT, II, false, 256>(KIN_REG_ARGS); else launch_sweep_reg_t<TT, II, true, 256>(KIN_REG_ARGS); }   \
+    else if (bs == 512) { if (adj) launch_sweep_reg_t<TT, II, false, 512>(KIN_REG_ARGS); else launch_sweep_reg_t<TT, II, true, 512>(KIN_REG_ARGS); } \
+    else { if (adj) launch_sweep_reg_t<TT, II, false, 1024>(KIN_REG_ARGS); else launch_sweep_reg_t<TT, II, true, 1024>(KIN_REG_ARGS); }       \
   } while (0)
-      const int want = (int)std::min<int64_t>(use_reg, T);
+      const int want = (int)std::min<int64_t>(use_reg, Tr);
       if (want >= 16) KIN_REG_GO(16, 4);
       else if (want >= 12) KIN_REG_GO(12, 4);
       else if (want >= 8) KIN_REG_GO(8, 4);
@@ -928,6 +935,7 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, boo
       else if (use_reg == 1) KIN_REG_GO(0, 8);
       else KIN_REG_GO(0, 4);
 #undef KIN_REG_GO
+#undef KIN_REG_ARGS
       KIN_HIP(hipGetLastError());
       return;
     }
