@@ -610,7 +610,8 @@ static void launch_sweep_reg_t(int grid, size_t smem, int N, int R, int P, int B
 // decoding loop of sweep_lds_kernel for this case (C3 CRN minus a random 30 % of its reactions, B = 4096:
 // 0.66 ms -> 0.52 ms, tools/unpaired_sweep.py).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sweep_gen_kernel(int N, int R, int P, int B, int tile, const uint2* __restrict__ rec8,
+template <int BS>
+__global__ __launch_bounds__(BS) void sweep_gen_kernel(int N, int R, int P, int B, int tile, const uint2* __restrict__ rec8,
                                                          const int2* __restrict__ pair_k, const SweepRec* __restrict__ rec,
                                                          const int32_t* __restrict__ expl, int n_expl,
                                                          const double* __restrict__ u, const double* __restrict__ k_b,
@@ -623,29 +624,29 @@ __global__ __launch_bounds__(1024) void sweep_gen_kernel(int N, int R, int P, in
   const uint32_t dl = (uint32_t)(N + (tid & 63));
   const uint2 EMPTY = {dl | (dl << 16), dl | (dl << 16)};
   if (tid < SWEEP_DUMMY) { u_s[N + tid] = 1.0; du_s[N + tid] = 0.0; }
-  for (int i = tid; i < N; i += 1024) du_s[i] = 0.0;
+  for (int i = tid; i < N; i += BS) du_s[i] = 0.0;
   // the next state's u travels HBM -> registers while this state's records are processed (N <= 10176)
   constexpr int UPT = 10;
   double un[UPT];
   int b = blockIdx.x;
 #pragma unroll
-  for (int x = 0; x < UPT; x++) { const int i = tid + x * 1024; un[x] = (b < B && i < N) ? u[(size_t)b * N + i] : 0.0; }
+  for (int x = 0; x < UPT; x++) { const int i = tid + x * BS; un[x] = (b < B && i < N) ? u[(size_t)b * N + i] : 0.0; }
   for (; b < B; b += gridDim.x) {
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
     double* dub = du + (size_t)b * N;
 #pragma unroll
-    for (int x = 0; x < UPT; x++) { const int i = tid + x * 1024; if (i < N) u_s[i] = un[x]; }
+    for (int x = 0; x < UPT; x++) { const int i = tid + x * BS; if (i < N) u_s[i] = un[x]; }
     __syncthreads();
     const int bn = b + gridDim.x;
 #pragma unroll
-    for (int x = 0; x < UPT; x++) { const int i = tid + x * 1024; un[x] = (bn < B && i < N) ? u[(size_t)bn * N + i] : 0.0; }
-    for (int qq = tid; qq < P; qq += 1024 * ILP) {
+    for (int x = 0; x < UPT; x++) { const int i = tid + x * BS; un[x] = (bn < B && i < N) ? u[(size_t)bn * N + i] : 0.0; }
+    for (int qq = tid; qq < P; qq += BS * ILP) {
       uint2 w[ILP];
       int2 ki[ILP];
       double kf[ILP], kr[ILP];
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        const int p = qq + x * 1024;
+        const int p = qq + x * BS;
         w[x] = p < P ? rec8[p] : EMPTY;
         ki[x] = p < P ? pair_k[p] : make_int2(-1, -1);
       }
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(1024) void sweep_gen_kernel(int N, int R, int P, in
       }
     }
     // reactions with a species on both sides: net = kf u[a] u[c], coefficients from the 16-byte record
-    for (int i = tid; i < n_expl; i += 1024) {
+    for (int i = tid; i < n_expl; i += BS) {
       const int p = expl[i];
       const SweepRec q = rec[p];
       const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(1024) void sweep_gen_kernel(int N, int R, int P, in
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    for (int i = tid; i < N; i += 1024) { dub[i] = du_s[i]; du_s[i] = 0.0; }
+    for (int i = tid; i < N; i += BS) { dub[i] = du_s[i]; du_s[i] = 0.0; }
     // no barrier needed here: the next trip only touches u_s before its own barrier
   }
 }
@@ -940,11 +941,21 @@ void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, boo
       return;
     }
     if (gen_rec8 && (size_t)(2 * (N + SWEEP_DUMMY)) * 8 <= lds_max) {
-      // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
-      KIN_HIP(hipFuncSetAttribute((const void*)sweep_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       const int gtile = (int)N + SWEEP_DUMMY;
-      hipLaunchKernelGGL(sweep_gen_kernel, dim3(grid), dim3(1024), (size_t)2 * gtile * 8, s, (int)N, (int)R, (int)P, (int)B, gtile,
-                         (const uint2*)gen_rec8, (const int2*)pair_k, (const SweepRec*)rec, gen_expl, n_gen_expl, u, k_b, k_1, du);
+      const size_t gsmem = (size_t)2 * gtile * 8;
+      const int bs = N <= 2560 ? 256 : (N <= 5120 ? 512 : 1024);     // smaller states: smaller workgroups, several per CU
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / bs, lds_max / gsmem));
+      const int ggrid = (int)std::min<int64_t>(B, (int64_t)n_cu * per_cu);
+#define KIN_GEN_GO(BSZ)                                                                                                                 \
+  do {                                                                                                                                  \
+    KIN_HIP(hipFuncSetAttribute((const void*)sweep_gen_kernel<BSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+    hipLaunchKernelGGL(sweep_gen_kernel<BSZ>, dim3(ggrid), dim3(BSZ), gsmem, s, (int)N, (int)R, (int)P, (int)B, gtile,                  \
+                       (const uint2*)gen_rec8, (const int2*)pair_k, (const SweepRec*)rec, gen_expl, n_gen_expl, u, k_b, k_1, du);       \
+  } while (0)
+      if (bs == 256) KIN_GEN_GO(256);
+      else if (bs == 512) KIN_GEN_GO(512);
+      else KIN_GEN_GO(1024);
+#undef KIN_GEN_GO
       KIN_HIP(hipGetLastError());
       return;
     }
