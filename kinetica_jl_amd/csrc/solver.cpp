@@ -20,6 +20,7 @@
 #include "solver.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <functional>
@@ -102,13 +103,20 @@ struct Solver {
     red.alloc((size_t)5 * bdf_reduce_blocks(N));
     KIN_HIP(hipMemsetAsync(ctrl.p, 0, sizeof(BdfCtrl), s));
     KIN_HIP(hipHostMalloc((void**)&hc, sizeof(BdfCtrl), hipHostMallocDefault));
+    KIN_HIP(hipHostMalloc((void**)&hseq, sizeof(unsigned long long), hipHostMallocDefault));
+    *hseq = 0;
+    if (hipHostGetDevicePointer((void**)&hc_dev, hc, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&hseq_dev, hseq, 0) != hipSuccess || getenv("KIN_NO_FAST_SYNC")) {
+      (void)hipGetLastError();
+      fast_sync = false; hc_dev = nullptr; hseq_dev = nullptr;
+    }
     cf.gamma[0] = 0.0;
     for (int j = 1; j <= BDF_MAX_ORDER; j++) cf.gamma[j] = cf.gamma[j - 1] + 1.0 / j;
     for (int j = 0; j <= BDF_MAX_ORDER; j++) cf.alpha[j] = (1.0 - KAPPA[j]) * cf.gamma[j];
     for (int j = 0; j <= BDF_MAX_ORDER; j++) cf.error_const[j] = KAPPA[j] * cf.gamma[j] + 1.0 / (j + 1);
     cf.error_const[BDF_MAX_ORDER + 1] = 0.0;
   }
-  ~Solver() { if (hc) (void)hipHostFree(hc); }
+  ~Solver() { if (hc) (void)hipHostFree(hc); if (hseq) (void)hipHostFree(hseq); }
 
   void set_tols(double a, double r) {
     atol = a; rtol = r;
@@ -117,7 +125,30 @@ struct Solver {
     newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, 0.05);
   }
 
+  // step-end hand-over without a stream synchronisation: the error kernel publishes the control block into
+  // pinned host memory and bumps `*hseq`; the host spins on it (bounded), else falls back to sync_ctrl()
+  unsigned long long* hseq = nullptr;
+  BdfCtrl* hc_dev = nullptr;                // device-side address of hc
+  unsigned long long* hseq_dev = nullptr;
+  unsigned long long seq_no = 0;
+  bool fast_sync = true;
   double sync_wait_s = 0.0;   // host time spent blocked in sync_ctrl (diagnostic, KIN_TIMING=1)
+  void wait_ctrl(unsigned long long want) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (fast_sync) {
+      for (unsigned spins = 0;; spins++) {
+        if (*(volatile unsigned long long*)hseq == want) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          return;
+        }
+        if ((spins & 1023) == 1023 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) break;   // not seen: fall back
+      }
+    }
+    sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    sync_ctrl();
+  }
   int64_t iter_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // corrector iterations executed per converged attempt (diagnostic)
   void sync_ctrl() {
     KIN_HIP(hipMemcpyAsync(hc, ctrl.p, sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
@@ -336,13 +367,13 @@ struct Solver {
         launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
         newton_iteration(0, c);
         newton_iteration(1, c);
-        launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, s);
-        sync_ctrl();
+        launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
+        wait_ctrl(seq_no);
         if (!hc->newton_done) {
           newton_iteration(2, c);
           newton_iteration(3, c);
-          launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, s);
-          sync_ctrl();
+          launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
+          wait_ctrl(seq_no);
         }
         converged = hc->newton_done && hc->converged && !hc->nonfinite;
         if (converged) break;

@@ -399,10 +399,21 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
 
 __global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const double* __restrict__ D, const double* __restrict__ y,
                                                         const double* __restrict__ d, double atol, double rtol, BdfCoef cf,
-                                                        BdfCtrl* ctrl, double* __restrict__ part) {
+                                                        BdfCtrl* ctrl, double* __restrict__ part, BdfCtrl* host_ctrl,
+                                                        unsigned long long* host_seq, unsigned long long seq) {
   __shared__ double sh[4];
   __shared__ int last;
-  if (!ctrl->newton_done || !ctrl->converged) return;
+  // The attempt ends with this kernel: its last action publishes the control block straight into pinned host
+  // memory and bumps a sequence number the host spins on - no D2H copy, no stream synchronisation on the
+  // step's critical path (the host falls back to both if the number does not show up).
+  if (!ctrl->newton_done || !ctrl->converged) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && host_ctrl) {
+      *host_ctrl = *ctrl;
+      __threadfence_system();
+      *(volatile unsigned long long*)host_seq = seq;
+    }
+    return;
+  }
   const int G = gridDim.x;
   double se = 0.0, sm = 0.0, sp = 0.0;
   int neg = 0, bad = 0;
@@ -442,6 +453,11 @@ __global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const 
     ctrl->err_p_norm = sqrt(sum_partials(part + 2 * G, G) / (double)N);
     ctrl->any_negative = sum_partials(part + 3 * G, G) > 0.0;
     if (sum_partials(part + 4 * G, G) > 0.0) ctrl->nonfinite = 1;
+    if (host_ctrl) {
+      *host_ctrl = *ctrl;
+      __threadfence_system();
+      *(volatile unsigned long long*)host_seq = seq;
+    }
   }
 }
 
@@ -598,8 +614,10 @@ void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xl
   hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, ctrl, part);
 }
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
-                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl, part);
+                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
+                      unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl, part,
+                     host_ctrl, host_seq, seq);
 }
 void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s) {
   hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d);

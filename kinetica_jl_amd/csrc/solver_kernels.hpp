@@ -31,7 +31,8 @@ void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, do
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
                        double* y, double* d, BdfCtrl* ctrl, double* part, hipStream_t s);
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
-                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, hipStream_t s);
+                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
+                      unsigned long long seq, hipStream_t s);   // host_ctrl / host_seq: device-visible pinned host memory (or null)
 // `part`: 5 * bdf_reduce_blocks(N) doubles of partial sums shared by the two reductions above
 int bdf_reduce_blocks(int N);
 void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s);
