@@ -291,8 +291,8 @@ struct Solver {
       rhs(rk_ynew.p, rk_K.p + (size_t)6 * N);
       RkVec e;
       for (int j = 0; j < 7; j++) e.v[j] = hh * E[j];
-      launch_rk_error(N, e, D.p, rk_ynew.p, rk_K.p, atol, rtol, ctrl.p, red.p, s);
-      sync_ctrl();
+      launch_rk_error(N, e, D.p, rk_ynew.p, rk_K.p, atol, rtol, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
+      wait_ctrl(seq_no);
       if (hc->nonfinite) {
         // SciPy would propagate the NaN; here a non-finite stage is treated like a failed step (halve)
         h_abs *= 0.5; rejected = true; st.n_rejected++;

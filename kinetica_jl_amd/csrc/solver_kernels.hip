@@ -523,7 +523,8 @@ __global__ __launch_bounds__(256) void rk_combine_kernel(int N, int n, RkVec w, 
 // err_norm = rms( (sum_j e[j] K[j]) / (atol + rtol max(|y|, |y_new|)) ), flags for NaN / negative entries
 __global__ __launch_bounds__(256) void rk_error_kernel(int N, RkVec e, const double* __restrict__ y, const double* __restrict__ y_new,
                                                        const double* __restrict__ K, double atol, double rtol, BdfCtrl* ctrl,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
+                                                       unsigned long long seq) {
   __shared__ double sh[4];
   __shared__ int last;
   const int G = gridDim.x;
@@ -547,6 +548,11 @@ __global__ __launch_bounds__(256) void rk_error_kernel(int N, RkVec e, const dou
     ctrl->err_norm = sqrt(sum_partials(part, G) / (double)N);
     ctrl->any_negative = sum_partials(part + G, G) > 0.0;
     ctrl->nonfinite = sum_partials(part + 2 * G, G) > 0.0 || !isfinite(ctrl->err_norm);
+    if (host_ctrl) {   // step-end hand-over through pinned host memory (see bdf_error_kernel)
+      *host_ctrl = *ctrl;
+      __threadfence_system();
+      *(volatile unsigned long long*)host_seq = seq;
+    }
   }
 }
 
@@ -635,8 +641,10 @@ void launch_rk_combine(int N, int n, const RkVec& w, const double* y, const doub
   hipLaunchKernelGGL(rk_combine_kernel, GRID1(N), 0, s, N, n, w, y, K, out);
 }
 void launch_rk_error(int N, const RkVec& e, const double* y, const double* y_new, const double* K, double atol, double rtol,
-                     BdfCtrl* ctrl, double* part, hipStream_t s) {
-  hipLaunchKernelGGL(rk_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, e, y, y_new, K, atol, rtol, ctrl, part);
+                     BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(rk_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, e, y, y_new, K, atol, rtol, ctrl, part, host_ctrl,
+                     host_seq, seq);
 }
 void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s) {
   hipLaunchKernelGGL(axpy_out_kernel, GRID1(N), 0, s, N, a, sc, b, out);

@@ -41,7 +41,8 @@ void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, dou
 void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s);
 void launch_rk_combine(int N, int n, const RkVec& w, const double* y, const double* K, double* out, hipStream_t s);
 void launch_rk_error(int N, const RkVec& e, const double* y, const double* y_new, const double* K, double atol, double rtol,
-                     BdfCtrl* ctrl, double* part, hipStream_t s);
+                     BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq,
+                     hipStream_t s);
 void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s);
 void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s);
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s);
