@@ -526,3 +526,28 @@ def test_inert_collision_partner_n4():
     ref = np.stack([[-2.0 * x[0] * x[2] + 0.5 * x[1] * x[2], 2.0 * x[0] * x[2] - 0.5 * x[1] * x[2], 0.0] for x in U])
     np.testing.assert_allclose(got, ref, rtol=1e-14, atol=1e-300)
     h.close()
+
+
+def test_solve_network_with_explicit_solver_selection():
+    """`pars.solver = "RK45"` routes solve_network through kin_solve_explicit; same trajectories as the default
+    BDF within the solver tolerance; an unknown solver name is refused before anything runs."""
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    from kinetica_jl_amd.synth import narrow_k_variant
+    net, Ea, A = synthetic_crn(60, 300, seed=11)
+    sd = S.SpeciesData.from_names([f"S{i}" for i in range(60)])
+    out = {}
+    for name in (None, "RK45"):
+        rd = S.RxData.from_flat(net)
+        calc = S.PrecalculatedArrheniusCalculator(narrow_k_variant(Ea), A, k_max=1e3)
+        pars = S.ODESimulationParams(tspan=(0.0, 0.1), u0={"S0": 1.0}, solver=name, solve_chunkstep=0.05, save_interval=0.025,
+                                     abstol=1e-9, reltol=1e-7, low_k_cutoff="none")
+        out[name] = S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 900.0}), calc), sd, rd)
+        assert out[name].sol.retcode == "Success"
+    assert out["RK45"].sol.stats["n_factor"] == 0 and out[None].sol.stats["n_factor"] > 0
+    np.testing.assert_allclose(out["RK45"].sol.t, out[None].sol.t)
+    assert errscale(np.asarray(out["RK45"].sol.u), np.asarray(out[None].sol.u), 1e-9, 1e-7) < 100
+    pars = S.ODESimulationParams(tspan=(0.0, 0.1), u0={"S0": 1.0}, solver="Rodas5")
+    with pytest.raises(ValueError):
+        S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 900.0}), S.DummyKineticCalculator(np.ones(300))), sd,
+                        S.RxData.from_flat(net))
