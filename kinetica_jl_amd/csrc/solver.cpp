@@ -142,8 +142,10 @@ struct Solver {
           sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           return;
         }
+        // not seen within 50 ms (an attempt incl. a large factorisation takes a few ms at most): the platform does not
+        // make device writes to pinned host memory visible while the kernel runs - use the synchronising path from now on
         if ((spins & 1023) == 1023 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) break;   // not seen: fall back
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 50e-3) { fast_sync = false; break; }
       }
     }
     sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
