@@ -116,6 +116,12 @@ typedef struct kin_params {
   double solve_chunkstep;    /* 1e-3  */
   int64_t maxiters;          /* 100000 */
   double save_interval;      /* < 0 means `nothing` */
+  double dtmin;              /* minimum step size handed to the integrator; <= 0 selects the reference's own choice:
+                              * eps(solve_chunkstep) for chunkwise solves (methods.jl:232, 770), eps(tspan[end]) for
+                              * complete-timespan solves (methods.jl:164, 694). A step that merely STARTS below dtmin is
+                              * raised to it (CVodeSetMinStep semantics); a step pushed below it by the corrector or
+                              * the error test ends the attempt with KIN_RETCODE_DTLESSTHANMIN, which the retry loop
+                              * (adaptive_solve!, solve_utils.jl:376-424) answers with tighter tolerances. */
   /* `solver`, `jac`, `sparse`, `progress`, `u0`, `low_k_*`, `allow_short_u0` are consumed
    * by the host layer (the integrator is always the library's BDF with the analytic
    * sparse Jacobian). */
@@ -167,6 +173,10 @@ int kin_solve_continuous(kin_network* h, const kin_params* params, const double*
  * not part of an integrator (they belong to adaptive_solve!, solve_utils.jl:376-424). */
 int kin_integrator_init(kin_network* h, const kin_params* params, const double* u0, const double* tstops,
                         const double* T_stops, const double* k_table, int64_t n_stops);
+/* The same for continuous rate updates (methods.jl:363-458 with :445-449, and :461-653): the integrator re-evaluates
+ * the Arrhenius rates at T(t) of every step attempt, T(t) as in kin_solve_continuous. */
+int kin_integrator_init_continuous(kin_network* h, const kin_params* params, const double* u0, const double* t_nodes,
+                                   const double* T_nodes, int64_t n_nodes);
 /* step!(integ) x max_steps accepted steps (max_steps <= 0: solve!(integ), run to the end of the span);
  * rate updates fire when the time reaches a tstop (solve_utils.jl:435-509). steps_taken < max_steps
  * means the end of the span was reached or the integrator failed (see kin_integrator_state). */

@@ -23,7 +23,8 @@ SYMBOLS = [
     "kin_set_rates", "kin_get_rates", "kin_set_arrhenius", "kin_rates_at", "kin_arrhenius_eval",
     "kin_rate_table", "kin_rhs", "kin_rhs_batched", "kin_rhs_batched_dev",
     "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solve_explicit", "kin_solve_continuous", "kin_solution_size",
-    "kin_solution_copy", "kin_solution_max", "kin_integrator_init", "kin_integrator_step", "kin_integrator_state",
+    "kin_solution_copy", "kin_solution_max", "kin_integrator_init", "kin_integrator_init_continuous", "kin_integrator_step",
+    "kin_integrator_state",
     "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
 ]
 
@@ -33,7 +34,7 @@ class KinParams(ctypes.Structure):
     _fields_ = [("tspan0", c_double), ("tspan1", c_double), ("abstol", c_double), ("reltol", c_double),
                 ("adaptive_tols", c_int32), ("update_tols", c_int32), ("solve_chunks", c_int32),
                 ("ban_negatives", c_int32), ("solve_chunkstep", c_double), ("maxiters", c_int64),
-                ("save_interval", c_double)]
+                ("save_interval", c_double), ("dtmin", c_double)]
 
 
 class KinStats(ctypes.Structure):
@@ -89,6 +90,7 @@ def lib():
         L.kin_solve_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64, P64, POINTER(c_int32),
                                            POINTER(KinStats)]
         L.kin_integrator_init.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64]
+        L.kin_integrator_init_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64]
         L.kin_integrator_step.argtypes = [c_void_p, c_int64, P64]
         L.kin_integrator_state.argtypes = [c_void_p, PD, PD, POINTER(c_int32), POINTER(KinStats)]
         L.kin_solution_size.argtypes = [c_void_p, P64, P64]
@@ -287,6 +289,13 @@ class HipNetwork:
             k_table = _f64(k_table) if k_table is not None else None
         self._chk(lib().kin_integrator_init(self._h, ctypes.byref(params), _pd(u0), _pd(tstops), _pd(T_stops),
                                             _pd(k_table), n_stops))
+
+    def integrator_init_continuous(self, params: KinParams, u0, t_nodes, T_nodes):
+        """kin_integrator_init_continuous: the integrator of a continuous-rate solve (k(t) = Arrhenius(T(t)))."""
+        u0, t_nodes, T_nodes = _f64(u0), _f64(t_nodes), _f64(T_nodes)
+        assert len(u0) == self.n and len(t_nodes) == len(T_nodes)
+        self._chk(lib().kin_integrator_init_continuous(self._h, ctypes.byref(params), _pd(u0), _pd(t_nodes), _pd(T_nodes),
+                                                       len(t_nodes)))
 
     def integrator_step(self, max_steps=1):
         """step!(integ) x max_steps (<= 0: solve!(integ)); returns the number of accepted steps taken."""

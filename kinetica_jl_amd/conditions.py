@@ -128,7 +128,10 @@ class AbstractGradientProfile(AbstractVariableProfile):
             X[0] = x
             for i in range(1, len(ts)):
                 a0, b0 = ts[i - 1], ts[i]
-                cuts = [a0] + [c for c in kinks if a0 < c < b0] + [b0]
+                # kinks strictly inside (a0, b0): none when every stop is a grid point (the usual case, `ts` contains the
+                # stops); found by bisection on the sorted kinks, not by a scan (C4 has 14 001 stops x 15 000 intervals)
+                lo, hi = np.searchsorted(kinks, a0, side="right"), np.searchsorted(kinks, b0, side="left")
+                cuts = [a0] + list(kinks[lo:hi]) + [b0]
                 for a, b in zip(cuts[:-1], cuts[1:]):
                     if b > a:
                         e = (b - a) * 1e-9

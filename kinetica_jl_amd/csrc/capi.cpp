@@ -322,6 +322,16 @@ int kin_integrator_init(kin_network* h, const kin_params* params, const double* 
   KIN_CATCH(h)
 }
 
+int kin_integrator_init_continuous(kin_network* h, const kin_params* params, const double* u0, const double* t_nodes,
+                                   const double* T_nodes, int64_t n_nodes) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(params && u0, ERR_INVALID_ARG, "params / u0 is null");
+  require(n_nodes >= 2, ERR_INVALID_ARG, "need >= 2 (t, T) nodes");
+  integrator_init(h, *params, u0, nullptr, nullptr, nullptr, 0, t_nodes, T_nodes, n_nodes);
+  KIN_CATCH(h)
+}
+
 int kin_integrator_step(kin_network* h, int64_t max_steps, int64_t* steps_taken) {
   if (!h) return KIN_ERR_INVALID_ARG;
   KIN_TRY(h)

@@ -208,11 +208,11 @@ void launch_drates(int64_t R, const double* k, const double* u, const int32_t* x
 // Arrhenius: k = A exp(-Ea/(R T)) N_A t_mult, optionally capped 1/(1/k_max + 1/k)
 // (PrecalculatedArrheniusCalculator functor, src/solving/calculator.jl:223-232; constants.jl:4-5)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double arrhenius_one(double Ea, double A, double RT, int has_kmax, double inv_kmax, double t_mult) {
+__device__ __forceinline__ double arrhenius_one(double Ea, double A, double RT, int has_kmax, double k_max, double t_mult) {
   const double kr = A * exp(-Ea / RT) * 6.02214076e23 * t_mult;
-  // 1/(1/k_max + 1/k) evaluated as k / (1 + k/k_max): one IEEE division instead of two (the table
-  // kernel is FP64-VALU bound, not HBM bound); agrees with the two-division form to ~2 ulp
-  return has_kmax ? kr / fma(kr, inv_kmax, 1.0) : kr;
+  // the cap in the reference's own form 1/(1/k_max + 1/k_r) (calculator.jl:225): exact limits at both ends
+  // (k_r = inf -> k_max, k_r = 0 -> 0), where the cheaper k_r / (1 + k_r/k_max) gives NaN for an overflowing k_r
+  return has_kmax ? 1.0 / (1.0 / k_max + 1.0 / kr) : kr;
 }
 
 __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __restrict__ Ea, const double* __restrict__ A,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __r
                                                         double* __restrict__ k) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  k[i] = arrhenius_one(Ea[i], A[i], 8.314462618 * T, has_kmax, 1.0 / k_max, t_mult);
+  k[i] = arrhenius_one(Ea[i], A[i], 8.314462618 * T, has_kmax, k_max, t_mult);
 }
 
 // Table variant without IEEE divisions and with a lean exp (the table kernel is FP64-VALU bound: with two full

@@ -102,13 +102,15 @@ struct Solver {
     ctrl.alloc(1);
     red.alloc((size_t)5 * bdf_reduce_blocks(N));
     KIN_HIP(hipMemsetAsync(ctrl.p, 0, sizeof(BdfCtrl), s));
-    KIN_HIP(hipHostMalloc((void**)&hc, sizeof(BdfCtrl), hipHostMallocDefault));
-    KIN_HIP(hipHostMalloc((void**)&hseq, sizeof(unsigned long long), hipHostMallocDefault));
+    // the step-end hand-over needs device writes to become visible to the spinning host thread while the stream
+    // keeps running: fine-grained (coherent), device-mapped pinned memory
+    KIN_HIP(hipHostMalloc((void**)&hc, sizeof(BdfCtrl), hipHostMallocCoherent | hipHostMallocMapped));
+    KIN_HIP(hipHostMalloc((void**)&hseq, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
     *hseq = 0;
     if (hipHostGetDevicePointer((void**)&hc_dev, hc, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&hseq_dev, hseq, 0) != hipSuccess || getenv("KIN_NO_FAST_SYNC")) {
       (void)hipGetLastError();
-      fast_sync = false; hc_dev = nullptr; hseq_dev = nullptr;
+      fast_sync = false; fast_sync_allowed = false; hc_dev = nullptr; hseq_dev = nullptr;
     }
     cf.gamma[0] = 0.0;
     for (int j = 1; j <= BDF_MAX_ORDER; j++) cf.gamma[j] = cf.gamma[j - 1] + 1.0 / j;
@@ -131,7 +133,9 @@ struct Solver {
   BdfCtrl* hc_dev = nullptr;                // device-side address of hc
   unsigned long long* hseq_dev = nullptr;
   unsigned long long seq_no = 0;
-  bool fast_sync = true;
+  bool fast_sync = true, fast_sync_allowed = true;
+  int64_t n_sync_fallbacks = 0;   // step-end hand-overs that timed out and went through copy + stream sync (KIN_TIMING=1)
+  int sync_ok_streak = 0;
   double sync_wait_s = 0.0;   // host time spent blocked in sync_ctrl (diagnostic, KIN_TIMING=1)
   void wait_ctrl(unsigned long long want) {
     auto t0 = std::chrono::steady_clock::now();
@@ -145,11 +149,18 @@ struct Solver {
         // not seen within 50 ms (an attempt incl. a large factorisation takes a few ms at most): the platform does not
         // make device writes to pinned host memory visible while the kernel runs - use the synchronising path from now on
         if ((spins & 1023) == 1023 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 50e-3) { fast_sync = false; break; }
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 50e-3) {
+          fast_sync = false; n_sync_fallbacks++; sync_ok_streak = 0; break;
+        }
       }
     }
     sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     sync_ctrl();
+    // a slow wait may have been a one-off (first-launch code loading, a profiler, a preempted GPU): after 64
+    // synchronising hand-overs in a row whose sequence number DID arrive the fast path is tried again
+    if (fast_sync_allowed && !fast_sync && *(volatile unsigned long long*)hseq == want && ++sync_ok_streak >= 64) {
+      fast_sync = true; sync_ok_streak = 0;
+    }
   }
   int64_t iter_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // corrector iterations executed per converged attempt (diagnostic)
   void sync_ctrl() {
@@ -510,6 +521,15 @@ struct SaveBuf {
   void push_time(double t) { h->sol_t.push_back(t); h->n_saved++; }
 };
 
+// dtmin handed to the integrator: the caller's value, else what the reference passes - eps(solve_chunkstep) for
+// chunkwise solves (methods.jl:232, 770), eps(tspan[end]) for complete-timespan ones (methods.jl:164, 694);
+// Julia's eps(x) is the spacing of the doubles at x
+double resolve_dtmin(const kin_params& p) {
+  if (p.dtmin > 0.0) return p.dtmin;
+  const double x = std::fabs(p.solve_chunks != 0 ? p.solve_chunkstep : p.tspan1);
+  return std::nextafter(x, INF) - x;
+}
+
 // sets the handle's current rates for time-stop index si
 void apply_rates(kin_network* h, const double* T_stops, bool have_table, int64_t si) {
   const int64_t R = h->host.R;
@@ -568,6 +588,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   S.sync_wait_s = 0.0;
   std::fill(S.iter_hist, S.iter_hist + 8, 0);
   S.ban_negatives = p.ban_negatives != 0;
+  S.dtmin = resolve_dtmin(p);
   double abstol = p.abstol, reltol = p.reltol;
   S.set_tols(abstol, reltol);
 
@@ -592,9 +613,16 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     const int64_t cnt = (int64_t)std::floor(span_len / si + 1e-9) + 1;
     for (int64_t i = 0; i < cnt; i++) save_local.push_back(std::min(base + (double)i * si, last));
     if (!chunks && save_local.back() < last) save_local.push_back(last);  // save_end
-    if (chunks) save_local.back() = last;
+    // chunkwise: saveat_local = collect(0:save_interval:chunkstep) is a VECTOR, so the chunk end is saved only when it
+    // is a grid point; otherwise the chunk's last saved point lies before the chunk end (methods.jl:756-758, 829-846)
+    if (chunks && std::fabs(save_local.back() - last) <= 1e-9 * last) save_local.back() = last;
   }
   const int64_t L = (int64_t)save_local.size();
+  // true: the chunk end is the last local save point (the usual case). false (save_interval does not divide the
+  // chunk): the final chunk's last output is the dense-output value at its last local save point. (The reference
+  // then also restarts every chunk from integ.sol.u[end] = the state at that last SAVED point while labelling it
+  // as the chunk end - a defect that is not copied: chunks always continue from the state at the chunk end.)
+  const bool save_hits_end = chunks && L > 0 && save_local.back() == p.solve_chunkstep;
   if (chunks) sb.reserve((L - 1) * n_chunks + 1);
   else sb.reserve(has_save ? L : 1024);
 
@@ -706,7 +734,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
             const double t_abs = S.t >= seg_len ? seg_end : t_seg + S.t;   // chunk-local time reached
             // saves covered by this step
             if (L > 0) {
-              const int64_t last = chunks ? L - 1 : L;   // the chunk's last point is saved below
+              // the chunk's last local point: dropped except on the final chunk (methods.jl:829-846), where it is the
+              // chunk's end state (saved below) or, off the grid, a dense-output value
+              const int64_t last = (chunks && !(nc == n_chunks - 1 && !save_hits_end)) ? L - 1 : L;
               while (save_i < last && save_local[save_i] <= t_abs) {
                 sb.reserve(h->n_saved + 1);
                 S.interpolate(std::min(save_local[save_i] - t_seg, S.t), sb.row(h->n_saved));
@@ -730,7 +760,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
       if (!failed) {
         // all but the chunk's last save point go to the output, the last only on the final chunk
         // (methods.jl:829-846); its value is the state at the chunk end
-        if (chunks && nc == n_chunks - 1 && L > 1) save_state_now(save_local[L - 1]);
+        if (chunks && nc == n_chunks - 1 && L > 1 && save_hits_end) save_state_now(save_local[L - 1]);
         next_stop = stop_i;
         break;
       }
@@ -754,8 +784,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   S.st.lu_nnz = 2 * S.lu.nnzU + S.lu.ns + (int64_t)S.lu.m * S.lu.m;
   S.st.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   if (getenv("KIN_TIMING"))
-    fprintf(stderr, "[kin_solve] wall %.4f s, of which blocked in step syncs %.4f s (the rest is host-side enqueue)\n",
-            S.st.wall_seconds, S.sync_wait_s);
+    fprintf(stderr, "[kin_solve] wall %.4f s, of which blocked in step syncs %.4f s (the rest is host-side enqueue); "
+            "step-end hand-overs that fell back to copy + sync: %lld (fast path %s)\n",
+            S.st.wall_seconds, S.sync_wait_s, (long long)S.n_sync_fallbacks, S.fast_sync ? "on" : "off");
   if (getenv("KIN_TIMING"))
     fprintf(stderr, "[kin_solve] corrector iterations per converged attempt: 1:%lld 2:%lld 3:%lld 4:%lld\n", (long long)S.iter_hist[1],
             (long long)S.iter_hist[2], (long long)S.iter_hist[3], (long long)S.iter_hist[4]);
@@ -776,13 +807,31 @@ struct IntegratorState {
   double t_loc0 = 0, t_loc1 = 0, t_seg = 0, seg_end = 0;
   bool ends_at_stop = false;
   std::vector<double> tstops, T_stops;
+  std::vector<double> t_nodes, T_nodes;   // continuous rate updates: T(t) = linear interpolation of these (global time)
   int64_t stop_i = 0;
   int retcode = KIN_RETCODE_SUCCESS;
+  double T_of(double tg) const {
+    const int64_t n = (int64_t)t_nodes.size();
+    if (tg <= t_nodes[0]) return T_nodes[0];
+    if (tg >= t_nodes[n - 1]) return T_nodes[n - 1];
+    const int64_t i = std::upper_bound(t_nodes.begin(), t_nodes.end(), tg) - t_nodes.begin();
+    const double dt = t_nodes[i] - t_nodes[i - 1];
+    const double th = dt > 0 ? (tg - t_nodes[i - 1]) / dt : 1.0;
+    return (1.0 - th) * T_nodes[i - 1] + th * T_nodes[i];
+  }
 };
 
 void integrator_init(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
-                     const double* k_table, int64_t n_stops) {
+                     const double* k_table, int64_t n_stops, const double* t_nodes, const double* T_nodes, int64_t n_nodes) {
   const int64_t N = h->host.N, R = h->host.R;
+  const bool continuous = n_nodes > 0;
+  if (continuous) {
+    if (n_stops > 0) throw KinError(ERR_INVALID_ARG, "continuous and discrete rate updates are mutually exclusive");
+    if (!t_nodes || !T_nodes || n_nodes < 2) throw KinError(ERR_INVALID_ARG, "need >= 2 (t, T) nodes");
+    if (!h->has_arrhenius) throw KinError(ERR_STATE, "continuous rates need the Arrhenius parameters");
+    for (int64_t i = 1; i < n_nodes; i++)
+      if (!(t_nodes[i] >= t_nodes[i - 1])) throw KinError(ERR_INVALID_ARG, "t_nodes must be non-decreasing");
+  }
   if (!(p.tspan0 < p.tspan1)) throw KinError(ERR_INVALID_ARG, "Invalid time span");
   if (!(p.abstol > 0) || !(p.reltol > 0)) throw KinError(ERR_INVALID_ARG, "tolerances must be positive");
   const bool chunks = p.solve_chunks != 0;
@@ -798,7 +847,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
     if (!k_table && !h->has_arrhenius) throw KinError(ERR_STATE, "T_stops given but Arrhenius parameters were never set");
     for (int64_t i = 1; i < n_stops; i++)
       if (!(tstops[i] > tstops[i - 1])) throw KinError(ERR_INVALID_ARG, "tstops must be strictly increasing");
-  } else if (!h->has_rates) {
+  } else if (!continuous && !h->has_rates) {
     throw KinError(ERR_STATE, "rates were never set");
   }
   if (!h->solver) h->solver.reset(new Solver(h));
@@ -809,6 +858,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
   S.st = kin_stats{};
   S.explicit_mode = false;
   S.ban_negatives = p.ban_negatives != 0;
+  S.dtmin = resolve_dtmin(p);
   S.set_tols(p.abstol, p.reltol);
   S.pre_attempt = nullptr;
   S.iters_left = p.maxiters;
@@ -818,6 +868,11 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
   if (variable) {
     I.tstops.assign(tstops, tstops + n_stops);
     if (T_stops) I.T_stops.assign(T_stops, T_stops + n_stops);
+  }
+  if (continuous) {
+    I.t_nodes.assign(t_nodes, t_nodes + n_nodes);
+    I.T_nodes.assign(T_nodes, T_nodes + n_nodes);
+    h->has_rates = true;
   }
   I.t_loc0 = chunks ? 0.0 : p.tspan0;
   I.t_loc1 = chunks ? p.solve_chunkstep : p.tspan1;
@@ -840,11 +895,19 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
   hipStream_t s = h->stream;
   const int64_t N = h->host.N;
   int64_t taken = 0;
+  // continuous rate updates: the Arrhenius rates are re-evaluated at T(global time) of every step attempt, as in
+  // solve_entry (the integrator's span starts at global time t_loc0, its segments run in local time)
+  if (!I.t_nodes.empty())
+    S.pre_attempt = [h, &I, s](double tau) {
+      launch_arrhenius(h->host.R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, I.T_of(I.t_seg + tau), h->k.p, s);
+    };
+  struct ClearHook { Solver& S; ~ClearHook() { S.pre_attempt = nullptr; } } clear_hook{S};
   while (I.retcode == KIN_RETCODE_SUCCESS && I.t_seg < I.t_loc1 && (max_steps <= 0 || taken < max_steps)) {
     if (!I.in_segment) {
       I.seg_end = I.t_loc1;
       I.ends_at_stop = false;
       if (I.stop_i < (int64_t)I.tstops.size() && I.tstops[I.stop_i] < I.t_loc1) { I.seg_end = I.tstops[I.stop_i]; I.ends_at_stop = true; }
+      if (S.pre_attempt) S.pre_attempt(0.0);   // rates at the segment start for f0 / J of the restart
       if (!S.restart(0.0, I.seg_end - I.t_seg)) { I.retcode = KIN_RETCODE_UNSTABLE; break; }
       I.in_segment = true;
     }

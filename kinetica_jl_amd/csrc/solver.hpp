@@ -13,7 +13,8 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
                 bool explicit_solver = false);   // explicit: Dormand-Prince 5(4) instead of the BDF (kin_solve_explicit)
 // return_integrator=true: initialise / advance / inspect the integrator without solving (solver.cpp)
 void integrator_init(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
-                     const double* k_table, int64_t n_stops);
+                     const double* k_table, int64_t n_stops, const double* t_nodes = nullptr, const double* T_nodes = nullptr,
+                     int64_t n_nodes = 0);   // n_nodes > 0: continuous rate updates (kin_integrator_init_continuous)
 int64_t integrator_step(kin_network* h, int64_t max_steps);
 void integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, kin_stats* stats);
 // max over saved times per species, reduced on the device

@@ -477,12 +477,24 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
             h.set_arrhenius(calc.Ea, calc.A, calc.k_max, calc.t_mult)
         sol_k = None
         sol_vcs = None
+        continuous = variable and not conditions.discrete_updates and arr
+        if continuous:
+            # continuous rate updates (methods.jl:363-653): T(t) = the profile solution, linearly interpolated
+            # (src/utils.jl:135-139); a static T in the set is a constant trace
+            prof = conditions.profiles[conditions.symbols.index("T")]
+            if isstatic(prof):
+                nodes_t, nodes_T = np.array([pars.tspan[0], pars.tspan[1]]), np.array([prof.value, prof.value], dtype=float)
+            else:
+                nodes_t, nodes_T = prof.sol.t, prof.sol.u
+        if pars.explicit and (return_integrator or continuous):
+            # the explicit pair exists behind kin_solve_explicit only (static / discrete-update solves)
+            raise ValueError("solver='RK45' is not available with return_integrator=true or continuous rate updates; "
+                             "use the default BDF there")
         if return_integrator:
-            # methods.jl:175-178, 242-246, 706-709: hand back the initialised integrator instead of solving
-            if variable and not conditions.discrete_updates and arr:
-                raise NotImplementedError("return_integrator with continuous rate updates: use solve_network, or a "
-                                          "ConditionSet with ts_update (discrete updates)")
-            if not variable or not conditions.discrete_updates:
+            # methods.jl:175-178, 242-246, 445-449, 706-709: hand back the initialised integrator instead of solving
+            if continuous:
+                h.integrator_init_continuous(pars.to_kin_params(), u0, nodes_t, nodes_T)
+            elif not variable or not conditions.discrete_updates:
                 h.set_rates(get_initial_rates(conditions, calc))
                 h.integrator_init(pars.to_kin_params(), u0)
             else:
@@ -499,15 +511,8 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
             h.set_rates(k0)
             t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, explicit=pars.explicit)
         elif not conditions.discrete_updates:
-            # continuous rate updates (methods.jl:363-653): k(t) = calculator(T(t)) evaluated on the device at
-            # every step; T(t) = the profile solution, linearly interpolated (src/utils.jl:135-139)
-            prof = conditions.profiles[conditions.symbols.index("T")]
-            if isstatic(prof):
-                nodes_t, nodes_T = np.array([pars.tspan[0], pars.tspan[1]]), np.array([prof.value, prof.value], dtype=float)
-            else:
-                nodes_t, nodes_T = prof.sol.t, prof.sol.u
+            # k(t) = calculator(T(t)) evaluated on the device at every step attempt
             t, u, rc, st, status = h.solve_continuous(pars.to_kin_params(), u0, nodes_t, nodes_T)
-            sol_vcs = {"T": np.interp(t, nodes_t, nodes_T)}      # ODESolutionVC's condition traces (solutions.jl:1-21)
         else:
             tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
             sol_k = DiscreteRates(tstops, table)
@@ -517,6 +522,13 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
                 t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, k_table=table, explicit=pars.explicit)
         if status == capi.KIN_ERR_SOLVE_FAILED:
             raise RuntimeError("ODE solution failed.")      # ErrorException (solve_utils.jl:405-411)
+        if variable and not conditions.discrete_updates:
+            # ODESolutionVC's condition traces (solutions.jl:1-21, rebuild_vc_solution): one per VARIABLE condition of
+            # the set, whatever the calculator reads (a Dummy calculator accepts :T and :V, calculator.jl:154-156)
+            sol_vcs = {}
+            for sym, prof in zip(conditions.symbols, conditions.profiles):
+                if not isstatic(prof):
+                    sol_vcs[sym] = np.interp(t, prof.sol.t, prof.sol.u)
         if pars.update_tols and st["final_abstol"] != pars.abstol:
             pars.abstol, pars.reltol = st["final_abstol"], st["final_reltol"]   # solve_utils.jl:397-401
     finally:

@@ -7,8 +7,12 @@ leaves Sundials unpinned). The stand-in restated here is the published quasi-con
 variable-order (1-5) BDF/NDF of Shampine & Reichelt, "The MATLAB ODE Suite", SIAM J. Sci.
 Comput. 18 (1997): backward differences D, Newton corrector on  d - c f(y_pred + d) + psi = 0
 with c = h / alpha_k, local error kappa-corrected, order chosen from the error estimates at
-k-1, k, k+1. SciPy's solve_ivp(method="BDF") implements the same paper; tests/test_oracle_bdf.py
-pins this file against it step for step. Sparse LU: SuperLU (scipy.sparse.linalg.splu) with a
+k-1, k, k+1. SciPy's solve_ivp(method="BDF") implements the same paper, and the integrator core below
+(KAPPA / GAMMA / ALPHA / ERROR_CONST, _R, change_D, the step and order-selection logic) is ADAPTED FROM
+SciPy's scipy/integrate/_ivp/bdf.py (BSD-3-Clause, (c) SciPy developers) - restructured for restarts,
+segment-local time, the ode15s/CVODE corrector acceptance, history resets and the reference's
+orchestration. tests/test_oracle_bdf.py therefore shows a faithful adaptation (same step sequence as
+SciPy with scipy_newton=True), not an independent pin. Sparse LU: SuperLU (scipy.sparse.linalg.splu) with a
 minimum-degree ordering - the same class of CPU solver as KLU.
 
 PARITY UNPINNED against the reference itself: trajectories are checked against closed forms and
@@ -384,16 +388,24 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
         save_local = [min(base + i * si, last) for i in range(cnt)]
         if not chunks and save_local[-1] < last:
             save_local.append(last)
-        if chunks:
+        # chunkwise: collect(0:save_interval:chunkstep) holds the chunk end only when it is a grid point
+        # (methods.jl:756-758); see solver.cpp for the off-grid case
+        if chunks and abs(save_local[-1] - last) <= 1e-9 * last:
             save_local[-1] = last
     L = len(save_local) if save_local is not None else 0
+    save_hits_end = chunks and L > 0 and save_local[-1] == chunkstep
 
     state = {"k": None if k0 is None else np.array(k0, dtype=float)}
     if params.get("explicit", False):
         bdf = OracleRK45(lambda y: fun_of_k(state["k"])(y), n, abstol, reltol)
     else:
+        # dtmin as the reference passes it: eps(solve_chunkstep) chunkwise (methods.jl:232, 770), eps(tspan[end]) otherwise
+        # (methods.jl:164, 694)
+        dtmin = params.get("dtmin", 0.0)
+        if not dtmin > 0.0:
+            dtmin = float(np.spacing(abs(chunkstep if chunks else tspan1)))
         bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
-                        dtmin=0.0, ban_negatives=params.get("ban_negatives", False))
+                        dtmin=dtmin, ban_negatives=params.get("ban_negatives", False))
     # continuous rate updates (methods.jl:363-653): k re-evaluated at the global time of every step attempt
     seg_origin = [0.0]
     if k_of_time is not None:
@@ -465,7 +477,7 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                             break
                         t_abs = seg_end if bdf.t >= seg_len else t_seg + bdf.t
                         if L > 0:
-                            last_i = L - 1 if chunks else L
+                            last_i = L - 1 if (chunks and not (nc == n_chunks - 1 and not save_hits_end)) else L
                             while save_i < last_i and save_local[save_i] <= t_abs:
                                 out_t.append(save_local[save_i] + shift)
                                 out_u.append(bdf.interpolate(min(save_local[save_i] - t_seg, bdf.t)))
@@ -483,7 +495,7 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                     rates_changed = True
                     stop_i += 1
             if not failed:
-                if chunks and nc == n_chunks - 1 and L > 1:
+                if chunks and nc == n_chunks - 1 and L > 1 and save_hits_end:
                     out_t.append(save_local[L - 1] + shift); out_u.append(y.copy())
                 next_stop = stop_i
                 break

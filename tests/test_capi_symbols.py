@@ -9,6 +9,7 @@ import pytest
 from kinetica_jl_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kinetica_hip.h")
 
 
 def _declared():
@@ -31,9 +32,35 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in capi.lib().kin_version()
 
 
-def test_struct_layouts_match_header():
-    assert ctypes.sizeof(capi.KinParams) == 8 * 4 + 4 * 4 + 8 * 3
-    assert ctypes.sizeof(capi.KinStats) == 8 * 17
+def test_struct_layouts_match_header(tmp_path):
+    """Field offsets and sizes of kin_params / kin_stats as the C compiler lays them out from the header itself,
+    against the ctypes mirrors (the Julia structs of INTEGRATION.md list the same fields in the same order)."""
+    import subprocess
+    fields = {"kin_params": capi.KinParams, "kin_stats": capi.KinStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, cls in fields.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in fields.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    # the header declares no field the mirrors lack
+    import re
+    text = open(HEADER).read()
+    for cname, cls in fields.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        declared = [n.strip() for decl in body.split(";") if decl.strip()
+                    for n in decl.strip().split(None, 1)[1].split(",")]
+        assert declared == [f for f, _ in cls._fields_], cname
 
 
 def test_invalid_network_is_rejected_before_touching_the_gpu():

@@ -1,0 +1,141 @@
+"""GPU tests of the boundary details added in round 2: `dtmin` (methods.jl:164, 232, 694, 770) with its
+DtLessThanMin -> tolerance-retry path, the synchronising step-end hand-over, the Arrhenius cap at its limits,
+return_integrator with continuous rate updates, and the explicit-solver guard."""
+import os
+
+import numpy as np
+import pytest
+
+from kinetica_jl_amd import capi
+from kinetica_jl_amd.synth import from_lists, synthetic_crn
+from oracle import bdf as obdf
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def kp(tspan, chunks=True, chunkstep=1e-3, save=None, abstol=1e-10, reltol=1e-8, maxiters=100000, adaptive=True, dtmin=0.0):
+    return capi.KinParams(tspan0=tspan[0], tspan1=tspan[1], abstol=abstol, reltol=reltol, adaptive_tols=int(adaptive),
+                          update_tols=0, solve_chunks=int(chunks), ban_negatives=0, solve_chunkstep=chunkstep,
+                          maxiters=maxiters, save_interval=-1.0 if save is None else save, dtmin=dtmin)
+
+
+def errscale(u, ref, abstol=1e-10, reltol=1e-8):
+    return (np.abs(u - ref) / (abstol + reltol * np.abs(ref))).max()
+
+
+ROBER = from_lists(3, [[(0, 1)], [(1, 2)], [(1, 1), (2, 1)]], [[(1, 1)], [(1, 1), (2, 1)], [(0, 1), (2, 1)]])
+ROBER_K = np.array([0.04, 3e7, 1e4])
+
+
+def oracle_rober(pars):
+    on = orc.OracleNetwork.from_flat(ROBER)
+    return obdf.solve_network_oracle(lambda kk: (lambda y: on.rhs(kk, y)), lambda kk: (lambda y: on.jac(kk, y)), 3, pars,
+                                     [1.0, 0.0, 0.0], k0=ROBER_K)
+
+
+def test_dtmin_ends_in_dtlessthanmin_and_the_retry_loop_answers():
+    """A dtmin far above what Robertson's initial transient needs: the first step is RAISED to dtmin (CVodeSetMinStep
+    semantics), the error test pushes it below -> DtLessThanMin; adaptive_solve! (solve_utils.jl:376-424) divides the
+    tolerances by 10 and retries, 5 attempts in all, then "ODE solution failed."."""
+    h = capi.HipNetwork.from_flat(ROBER)
+    h.set_rates(ROBER_K)
+    t, u, rc, st, status = h.solve(kp((0.0, 40.0), chunks=False, save=4.0, dtmin=1.0), [1.0, 0.0, 0.0])
+    assert status == capi.KIN_ERR_SOLVE_FAILED and rc == 2 and capi.RETCODE_NAMES[rc] == "DtLessThanMin"
+    assert st["n_retries"] == 4
+    assert st["final_abstol"] == pytest.approx(1e-14) and st["final_reltol"] == pytest.approx(1e-12)
+    # the oracle takes the same path
+    to, uo, rco, sto = oracle_rober(dict(tspan=(0.0, 40.0), solve_chunks=False, save_interval=4.0, dtmin=1.0))
+    assert rco == obdf.RET_DTMIN and sto["n_retries"] == 4
+    # adaptive_tols = false: no retry (solve_utils.jl:403-405)
+    t, u, rc, st, status = h.solve(kp((0.0, 40.0), chunks=False, save=4.0, dtmin=1.0, adaptive=False), [1.0, 0.0, 0.0])
+    assert status == capi.KIN_ERR_SOLVE_FAILED and rc == 2 and st["n_retries"] == 0
+    # a dtmin the problem can live with changes nothing but the first steps: still within the stated tolerance of the
+    # default run, and the default is eps(tspan[end]) (complete) / eps(solve_chunkstep) (chunkwise), bit for bit
+    t0, u0, rc0, st0, _ = h.solve(kp((0.0, 40.0), chunks=False, save=4.0), [1.0, 0.0, 0.0])
+    t1, u1, rc1, st1, _ = h.solve(kp((0.0, 40.0), chunks=False, save=4.0, dtmin=float(np.spacing(40.0))), [1.0, 0.0, 0.0])
+    assert rc0 == 0 and rc1 == 0 and np.array_equal(u0, u1) and st0["n_steps"] == st1["n_steps"]
+    t2, u2, rc2, st2, _ = h.solve(kp((0.0, 40.0), chunks=False, save=4.0, dtmin=1e-7), [1.0, 0.0, 0.0])
+    assert rc2 == 0 and errscale(u2, u0) < 100
+    tc0, uc0, *_ = h.solve(kp((0.0, 40.0), True, 10.0, 5.0), [1.0, 0.0, 0.0])
+    tc1, uc1, *_ = h.solve(kp((0.0, 40.0), True, 10.0, 5.0, dtmin=float(np.spacing(10.0))), [1.0, 0.0, 0.0])
+    assert np.array_equal(uc0, uc1)
+    h.close()
+
+
+def test_synchronising_hand_over_gives_the_same_trajectory():
+    """KIN_NO_FAST_SYNC=1 forces the copy + hipStreamSynchronize hand-over at the end of every step attempt (the
+    fallback of the pinned-memory sequence number): same kernels, same numbers."""
+    net, Ea, A = synthetic_crn(300, 1500)
+    k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
+    u0 = np.zeros(300); u0[0] = 1.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates(k)
+    t, u, rc, st, _ = h.solve(kp((0.0, 3e-3)), u0)
+    h.close()
+    os.environ["KIN_NO_FAST_SYNC"] = "1"
+    try:
+        h = capi.HipNetwork.from_flat(net)
+        h.set_rates(k)
+        t2, u2, rc2, st2, _ = h.solve(kp((0.0, 3e-3)), u0)
+        h.close()
+    finally:
+        del os.environ["KIN_NO_FAST_SYNC"]
+    assert rc == 0 and rc2 == 0 and np.array_equal(u, u2)
+    assert all(st[q] == st2[q] for q in ("n_steps", "n_rejected", "n_factor", "n_linsolve", "n_jac"))
+
+
+def test_arrhenius_cap_at_its_limits():
+    """k = 1/(1/k_max + 1/k_r) (calculator.jl:225): k_r = inf gives k_max, k_r = 0 gives 0 - on the device as in the
+    reference's formula (the oracle evaluates it literally)."""
+    Ea = np.array([0.0, 0.0, 5.0e6, 1.0e5])
+    A = np.array([1e300, 1e-320, 1e10, 1e10])           # A N_A overflows / is subnormal / exp underflows / ordinary
+    for T in (300.0, 1000.0):
+        with np.errstate(over="ignore", divide="ignore"):
+            ref = orc.arrhenius(Ea, A, T, k_max=1e12)
+        got = capi.arrhenius_eval(Ea, A, T, k_max=1e12)
+        assert np.all(np.isfinite(got)) and got[0] == 1e12
+        np.testing.assert_allclose(got, ref, rtol=4e-15, atol=0)
+    # the table kernel agrees (its own fast arithmetic: bound of the parity test in test_gpu_parity.py)
+    net = from_lists(2, [[(0, 1)]] * 4, [[(1, 1)]] * 4)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    tab = h.rate_table(np.array([300.0, 1000.0]))
+    with np.errstate(over="ignore", divide="ignore"):
+        ref = orc.rate_table(Ea, A, np.array([300.0, 1000.0]), k_max=1e12)
+    assert np.all(np.isfinite(tab)) and np.all(tab[:, 0] == 1e12)
+    np.testing.assert_allclose(tab, ref, rtol=1e-11, atol=0)
+    h.close()
+
+
+def test_return_integrator_with_continuous_rates_and_the_explicit_guard():
+    """return_integrator=true on a continuous-rate VariableODESolve (methods.jl:363-458 with :445-449): stepping the
+    integrator to the end reproduces kin_solve_continuous; solver='RK45' is refused on these paths instead of being
+    silently replaced by the BDF."""
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    Ea, A = np.array([8.0e4]), np.array([1.0e-17])
+    sd = S.SpeciesData.from_names(["A", "B"])
+    rd = S.RxData(1, [[1]], [[2]], [[1]], [[1]])
+
+    def method(**kw):
+        cs = C.ConditionSet({"T": C.LinearGradientProfile(rate=100.0, X_start=500.0, X_end=700.0)})
+        pars = S.ODESimulationParams(tspan=(0.0, 2.0), u0=[1.0, 0.0], solve_chunks=False, low_k_cutoff="none", **kw)
+        return S.VariableODESolve(pars, cs, S.PrecalculatedArrheniusCalculator(Ea, A))
+
+    res = S.solve_network(method(), sd, rd)
+    assert res.sol.retcode == "Success" and set(res.sol_vcs) == {"T"}
+    with S.solve_network(method(), sd, rd, return_integrator=True) as integ:
+        assert integ.t == 0.0
+        ts = []
+        while integ.step(1) == 1:
+            ts.append(integ.t)
+        assert np.array_equal(np.array(ts), res.sol.t[1:])           # saveat = []: every accepted step
+        assert integ.t == 2.0 and integ.retcode == "Success" and np.array_equal(integ.u, res.sol.u[-1])
+    for ri in (False, True):
+        with pytest.raises(ValueError):
+            S.solve_network(method(solver="RK45"), sd, rd, return_integrator=ri)
+    cs = C.ConditionSet({"T": 600.0})
+    pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0, 0.0], solve_chunks=False, low_k_cutoff="none", solver="RK45")
+    with pytest.raises(ValueError):
+        S.solve_network(S.StaticODESolve(pars, cs, S.PrecalculatedArrheniusCalculator(Ea, A)), sd, rd, return_integrator=True)

@@ -316,10 +316,12 @@ def test_edge_semantics_of_the_driver():
     # (2) stops after the end of the span are ignored; a single stop at t = 0 equals the static solve
     t2, u2, *_ = h.solve(kp((0.0, 1.0), True, 0.5, 0.25), [1.0, 0.0], tstops=np.array([0.0, 5.0]), k_table=np.array([[1.0], [9.0]]))
     assert errscale(u2[:, 0], np.exp(-t2)) < 100
-    # (3) save_interval that does not divide the chunk: 0:0.2:0.5 -> local saves 0, 0.2, 0.4 (+ end on the last chunk)
+    # (3) save_interval that does not divide the chunk: collect(0:0.2:0.5) = [0, 0.2, 0.4] (methods.jl:756-758)
     h.set_rates([1.0])
     t3, u3, *_ = h.solve(kp((0.0, 1.0), True, 0.5, 0.2), [1.0, 0.0])
-    np.testing.assert_allclose(t3, [0, 0.2, 0.5, 0.7, 1.0] if False else t3)      # shape rule below
+    # the reference drops each chunk's LAST local save point (0.4) except on the final chunk (methods.jl:829-846):
+    # global grid = chunk 0: 0, 0.2 | chunk 1: 0.5, 0.7 | final point 0.9 = the last local save of the last chunk
+    np.testing.assert_allclose(t3, [0.0, 0.2, 0.5, 0.7, 0.9], rtol=0, atol=1e-15)
     assert len(t3) == (3 - 1) * 2 + 1                                             # (len(saveat_local)-1)*n_chunks+1 (methods.jl:761)
     assert errscale(u3[:, 0], np.exp(-t3)) < 100
     # (4) non-increasing tstops are rejected
