@@ -133,6 +133,8 @@ typedef struct kin_stats {
   double final_abstol, final_reltol; /* what update_tols writes back (solve_utils.jl:397-401) */
   double wall_seconds;
   int64_t lu_dense_dim, lu_sparse_rows, lu_rounds, lu_nnz;
+  int64_t n_lu_reused;   /* step attempts that started on a cached factorisation (the solver's LU cache) */
+  int64_t lu_slots;      /* size of that cache */
 } kin_stats;
 
 /* ---- A4/A5/A9/A10: the solve --------------------------------------------------------- */

@@ -214,33 +214,48 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     bwd[r].upload(build_seg_plan(p1 - p0, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
   }
 
-  W.alloc((size_t)w_size);
-  KIN_HIP(hipMemsetAsync(W.p, 0, (size_t)w_size * sizeof(double), s));
   pinv.alloc(2 * 32 * 32);
-  S2.alloc((size_t)std::max(mpad, 64) * std::max(mpad, 64));
+  slots.clear();
+  ensure_slots(1, s);
   KIN_HIP(hipStreamSynchronize(s));
 }
 
-void SparseLU::factor(double c, const double* d_jvals, hipStream_t s) {
-  // zero everything up to the solve vectors, then scatter I - c*J
-  KIN_HIP(hipMemsetAsync(W.p, 0, (size_t)off_y * sizeof(double), s));
-  launch_lu_assemble(nnzJ, jmap.p, d_jvals, c, W.p, off_S, m, mpad, s);
-  for (int r = 0; r < nrounds; r++) {
-    launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W.p, off_L, off_diag, s);
-    launch_segsum(schur[r].view(), SEG_PROD_SUB, W.p, W.p, SegExtra{}, s);
+void SparseLU::ensure_slots(int nslots, hipStream_t s) {
+  while ((int)slots.size() < nslots) {
+    slots.emplace_back();
+    Slot& q = slots.back();
+    q.W.alloc((size_t)w_size);
+    KIN_HIP(hipMemsetAsync(q.W.p, 0, (size_t)w_size * sizeof(double), s));
+    q.S2.alloc((size_t)std::max(mpad, 64) * std::max(mpad, 64));
   }
-  if (m > 0) sinv = launch_gauss_jordan(W.p + off_S, S2.p, mpad, pinv.p, s);
 }
 
-void SparseLU::solve(const int* skip, hipStream_t s) {
+void SparseLU::factor(double c, const double* d_jvals, int slot, hipStream_t s) {
+  Slot& q = slots[slot];
+  double* W = q.W.p;
+  // zero everything up to the solve vectors, then scatter I - c*J
+  KIN_HIP(hipMemsetAsync(W, 0, (size_t)off_y * sizeof(double), s));
+  launch_lu_assemble(nnzJ, jmap.p, d_jvals, c, W, off_S, m, mpad, s);
+  for (int r = 0; r < nrounds; r++) {
+    launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W, off_L, off_diag, s);
+    launch_segsum(schur[r].view(), SEG_PROD_SUB, W, W, SegExtra{}, s);
+  }
+  if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, s);
+  q.c_fact = c;
+  q.valid = true;
+}
+
+void SparseLU::solve(const int* skip, int slot, hipStream_t s) {
+  Slot& q = slots[slot];
+  double* W = q.W.p;
   SegExtra ex;
   ex.skip = skip;
-  for (int r = 1; r < nrounds; r++) launch_segsum(fwd[r].view(), SEG_PROD_SUB, W.p, W.p, ex, s);
+  for (int r = 1; r < nrounds; r++) launch_segsum(fwd[r].view(), SEG_PROD_SUB, W, W, ex, s);
   if (m > 0) {
-    if (ns > 0) launch_segsum(fwd_dense.view(), SEG_PROD_SUB, W.p, W.p, ex, s);
-    launch_gemv(sinv, mpad, m, W.p + off_y + ns, W.p + off_x, skip, s);
+    if (ns > 0) launch_segsum(fwd_dense.view(), SEG_PROD_SUB, W, W, ex, s);
+    launch_gemv(q.sinv, mpad, m, W + off_y + ns, W + off_x, skip, s);
   }
-  for (int r = nrounds - 1; r >= 0; r--) launch_segsum(bwd[r].view(), SEG_PROD_SUB_DIV, W.p, W.p, ex, s);
+  for (int r = nrounds - 1; r >= 0; r--) launch_segsum(bwd[r].view(), SEG_PROD_SUB_DIV, W, W, ex, s);
 }
 
 }  // namespace kin

@@ -18,6 +18,7 @@
 // (diagonal), like KLU's refactor path; a bad pivot shows up as a Newton failure and the step
 // is retried with a smaller h (M -> I as h -> 0).
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "common.hpp"
@@ -41,9 +42,21 @@ struct SparseLU {
   // layout of the single value array W (so every gather indexes one base pointer)
   int64_t off_diag = 0, off_U = 0, off_L = 0, off_S = 0, off_y = 0, off_x = 0, w_size = 0;
 
-  DevBuf<double> W;
-  DevBuf<double> pinv, S2;                  // Gauss-Jordan pivot block inverse, ping-pong copy of the Schur block
-  const double* sinv = nullptr;             // where the inverse of the Schur block ended up (S or S2)
+  // Factor values live in SLOTS: one value array W = [diag | U | L | dense Schur block | solve vectors] plus the
+  // ping-pong copy of the Schur block per slot. The symbolic structure (plans, maps) is shared. Several slots = the LU
+  // cache of solver.cpp: factorisations for different c = h / alpha_k stay resident (HBM is plentiful: 25 MB per slot at
+  // 10k species, 157 MB at 50k) and are reused across step-size changes and across restarts.
+  struct Slot {
+    DevBuf<double> W, S2;
+    const double* sinv = nullptr;           // where the inverse of the Schur block ended up (inside W or S2)
+    double c_fact = 0.0;
+    int64_t last_use = 0;
+    bool valid = false;
+  };
+  std::vector<Slot> slots;
+  DevBuf<double> pinv;                      // Gauss-Jordan pivot block inverses (scratch of a factorisation)
+  size_t slot_bytes() const { return ((size_t)w_size + (size_t)std::max(mpad, 64) * std::max(mpad, 64)) * sizeof(double); }
+  void ensure_slots(int n, hipStream_t s);  // allocates (and zeroes) slots up to n
   DevBuf<int32_t> jmap;                     // J entry -> W position (bit 31: diagonal)
   DevBuf<int32_t> ent_pivot;                // sparse entry -> its pivot
   DevBuf<int32_t> yloc, xloc;               // species -> position of its rhs / solution in W
@@ -54,11 +67,11 @@ struct SparseLU {
 
   void analyze(int32_t n, const std::vector<int32_t>& j_ptr, const std::vector<int32_t>& j_col,
                const LUOptions& opt, hipStream_t s);
-  // M = I - c*J, factorised in place
-  void factor(double c, const double* d_jvals, hipStream_t s);
-  // solves M x = b in place: b was written to W[yloc[v]], x is read from W[xloc[v]].
-  // `skip`: optional device flag making every kernel of the solve a no-op.
-  void solve(const int* skip, hipStream_t s);
+  // M = I - c*J, factorised into slot `slot`
+  void factor(double c, const double* d_jvals, int slot, hipStream_t s);
+  // solves M x = b in place with the factors of `slot`: b was written to W[yloc[v]], x is read from W[xloc[v]]
+  // (W = that slot's array). `skip`: optional device flag making every kernel of the solve a no-op.
+  void solve(const int* skip, int slot, hipStream_t s);
 };
 
 // dense / LU helper kernels (solver_kernels.hip)

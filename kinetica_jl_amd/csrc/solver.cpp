@@ -66,6 +66,15 @@ struct Solver {
   double t = 0, h_abs = 0, atol = 0, rtol = 0, newton_tol = 0, dtmin = 0;
   int order = 1, n_equal = 0;
   bool lu_valid = false, jac_current = false, ban_negatives = false;
+  // LU cache (CVODE keeps ONE factorisation while gamma drifts < 30 %; with 288 GB of HBM this solver keeps MANY):
+  // factorisations stay resident in slots and are reused - across step-size changes AND across restarts (every chunk
+  // start and rate update replays the same ramp of step sizes) - whenever a slot's c_fact is within `lu_band` of the
+  // current c = h / alpha_k; the Newton update is then scaled by 2 / (1 + c / c_fact) (CVODE's gamrat correction).
+  // A slot is refreshed (Jacobian at the predictor + factorisation at the current c) only when a corrector that used
+  // it fails. lu_slots == 1 and lu_band == 0 give the round-1 behaviour (a new factorisation at every change of c).
+  int lu_slots = 1, cur_slot = 0;
+  double lu_band = 0.0;
+  int64_t use_clock = 0;
   double fail_score = 0.0;   // leaky count of rejected attempts (history reset at 3, see reset_history)
   kin_stats st{};
   int64_t iters_left = 0;
@@ -91,6 +100,19 @@ struct Solver {
     if (const char* e = getenv("KIN_LU_MAX_TAIL_DEGREE")) opt.max_tail_degree = atoi(e);
     if (const char* e = getenv("KIN_LU_MAX_DEGREE")) opt.max_degree = atoi(e);
     lu.analyze(N, H.j_ptr, H.j_col, opt, s);
+    {
+      // cache size: KIN_LU_CACHE_SLOTS (default 32), bounded by KIN_LU_CACHE_MB (default 16384) of device memory
+      int want = 32;
+      double band = 0.35;
+      size_t budget_mb = 16384;
+      if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
+      if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
+      if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
+      const size_t fit = std::max<size_t>(1, budget_mb * 1024 * 1024 / std::max<size_t>(1, lu.slot_bytes()));
+      lu_slots = (int)std::min<size_t>((size_t)want, fit);
+      lu_band = lu_slots > 1 ? band : 0.0;
+      if (lu_slots == 1 && getenv("KIN_LU_BAND")) lu_band = band;   // single slot with a reuse band: CVODE's own scheme
+    }
     std::vector<int32_t> yl(N), ident(N);
     lu.yloc.download(yl.data(), N, s);
     KIN_HIP(hipStreamSynchronize(s));
@@ -260,13 +282,47 @@ struct Solver {
 
   void newton_iteration(int it, double c) {
     const int* skip = &ctrl.p->newton_done;
+    SparseLU::Slot& q = lu.slots[cur_slot];
     launch_rates_skip(h->host.R, h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s);
     SegExtra ex;
     ex.psi = psi.p; ex.d = d.p; ex.cscal = c; ex.skip = skip;
-    launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, lu.W.p, ex, s);
-    lu.solve(skip, s);
-    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, lu.W.p, scale.p, y.p, d.p, ctrl.p, red.p, s);
+    launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, q.W.p, ex, s);
+    lu.solve(skip, cur_slot, s);
+    // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
+    const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
+    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd, ctrl.p, red.p, s);
     st.n_rhs++; st.n_linsolve++;
+  }
+
+  void invalidate_lu() {
+    for (auto& q : lu.slots) { q.valid = false; q.c_fact = 0.0; q.last_use = 0; }
+    lu_valid = false; cur_slot = 0; use_clock = 0;
+  }
+  // slot whose c_fact is closest (in ratio) to c and within the band; -1: none
+  int nearest_slot(double c) const {
+    int best = -1;
+    double bd = 1e300;
+    for (int i = 0; i < (int)lu.slots.size(); i++) {
+      const SparseLU::Slot& q = lu.slots[i];
+      if (!q.valid) continue;
+      const double r = std::fabs(std::log(c / q.c_fact));
+      if (r < bd && std::fabs(c / q.c_fact - 1.0) <= lu_band) { bd = r; best = i; }
+    }
+    return best;
+  }
+  // a slot for a new factorisation: an unused one (allocated on demand), else the least recently used
+  int victim_slot() {
+    for (int i = 0; i < (int)lu.slots.size(); i++) if (!lu.slots[i].valid) return i;
+    if ((int)lu.slots.size() < lu_slots) { lu.ensure_slots((int)lu.slots.size() + 1, s); return (int)lu.slots.size() - 1; }
+    int v = 0;
+    for (int i = 1; i < (int)lu.slots.size(); i++) if (lu.slots[i].last_use < lu.slots[v].last_use) v = i;
+    return v;
+  }
+  void factor_into(int slot, double c) {
+    lu.factor(c, jv.p, slot, s);
+    lu.slots[slot].last_use = ++use_clock;
+    cur_slot = slot;
+    st.n_factor++;
   }
 
   // One accepted explicit step (Dormand & Prince 1980, the RK5(4)7M pair; step-size control as in SciPy's
@@ -371,12 +427,19 @@ struct Solver {
       const double c = hh / cf.alpha[order];
       if (pre_attempt) pre_attempt(t_new);
       bool converged = false;
+      // iteration matrix: the cached factorisation closest to this c, else a new one; `fresh` = made in this attempt
+      // from the Jacobian of this attempt's predictor
+      bool fresh = false;
+      if (lu_band > 0.0) {
+        const int hit = nearest_slot(c);
+        if (hit >= 0) { cur_slot = hit; lu.slots[hit].last_use = ++use_clock; st.n_lu_reused++; }
+        else { factor_into(victim_slot(), c); fresh = jac_current; }
+      } else if (!lu_valid) {
+        factor_into(0, c);
+        lu_valid = true;
+        fresh = jac_current;
+      }
       for (;;) {
-        if (!lu_valid) {
-          lu.factor(c, jv.p, s);
-          lu_valid = true;
-          st.n_factor++;
-        }
         launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
         newton_iteration(0, c);
         newton_iteration(1, c);
@@ -391,10 +454,25 @@ struct Solver {
         converged = hc->newton_done && hc->converged && !hc->nonfinite;
         if (converged) break;
         st.n_newton_fail++;
+        if (lu_band > 0.0) {
+          // matrix made for this very step from a current Jacobian: the step itself is too long. Otherwise the
+          // slot is refreshed: Jacobian at the predictor (if not current), factorisation at this c, one retry
+          if (fresh) break;
+          if (!jac_current) {
+            launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+            eval_jac(y.p);
+            jac_current = true;
+          }
+          factor_into(cur_slot, c);
+          fresh = true;
+          continue;
+        }
         if (jac_current) break;
         launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
         eval_jac(y.p);
         jac_current = true;
+        factor_into(0, c);
+        lu_valid = true;
       }
       if (!converged || (ban_negatives && hc->any_negative)) {
         // isoutofdomain (methods.jl:169-171) is treated like a failed corrector: halve the step
@@ -584,6 +662,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   Solver& S = *h->solver;
   hipStream_t s = h->stream;
   S.st = kin_stats{};
+  S.invalidate_lu();   // the LU cache lives within one solve: identical calls give identical results
   S.explicit_mode = explicit_solver;
   S.sync_wait_s = 0.0;
   std::fill(S.iter_hist, S.iter_hist + 8, 0);
@@ -782,6 +861,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   S.st.final_reltol = reltol;
   S.st.lu_dense_dim = S.lu.m; S.st.lu_sparse_rows = S.lu.ns; S.st.lu_rounds = S.lu.nrounds;
   S.st.lu_nnz = 2 * S.lu.nnzU + S.lu.ns + (int64_t)S.lu.m * S.lu.m;
+  S.st.lu_slots = S.lu_slots;
   S.st.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   if (getenv("KIN_TIMING"))
     fprintf(stderr, "[kin_solve] wall %.4f s, of which blocked in step syncs %.4f s (the rest is host-side enqueue); "
@@ -856,6 +936,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
   IntegratorState& I = *h->integ;
   hipStream_t s = h->stream;
   S.st = kin_stats{};
+  S.invalidate_lu();
   S.explicit_mode = false;
   S.ban_negatives = p.ban_negatives != 0;
   S.dtmin = resolve_dtmin(p);
@@ -959,7 +1040,8 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
   const int N = S.N;
   S.y.upload(u, N, s);
   S.eval_jac(S.y.p);
-  S.lu.factor(c, S.jv.p, s);
+  S.lu.factor(c, S.jv.p, 0, s);
+  S.cur_slot = 0;
   std::vector<int32_t> yl(N), xl(N);
   S.lu.yloc.download(yl.data(), N, s);
   S.lu.xloc.download(xl.data(), N, s);
@@ -969,9 +1051,9 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
   // the solve vectors live at the tail of W: write b there element by element
   std::vector<double> tail(S.lu.w_size - S.lu.off_y, 0.0);
   for (int i = 0; i < N; i++) tail[yl[i] - S.lu.off_y] = b[i];
-  KIN_HIP(hipMemcpyAsync(S.lu.W.p + S.lu.off_y, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  S.lu.solve(nullptr, s);
-  KIN_HIP(hipMemcpyAsync(tail.data(), S.lu.W.p + S.lu.off_y, tail.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  KIN_HIP(hipMemcpyAsync(S.lu.slots[0].W.p + S.lu.off_y, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  S.lu.solve(nullptr, 0, s);
+  KIN_HIP(hipMemcpyAsync(tail.data(), S.lu.slots[0].W.p + S.lu.off_y, tail.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   KIN_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < N; i++) x[i] = tail[xl[i] - S.lu.off_y];
 }

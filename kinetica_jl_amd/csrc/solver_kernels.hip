@@ -344,8 +344,8 @@ __device__ __forceinline__ double sum_partials(const double* part, int n) {
 // next predictor, so the stale update is never read.
 __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
                                                          const double* __restrict__ W, const double* __restrict__ scale,
-                                                         double* __restrict__ y, double* __restrict__ d, BdfCtrl* ctrl,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ y, double* __restrict__ d, double upd,
+                                                         BdfCtrl* ctrl, double* __restrict__ part) {
   __shared__ double sh[4];
   __shared__ int last;
   if (ctrl->newton_done) return;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
       yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
     }
 #pragma unroll
-    for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? W[xl[x]] : 0.0;
+    for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
 #pragma unroll
     for (int x = 0; x < 4; x++) {
       const int i = i0 + 256 * x;
@@ -616,8 +616,8 @@ void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, do
 }
 int bdf_reduce_blocks(int N) { return (int)ceil_div(N, RED_ELEMS); }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, BdfCtrl* ctrl, double* part, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, ctrl, part);
+                       double* y, double* d, double upd, BdfCtrl* ctrl, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, ctrl, part);
 }
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
                       const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,

@@ -240,6 +240,8 @@ class ODESimulationParams:
     low_k_cutoff: Union[float, str] = "auto"     # :auto / :none / number
     low_k_maxconc: float = 2.0
     allow_short_u0: bool = False
+    dtmin: Optional[float] = None   # EXTENSION (not a field of the reference's struct): None = what the reference hard-codes,
+                                    # eps(solve_chunkstep) / eps(tspan[end]) (methods.jl:164, 232, 694, 770)
 
     def __post_init__(self):
         # validation of the keyword constructor (params.jl:77-104); ArgumentError -> ValueError
@@ -271,7 +273,8 @@ class ODESimulationParams:
                               adaptive_tols=int(self.adaptive_tols), update_tols=int(self.update_tols),
                               solve_chunks=int(self.solve_chunks), ban_negatives=int(self.ban_negatives),
                               solve_chunkstep=self.solve_chunkstep, maxiters=int(self.maxiters),
-                              save_interval=-1.0 if self.save_interval is None else self.save_interval)
+                              save_interval=-1.0 if self.save_interval is None else self.save_interval,
+                              dtmin=0.0 if self.dtmin is None else float(self.dtmin))
 
 
 # ---- solve methods (src/solving/methods.jl:7-58) -----------------------------------------------------

@@ -67,17 +67,26 @@ class OracleBDF:
     """fun(y) -> f, jac(y) -> scipy CSR (autonomous system: the rate constants are frozen
     between restarts, exactly as in the discrete-rate solves of methods.jl:655-865)."""
 
-    def __init__(self, fun, jac, n, atol, rtol, dtmin=0.0, ban_negatives=False, scipy_newton=False):
+    def __init__(self, fun, jac, n, atol, rtol, dtmin=0.0, ban_negatives=False, scipy_newton=False, lu_band=0.35, lu_slots=32):
         # scipy_newton=True reproduces SciPy's corrector acceptance (tolerance from Hairer's RADAU5
         # heuristic, no acceptance on the first iteration) and exists only for the step-for-step
         # pin test; the production rule below is the one of the BDF codes themselves.
         self.scipy_newton = scipy_newton
+        # LU cache, mirroring Solver (solver.cpp): factorisations are kept in slots and reused - across step-size changes
+        # and across restarts - whenever a slot's c_fact is within lu_band of the current c = h / alpha_k, the Newton
+        # update scaled by 2 / (1 + c / c_fact) (CVODE's gamrat correction); a slot is refreshed only when a corrector
+        # that used it fails. lu_band = 0: a new factorisation at every change of c (SciPy's behaviour).
+        self.lu_band = 0.0 if scipy_newton else lu_band
+        self.lu_slots = lu_slots
+        self.slots = []          # dicts: c_fact, LU, last_use
+        self.use_clock = 0
+        self.c_fact = 0.0
         self.fun, self.jac, self.n = fun, jac, n
         self.dtmin = dtmin
         self.ban_negatives = ban_negatives
         self.set_tols(atol, rtol)
         self.stats = dict(n_steps=0, n_rejected=0, n_rhs=0, n_jac=0, n_factor=0, n_linsolve=0, n_newton_fail=0,
-                          n_restarts=0)
+                          n_restarts=0, n_lu_reused=0)
         self.I = sp.identity(n, format="csc")
         self.iters_left = 0
         self.pre_attempt = None   # continuous rates: called with the local time of every step attempt
@@ -96,6 +105,59 @@ class OracleBDF:
     def _f(self, y):
         self.stats["n_rhs"] += 1
         return self.fun(y)
+
+    def invalidate_lu(self):
+        """The cache lives within one solve (solve_entry does the same)."""
+        self.slots = []
+        self.use_clock = 0
+        self.LU = None
+
+    def _nearest_slot(self, c):
+        best, bd = None, 1e300
+        for sl in self.slots:
+            r = abs(math.log(c / sl["c_fact"]))
+            if r < bd and abs(c / sl["c_fact"] - 1.0) <= self.lu_band:
+                best, bd = sl, r
+        return best
+
+    def _factor_into(self, sl, c):
+        if sl is None:
+            if len(self.slots) < self.lu_slots:
+                sl = {}
+                self.slots.append(sl)
+            else:
+                sl = min(self.slots, key=lambda q: q["last_use"])
+        sl["LU"] = self._factor(c)
+        sl["c_fact"] = c
+        self.use_clock += 1
+        sl["last_use"] = self.use_clock
+        return sl
+
+    def _corrector_cached(self, c, y_pred, psi, scale):
+        """The cached factorisation closest to this c, else a new one; a failure with a matrix that was not made in this
+        attempt from a current Jacobian refreshes the slot (Jacobian at the predictor, factorisation at this c), one retry."""
+        sl = self._nearest_slot(c)
+        fresh = False
+        if sl is not None:
+            self.use_clock += 1
+            sl["last_use"] = self.use_clock
+            self.stats["n_lu_reused"] += 1
+        else:
+            sl = self._factor_into(None, c)
+            fresh = self.jac_current
+        while True:
+            self.LU, self.c_fact = sl["LU"], sl["c_fact"]
+            converged, n_iter, y_new, d = self._newton(y_pred, c, psi, scale)
+            if converged:
+                return converged, n_iter, y_new, d
+            self.stats["n_newton_fail"] += 1
+            if fresh:
+                return converged, n_iter, y_new, d
+            if not self.jac_current:
+                self.J = self.jac(y_pred); self.stats["n_jac"] += 1
+                self.jac_current = True
+            self._factor_into(sl, c)
+            fresh = True
 
     def _factor(self, c):
         self.stats["n_factor"] += 1
@@ -199,9 +261,13 @@ class OracleBDF:
             if self.pre_attempt is not None:
                 self.pre_attempt(t_new)
             converged = False
-            while True:
+            while self.lu_band > 0:
+                converged, n_iter, y_new, d = self._corrector_cached(c, y_pred, psi, scale)
+                break
+            while not self.lu_band > 0:
                 if self.LU is None:
                     self.LU = self._factor(c)
+                    self.c_fact = c
                 converged, n_iter, y_new, d = self._newton(y_pred, c, psi, scale)
                 if converged:
                     break
@@ -260,9 +326,14 @@ class OracleBDF:
         dy_norm_old = None
         converged = False
         k = 0
+        # a factorisation made for another c (cache hit, or kept across an error-test rejection): update scaled by
+        # 2 / (1 + c / c_fact)
+        upd = 2.0 / (1.0 + c / self.c_fact) if (self.c_fact != c and not self.scipy_newton) else 1.0
         for k in range(NEWTON_MAXITER):
             f = self._f(y)
             dy = self._lusolve(self.LU, c * f - psi - d)
+            if upd != 1.0:
+                dy = dy * upd
             if not np.all(np.isfinite(dy)):
                 break
             dy_norm = rms(dy / scale)
@@ -405,7 +476,8 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
         if not dtmin > 0.0:
             dtmin = float(np.spacing(abs(chunkstep if chunks else tspan1)))
         bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
-                        dtmin=dtmin, ban_negatives=params.get("ban_negatives", False))
+                        dtmin=dtmin, ban_negatives=params.get("ban_negatives", False),
+                        lu_band=params.get("lu_band", 0.35), lu_slots=params.get("lu_slots", 32))
     # continuous rate updates (methods.jl:363-653): k re-evaluated at the global time of every step attempt
     seg_origin = [0.0]
     if k_of_time is not None:
