@@ -6,27 +6,38 @@ A "step" is one batched RHS sweep: B states of the 10k-species / 50k-reaction sy
 (SURVEY.md 8(d), C3/C4), each state with its own rate-constant vector (ensemble of
 temperatures), all inputs resident in HBM before the timed region. `value` = RHS evaluations
 per second over all ranks. The same JSON line carries
-  roofline      - algorithmic bytes of one sweep (M2: 20R + B(8R + 16N)) / HIP-event time of the sweep kernels,
+  roofline      - algorithmic bytes of one sweep (M2: 20R + B(8R + 16N)) / HIP-event time of the sweep kernel; `traffic`
+                  is MEASURED IN THIS RUN: rank 0 (N = 1) starts two child processes under `rocprofv3 --pmc` (FETCH_SIZE
+                  and WRITE_SIZE cannot share a pass on gfx950) that launch the same sweep, before this process touches
+                  the GPU; null when the profiler is unavailable (never read from a committed file);
   cpu_baseline  - the CPU oracle's RHS (plain C, 1 core) on the same CRN, bounded sample,
-  solve_network - wall-clock of kin_solve (implicit BDF, on-device sparse LU) on the same CRN
-                  next to the CPU oracle's BDF + SuperLU on a bounded number of chunks.
-Multi-GPU (weak scaling): every rank sweeps its own B states (ensemble replicas, SURVEY 8(e)(2));
-no data-path collective, only the barrier / max-over-ranks timing of the contract.
+  solve_network - wall-clock of kin_solve (implicit BDF, on-device sparse LU) on the same CRN, and the compiled CPU
+                  baseline (oracle/cpu_bdf.cpp: the same BDF with a KLU-style sparse LU, -O3) on a bounded number of
+                  chunks with the device timed on THE SAME chunks; 1 core (the reference's solve path is single-threaded)
+                  and all cores (one replica per core, the CPU counterpart of one replica per GPU).
+Multi-GPU (weak scaling): every rank sweeps its own B states and solves its own replica; no data-path
+collective in the timed region, the contract's barrier / max-over-ranks timing only; the replicas' per-species maxima
+(what identify_next_seeds reads) are gathered with an RCCL all-gather on device buffers after the solve.
+`python bench.py --gpus N` without a launcher starts its own N ranks (before any GPU call).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing only)
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -34,17 +45,88 @@ def main():
     ap.add_argument("--species", type=int, default=10000)
     ap.add_argument("--reactions", type=int, default=50000)
     ap.add_argument("--batch", type=int, default=4096, help="states per sweep per GPU")
-    ap.add_argument("--solve-chunks", type=int, default=20, help="chunks of the timed kin_solve (0 = skip)")
-    ap.add_argument("--cpu-solve-chunks", type=int, default=2)
+    ap.add_argument("--solve-chunks", type=int, default=100, help="chunks of the timed kin_solve (0 = skip)")
+    ap.add_argument("--cpu-solve-chunks", type=int, default=2, help="chunks the CPU baseline solves (the device is timed on the same ones)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="back-to-back sweeps after the timed region (sustained clock)")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# self-launch: python bench.py --gpus N without torchrun
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """Starts one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env) before this process has made any
+    GPU call, relays rank 0's output and exits with the worst child status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    rc = max(p.wait() for p in procs)
+    raise SystemExit(rc)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HBM traffic of the sweep kernel from the PMC counters, measured by child processes of this run
+# ---------------------------------------------------------------------------------------------------------------
+def measure_traffic(args):
+    """(bytes per launch, note). FETCH_SIZE and WRITE_SIZE in separate passes; units are KiB; FETCH_SIZE counts half of a
+    wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section) - doubled here."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="kin_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--species", str(args.species), "--reactions", str(args.reactions), "--batch", str(args.batch),
+                   "--steps", "4", "--warmup", "1"]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                                   stderr=subprocess.STDOUT, timeout=300)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, f"rocprofv3 --pmc {ctr}: {type(e).__name__}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} gave no counters (rc {p.returncode})"
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                 if "kin::sweep_" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if not v:
+                return None, f"no kin::sweep_ dispatch in the {ctr} pass"
+            vals[ctr] = sum(v) / len(v)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        "rocprofv3 --pmc child runs of this bench.py: (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over the sweep launches"
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.pmc_child:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+
+    import torch  # device memory, streams, torch.distributed: plumbing only (importing it makes no GPU call)
+
+    traffic, traffic_note = None, "not measured (--no-pmc, a child of the profiler, or N > 1)"
+    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
+        traffic, traffic_note = measure_traffic(args)      # child processes; this process has not touched the GPU yet
+
     # rehearsal knobs (a one-GPU box can run 2 ranks on the same card over gloo): never set by the driver
     if os.environ.get("BENCH_SINGLE_DEVICE"):
         local_rank = 0
@@ -59,6 +141,7 @@ def main():
             dist.init_process_group(backend)
 
     from kinetica_jl_amd import capi
+    from kinetica_jl_amd.distributed import gather_solution_max, max_over_ranks
     from kinetica_jl_amd.synth import synthetic_crn
     assert capi.lib().kin_set_device(local_rank) == 0
 
@@ -92,6 +175,12 @@ def main():
     for _ in range(args.warmup):
         sweep()
     torch.cuda.synchronize()
+    if args.pmc_child:                       # under rocprofv3 --pmc: the sweep launches only
+        for _ in range(args.steps):
+            sweep()
+        torch.cuda.synchronize()
+        h.close()
+        return
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -106,23 +195,27 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    from kinetica_jl_amd.distributed import max_over_ranks
-    elapsed = max_over_ranks(elapsed, dist, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
+    coll_dev = dev if (dist is None or dist.get_backend() == "nccl") else "cpu"
+    elapsed = max_over_ranks(elapsed, dist, coll_dev)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # ---- the same sweep back to back for a few seconds (outside the timed region): the rate the chip sustains once its
+    # clock management has settled, and enough GPU-resident time for an outside observer to see the device busy
+    sustained_ms = None
+    if args.sustain_seconds > 0:
+        n_sus = max(10, int(args.sustain_seconds / (kernel_ms * 1e-3)))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_sus):
+            sweep()
+        e1.record()
+        torch.cuda.synchronize()
+        sustained_ms = e0.elapsed_time(e1) / n_sus
 
     out = None
     if rank == 0:
         alg_bytes = 20 * R + B * (8 * R + 16 * N)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 runs of this same
-        # command, tools/collect_profiles.sh), only when they were taken on this configuration
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_sweep_pmc.json")))
-            if pm["algorithmic_bytes_per_launch"] == alg_bytes:
-                traffic = pm["hbm_bytes_per_launch_corrected"]
-        except (OSError, KeyError, ValueError):
-            pass
         out = {
             "metric": "RHS evals/sec (batched sweep) + wall-clock per solve_network, 10k-species CRN",
             "value": world * B * args.steps / elapsed, "unit": "RHS evals/s",
@@ -132,8 +225,12 @@ def main():
                                    f"B={B} states per GPU with per-state Arrhenius k (500-1200 K)",
                        "states_per_gpu": B, "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "kernel": "kin::sweep_reg_kernel<8, 4, BLK> (state fits LDS, reactions paired with their reverses; else kin::sweep_lds_kernel / sweep_big_kernel)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms},
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_over_algorithmic": None if traffic is None else traffic / alg_bytes,
+                         "kernel": "kin::sweep_reg_kernel<8, 4, BLK> (state fits LDS, reactions paired with their reverses; else kin::sweep_gen_kernel / sweep_big_kernel)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
+                         "sustained_launch_ms": sustained_ms,
+                         "sustained_frac": None if not sustained_ms else alg_bytes / (sustained_ms * 1e-3) / 8e12},
         }
 
     # ---- single-state RHS latency (what the integrator sees), rank 0 only
@@ -148,47 +245,78 @@ def main():
 
     # ---- wall-clock per solve_network (C3: static 1000 K, chunkwise, defaults of params.jl:55-75). Every rank solves
     # its own replica (rank r at 1000 + 10 r K: independent trajectories); the reported wall-clock is
-    # the maximum over ranks, rank 0's statistics are printed
+    # the maximum over ranks, rank 0's statistics are printed; the replicas' per-species maxima (identify_next_seeds'
+    # input) are gathered over RCCL from device buffers
+    chunk = 1e-3
+    u0 = np.zeros(N); u0[0] = 1.0
+
+    def kparams(nch):
+        return capi.KinParams(tspan0=0.0, tspan1=chunk * nch, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0,
+                              solve_chunks=1, ban_negatives=0, solve_chunkstep=chunk, maxiters=100000, save_interval=-1.0)
+
     if args.solve_chunks > 0:
-        u0 = np.zeros(N); u0[0] = 1.0
-        chunk = 1e-3
-        p = capi.KinParams(tspan0=0.0, tspan1=chunk * args.solve_chunks, abstol=1e-10, reltol=1e-8, adaptive_tols=1,
-                           update_tols=0, solve_chunks=1, ban_negatives=0, solve_chunkstep=chunk, maxiters=100000,
-                           save_interval=-1.0)
-        if rank > 0:
-            h.set_rates(h.rates_at(1000.0 + 10.0 * rank))
-        h.solve(p, u0)     # warm-up: symbolic analysis + allocations
+        k_rank = h.rates_at(1000.0 + 10.0 * rank)
+        h.solve(kparams(2), u0)     # warm-up: symbolic analysis + allocations
         if dist:
             dist.barrier()
         t1 = time.perf_counter()
-        ts, us, rc, st, status = h.solve(p, u0)
+        ts, us, rc, st, status = h.solve(kparams(args.solve_chunks), u0)
         gpu_wall_local = time.perf_counter() - t1
-        gpu_wall = max_over_ranks(gpu_wall_local, dist, dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
-    if rank == 0 and args.solve_chunks > 0:
-        out["solve_network"] = {"workload": f"StaticODESolve, T=1000 K (+10 K per rank), tspan (0, {p.tspan1:g}) s, solve_chunkstep 1e-3 "
-                                            f"({args.solve_chunks} chunks), abstol 1e-10, reltol 1e-8, one replica per GPU",
-                                "gpu_wall_s": gpu_wall, "gpu_s_per_chunk": gpu_wall / args.solve_chunks,
-                                "replicas": world, "solves_per_s": world / gpu_wall, "retcode": rc, "stats": st}
-        if not args.no_cpu and args.cpu_solve_chunks > 0 and world == 1:   # CPU legs: rank 0 at N=1 only
-            from oracle import bdf as obdf
+        gpu_wall = max_over_ranks(gpu_wall_local, dist, coll_dev)
+        t1 = time.perf_counter()
+        umax_all = gather_solution_max(h, dist, dev)         # [world][N] on every rank (RCCL all-gather on device buffers)
+        gather_s = time.perf_counter() - t1
+        assert umax_all.shape == (world, N) and np.array_equal(umax_all[rank], us.max(axis=0))
+        if rank == 0:
+            out["solve_network"] = {
+                "workload": f"StaticODESolve, T=1000 K (+10 K per rank), tspan (0, {chunk * args.solve_chunks:g}) s, solve_chunkstep 1e-3 "
+                            f"({args.solve_chunks} chunks), abstol 1e-10, reltol 1e-8, one replica per GPU",
+                "gpu_wall_s": gpu_wall, "gpu_s_per_chunk": gpu_wall / args.solve_chunks, "replicas": world,
+                "solves_per_s": world / gpu_wall, "retcode": rc, "stats": st,
+                "solution_max_allgather_s": gather_s, "solution_max_allgather": "RCCL all-gather of N doubles per rank from device buffers"
+                                                                                 if world > 1 else "single rank"}
+        # CPU legs: rank 0 at N = 1 only. The device is timed on the SAME chunks the CPU baseline solves.
+        if rank == 0 and world == 1 and not args.no_cpu and args.cpu_solve_chunks > 0:
+            from oracle import cpu_bdf
             from oracle import oracle as orc
-            on = orc.OracleNetwork.from_flat(net)
-            pars = dict(tspan=(0.0, chunk * args.cpu_solve_chunks), solve_chunks=True, solve_chunkstep=chunk)
-            t1 = time.perf_counter()
-            to, uo, rco, sto = obdf.solve_network_oracle(lambda kk: (lambda y: on.rhs(kk, y)),
-                                                         lambda kk: (lambda y: on.jac(kk, y)), N, pars, u0, k0=k1000)
-            cpu_wall = time.perf_counter() - t1
             nck = args.cpu_solve_chunks
-            dev = np.abs(us[:nck + 1] - uo) / (1e-10 + 1e-8 * np.abs(uo))
-            dev_vs_cpu = float(dev.max())
-            # the integrator controls the RMS norm over the N species (so a single species may sit sqrt(N) x
-            # further out than the norm): report the controlled quantity next to the per-species maximum
-            dev_rms = float(np.sqrt((dev ** 2).mean(axis=1)).max())
-            out["solve_network"].update({"cpu_wall_s": cpu_wall, "cpu_chunks": nck, "cpu_s_per_chunk": cpu_wall / nck,
-                                         "cpu_kind": "port (oracle BDF + SuperLU, 1 core)",
-                                         "speedup_per_chunk": (cpu_wall / nck) / (gpu_wall / args.solve_chunks),
-                                         "max_dev_vs_cpu_in_tol_units": dev_vs_cpu,
-                                         "rms_dev_vs_cpu_in_tol_units": dev_rms, "cpu_stats": sto})
+            h.set_rates(k_rank)
+            h.solve(kparams(nck), u0)
+            t1 = time.perf_counter()
+            tg, ug, rcg, stg, _ = h.solve(kparams(nck), u0)
+            gpu_same = time.perf_counter() - t1
+            cs = cpu_bdf.CpuSolver(net)
+            pars = dict(tspan=(0.0, chunk * nck), solve_chunks=True, solve_chunkstep=chunk)
+            t1 = time.perf_counter()
+            tc, uc, rcc, stc = cs.solve(pars, u0, k0=k_rank)
+            cpu_wall = time.perf_counter() - t1
+            dev_u = np.abs(ug - uc) / (1e-10 + 1e-8 * np.abs(uc))
+            # all cores: one replica per core (the CPU counterpart of one replica per GPU; the LU itself is sequential,
+            # as KLU's), each on its own network handle
+            import threading
+            cores = orc.usable_cores()
+            solvers = [cpu_bdf.CpuSolver(net) for _ in range(cores)]
+            ks = [orc.arrhenius(Ea, A, 1000.0 + 10.0 * i, k_max=1e12) for i in range(cores)]
+            th = [threading.Thread(target=lambda i=i: solvers[i].solve(pars, u0, k0=ks[i])) for i in range(cores)]
+            t1 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            cpu_all_wall = time.perf_counter() - t1
+            out["solve_network"].update({
+                "same_chunks": nck, "gpu_wall_same_chunks_s": gpu_same, "cpu_wall_same_chunks_s": cpu_wall,
+                "cpu_kind": "port (oracle/cpu_bdf.cpp: the same BDF + LU cache, left-looking sparse LU with AMD ordering, partial "
+                            "pivoting and KLU-style refactorisation, g++ -O3, 1 core)",
+                "speedup_same_chunks_1core": cpu_wall / gpu_same,
+                "cpu_all_cores": {"cores": cores, "replicas": cores, "wall_s": cpu_all_wall, "solves_per_s": cores / cpu_all_wall,
+                                  "gpu_solves_per_s_same_chunks": 1.0 / gpu_same,
+                                  "gpu_over_all_cores": (1.0 / gpu_same) / (cores / cpu_all_wall)},
+                "max_dev_vs_cpu_in_tol_units": float(dev_u.max()),
+                "rms_dev_vs_cpu_in_tol_units": float(np.sqrt((dev_u ** 2).mean(axis=1)).max()),
+                "gpu_stats_same_chunks": {q: stg[q] for q in ("n_steps", "n_rejected", "n_factor", "n_linsolve", "n_newton_fail")},
+                "cpu_stats": {q: stc[q] for q in ("n_steps", "n_rejected", "n_factor", "n_linsolve", "n_newton_fail", "lu_nnz",
+                                                  "t_rhs", "t_jac", "t_factor", "t_solve")}})
 
     # ---- CPU baseline for the headline metric: oracle RHS, 1 core, bounded sample
     if rank == 0 and not args.no_cpu and world == 1:

@@ -192,6 +192,25 @@ int kin_solution_copy(const kin_network* h, double* out_t, double* out_u);
  * src/exploration/explore_utils.jl:344-351), reduced on the device. */
 int kin_solution_max(const kin_network* h, double* out_umax);
 
+/* ---- multi-GPU building blocks (one process per GPU; the collectives themselves are RCCL calls of the host layer) -- */
+/* kin_solution_max into a caller-owned DEVICE buffer of N doubles: what an ensemble of replicas all-gathers. */
+int kin_solution_max_dev(const kin_network* h, double* d_out);
+/* kin_rate_table for a slice of time stops straight into a caller-owned DEVICE buffer [n_stops][R] (T on the host):
+ * ranks generate disjoint slices of the table; an all-gather follows only if sol_k is wanted. */
+int kin_rate_table_dev(kin_network* h, const double* T, int64_t n_stops, double* d_out);
+/* Partial right-hand side of reactions [r_lo, r_hi) only: du_partial = sum over the block of nu * rate (device buffers,
+ * enqueue only). Summed over a partition of the reactions (an all-reduce of N doubles) it is kin_rhs: the reaction-block
+ * decomposition of ONE trajectory. */
+int kin_rhs_block_dev(kin_network* h, int64_t r_lo, int64_t r_hi, const double* d_u, double* d_du, void* stream);
+
+/* out[t] = sum_i w[i] * u_i(t) for every saved time, reduced on the device: conserved quantities of the network
+ * (element or mass balances - what a caller checks before trusting a long run) without copying the trajectory. */
+int kin_solution_dot(const kin_network* h, const double* w, double* out);
+/* Selected rows of the device-resident rate table (k_precalc[s] of calculate_discrete_rates, solve_utils.jl:91-109):
+ * out[i][R] = table[rows[i]][:]. The full table (5.6 GB at 14 001 stops x 50 000 reactions) never has to cross PCIe
+ * for a caller that wants sol_k at a few stops. */
+int kin_rate_table_rows(kin_network* h, const int64_t* rows, int64_t n_rows, double* out);
+
 /* Diagnostic: one Newton-matrix solve on the device, (I - c*J(u)) x = b with the current rates,
  * through exactly the factorisation / substitution kernels kin_solve uses (what KLU does for
  * CVODE in the reference's documented setup, docs/src/getting-started.md:69). */

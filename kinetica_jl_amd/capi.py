@@ -25,7 +25,8 @@ SYMBOLS = [
     "kin_jac_nnz", "kin_jac_pattern", "kin_jac_values", "kin_solve", "kin_solve_explicit", "kin_solve_continuous", "kin_solution_size",
     "kin_solution_copy", "kin_solution_max", "kin_integrator_init", "kin_integrator_init_continuous", "kin_integrator_step",
     "kin_integrator_state",
-    "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version",
+    "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version", "kin_solution_dot", "kin_rate_table_rows",
+    "kin_solution_max_dev", "kin_rate_table_dev", "kin_rhs_block_dev",
 ]
 
 
@@ -316,6 +317,37 @@ class HipNetwork:
         x = np.empty(self.n)
         self._chk(lib().kin_newton_solve(self._h, float(c), _pd(u), _pd(b), _pd(x)))
         return x
+
+    def solution_max_dev(self, d_out):
+        """kin_solution_max into a device buffer (pointer as int) of N doubles."""
+        self._chk(lib().kin_solution_max_dev(self._h, c_void_p(d_out)))
+
+    def rate_table_dev(self, T_stops, d_out):
+        """Rows of the rate table for T_stops straight into a device buffer [len(T_stops)][R]."""
+        T_stops = _f64(T_stops)
+        self._chk(lib().kin_rate_table_dev(self._h, _pd(T_stops), len(T_stops), c_void_p(d_out)))
+
+    def rhs_block_dev(self, r_lo, r_hi, d_u, d_du, stream=0):
+        """Partial RHS of reactions [r_lo, r_hi) on device buffers; only enqueues."""
+        self._chk(lib().kin_rhs_block_dev(self._h, int(r_lo), int(r_hi), c_void_p(d_u), c_void_p(d_du),
+                                          c_void_p(stream) if stream else None))
+
+    def solution_dot(self, w):
+        """sum_i w[i] u_i(t) at every saved time, reduced on the device (conserved quantities)."""
+        w = _f64(w)
+        assert len(w) == self.n
+        n_saved = c_int64(0)
+        self._chk(lib().kin_solution_size(self._h, ctypes.byref(n_saved), None))
+        out = np.empty(n_saved.value)
+        self._chk(lib().kin_solution_dot(self._h, _pd(w), _pd(out)))
+        return out
+
+    def rate_table_rows(self, rows):
+        """Selected rows of the device-resident rate table."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((len(rows), self.nr))
+        self._chk(lib().kin_rate_table_rows(self._h, _p64(rows), len(rows), _pd(out)))
+        return out
 
     def solution_max(self):
         out = np.empty(self.n)

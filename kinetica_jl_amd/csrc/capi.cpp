@@ -8,6 +8,7 @@
 
 #include "handle.hpp"
 #include "solver.hpp"
+#include "solver_kernels.hpp"
 
 using namespace kin;
 
@@ -372,6 +373,71 @@ int kin_solution_max(const kin_network* hc, double* out_umax) {
   require(out_umax != nullptr, ERR_INVALID_ARG, "null output buffer");
   require(h->n_saved > 0, ERR_STATE, "no solution stored");
   solution_max(h, out_umax);
+  KIN_CATCH(h)
+}
+
+int kin_solution_max_dev(const kin_network* hc, double* d_out) {
+  kin_network* h = const_cast<kin_network*>(hc);
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(d_out != nullptr, ERR_INVALID_ARG, "null device buffer");
+  require(h->n_saved > 0, ERR_STATE, "no solution stored");
+  launch_colmax((int)h->host.N, h->n_saved, h->d_sol_u.p, d_out, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_rate_table_dev(kin_network* h, const double* T, int64_t n_stops, double* d_out) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(h->has_arrhenius, ERR_STATE, "Arrhenius parameters were never set");
+  require(T != nullptr && d_out != nullptr && n_stops >= 0, ERR_INVALID_ARG, "bad arguments");
+  h->T_stops.upload(T, n_stops, h->stream);
+  launch_rate_table(h->host.R, n_stops, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, h->T_stops.p, d_out, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_rhs_block_dev(kin_network* h, int64_t r_lo, int64_t r_hi, const double* d_u, double* d_du, void* stream) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(d_u && d_du, ERR_INVALID_ARG, "null device buffer");
+  require(h->has_rates, ERR_STATE, "rates were never set");
+  require(0 <= r_lo && r_lo <= r_hi && r_hi <= h->host.R, ERR_INVALID_ARG, "reaction block out of range");
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  // rates of the block, zeros elsewhere; the species-major gather then sums exactly this block's contributions
+  KIN_HIP(hipMemsetAsync(h->rate.p, 0, (size_t)h->host.R * sizeof(double), s));
+  launch_rates(r_hi - r_lo, h->k.p + r_lo, d_u, h->x0.p + r_lo, h->x1.p + r_lo, h->rate.p + r_lo, s);
+  launch_segsum(h->rhs_plan.view(), SEG_COEF_SET, h->rate.p, d_du, SegExtra{}, s);
+  KIN_CATCH(h)
+}
+
+int kin_solution_dot(const kin_network* hc, const double* w, double* out) {
+  kin_network* h = const_cast<kin_network*>(hc);
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(w && out, ERR_INVALID_ARG, "null buffer");
+  require(h->n_saved > 0, ERR_STATE, "no solution stored");
+  DevBuf<double> dw, dout;
+  dw.upload(w, h->host.N, h->stream);
+  dout.alloc(h->n_saved);
+  launch_rowdot((int)h->host.N, h->n_saved, h->d_sol_u.p, dw.p, dout.p, h->stream);
+  dout.download(out, h->n_saved, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  KIN_CATCH(h)
+}
+
+int kin_rate_table_rows(kin_network* h, const int64_t* rows, int64_t n_rows, double* out) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(rows && out && n_rows >= 0, ERR_INVALID_ARG, "bad arguments");
+  require(h->table_rows > 0, ERR_STATE, "no rate table resident (kin_rate_table / kin_solve with a table first)");
+  const int64_t R = h->host.R;
+  for (int64_t i = 0; i < n_rows; i++) {
+    require(rows[i] >= 0 && rows[i] < h->table_rows, ERR_INVALID_ARG, "row index out of range");
+    KIN_HIP(hipMemcpyAsync(out + (size_t)i * R, h->table.p + (size_t)rows[i] * R, R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  KIN_HIP(hipStreamSynchronize(h->stream));
   KIN_CATCH(h)
 }
 

@@ -595,6 +595,17 @@ __global__ __launch_bounds__(256) void colmax_kernel(int N, long long M, const d
   out[i] = v;
 }
 
+// out[t] = sum_i w[i] * U[t][i]: one 256-thread workgroup per saved state, fixed summation order
+__global__ __launch_bounds__(256) void rowdot_kernel(int N, const double* __restrict__ U, const double* __restrict__ w,
+                                                     double* __restrict__ out) {
+  __shared__ double sh[4];
+  const double* row = U + (size_t)blockIdx.x * N;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) acc += w[i] * row[i];
+  const double t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
 // rates kernel with a skip flag (Newton iterations)
 __global__ __launch_bounds__(256) void rates_skip_kernel(int R, const double* __restrict__ k, const double* __restrict__ u,
                                                          const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
@@ -654,6 +665,10 @@ void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f
 }
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s) {
   hipLaunchKernelGGL(colmax_kernel, GRID1(N), 0, s, N, (long long)M, U, out);
+}
+void launch_rowdot(int N, int64_t M, const double* U, const double* w, double* out, hipStream_t s) {
+  if (M == 0) return;
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)M), dim3(256), 0, s, N, U, w, out);
 }
 void launch_rates_skip(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate,
                        const int* skip, hipStream_t s) {

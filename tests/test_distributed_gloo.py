@@ -1,10 +1,14 @@
-"""CPU tests of the N>1 path: world-size-2 gloo processes exercising the partitioning,
-gathering and max-over-ranks logic bench.py and the ensemble driver use (no GPU needed)."""
+"""CPU tests of the N > 1 path: world-size-2 gloo processes. Every rank loads libkinetica_hip.so through the C ABI (on
+a box without a GPU the library must answer KIN_ERR_DEVICE - there is no CPU fallback to hide behind) and runs the
+collectives of kinetica_jl_amd.distributed on tensors: uneven row all-gather (rate-table slices), tensor-based
+ensemble gather, max-over-ranks. The same helpers run on device tensors over RCCL on a multi-GPU node and with two
+ranks on one card in tests/test_gpu_distributed.py."""
 import os
 import socket
 
 import numpy as np
 import pytest
+import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -20,14 +24,26 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from kinetica_jl_amd import capi
+        # (0) the product library is what each rank loads; without a device it refuses to compute
+        L = capi.lib()
+        assert all(hasattr(L, s) for s in ("kin_solution_max_dev", "kin_rate_table_dev", "kin_rhs_block_dev"))
+        status = None
+        if capi.device_count() == 0:
+            try:
+                capi.HipNetwork(2, [0, 1], [0], [1], [0, 1], [1], [1])
+            except capi.KineticaHipError as e:
+                status = e.code
         # (1) bench contract: step time = MAX over ranks
         t = D.max_over_ranks(1.0 + rank, dist)
-        # (2) rate table rows sharded over time stops, gathered in stop order
+        # (2) rate-table slices of uneven length (11 stops over 2 ranks: 6 + 5), gathered in stop order as tensors
         T = np.linspace(500.0, 1200.0, 11)
-        table = D.rate_table_sharded(lambda Ts: np.outer(Ts, [1.0, 2.0, 3.0]), T, dist)
-        # (3) ensemble of 5 independent solves, round-robin over ranks
-        res = D.solve_ensemble(list(range(5)), lambda m: {"member": m, "rank": dist.get_rank(), "umax": m * 10.0}, dist)
-        q.put((rank, t, table, res))
+        lo, hi = D.shard_range(len(T), rank, world)
+        mine = torch.tensor(np.outer(T[lo:hi], [1.0, 2.0, 3.0]))
+        table = D.all_gather_rows(mine, dist).numpy()
+        # (3) ensemble of 5 independent "solves", round-robin over ranks, results as float64 vectors
+        res = D.solve_ensemble(list(range(5)), lambda m: np.array([m, dist.get_rank(), m * 10.0]), dist)
+        q.put((rank, t, table, np.array(res), status))
     finally:
         dist.destroy_process_group()
 
@@ -39,16 +55,20 @@ def test_world_size_2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    out = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     T = np.linspace(500.0, 1200.0, 11)
-    for rank, t, table, res in out:
+    from kinetica_jl_amd import capi
+    for rank, t, table, res, status in out:
         assert t == 2.0                                               # max(1.0, 2.0)
         np.testing.assert_allclose(table, np.outer(T, [1.0, 2.0, 3.0]))
-        assert [r["member"] for r in res] == [0, 1, 2, 3, 4]
-        assert [r["rank"] for r in res] == [0, 1, 0, 1, 0]            # i % world
+        np.testing.assert_array_equal(res[:, 0], [0, 1, 2, 3, 4])
+        np.testing.assert_array_equal(res[:, 1], [0, 1, 0, 1, 0])     # i % world
+        np.testing.assert_array_equal(res[:, 2], [0, 10, 20, 30, 40])
+        if capi.device_count() == 0:
+            assert status == capi.KIN_ERR_DEVICE
 
 
 def test_shard_range_covers_everything():
@@ -60,4 +80,14 @@ def test_shard_range_covers_everything():
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
     assert D.max_over_ranks(3.5) == 3.5
-    assert D.solve_ensemble([1, 2, 3], lambda m: m * m) == [1, 4, 9]
+    r = D.solve_ensemble([1, 2, 3], lambda m: np.array([m * m]))
+    assert [float(x[0]) for x in r] == [1.0, 4.0, 9.0]
+
+
+def test_bench_self_launch_is_wired_before_any_gpu_call():
+    """bench.py --gpus N without a launcher must start its own ranks before touching the GPU: the launch branch sits in
+    front of `import torch` and of every capi call."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert body.index("self_launch(args)") < body.index("import torch") < body.index("torch.cuda.set_device")
+    assert body.index("measure_traffic(args)") < body.index("torch.cuda.set_device")
