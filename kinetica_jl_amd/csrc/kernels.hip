@@ -223,42 +223,41 @@ __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __r
   k[i] = arrhenius_one(Ea[i], A[i], 8.314462618 * T, has_kmax, k_max, t_mult);
 }
 
-// Table variant without IEEE divisions and with a lean exp (the table kernel is FP64-VALU bound: with two full
-// divisions and the library exp per element it ran at 2.0 ms for 14001 x 50000, against a 1.0 ms pure-store floor).
-// Ea/RT is a multiply by the row's reciprocal plus one FMA residual correction; exp is range reduction + a
-// degree-13 Taylor polynomial + ldexp with no special-case handling (<= 0.62 ulp on |x| <= 700, checked against
-// long double); the cap 1/(1/k_max + 1/k_r) is evaluated in exactly that form, 1/k_r = exp(+Ea/RT) / (A N_A t_mult),
-// with v_rcp_f64 and two Newton steps - an overflowing exp gives k = 0, the limit of the reference formula.
-// Deviation from the two-division form: <= (2 |Ea/RT| + 8) * 2^-53 relative (one ulp in the argument of
-// exp is amplified by |Ea/RT|), the bound the parity test applies element by element.
-__device__ __forceinline__ double exp_lean(double x) {
-  const double n = rint(x * 1.4426950408889634);
-  double r = fma(n, -6.93147180369123816490e-01, x);
-  r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
+// Table variant without IEEE divisions (the table kernel is FP64-VALU bound: with two full divisions and the library exp
+// per element it ran at 2.0 ms for 14001 x 50000, against a 1.0 ms pure-store floor). Ea/RT is a multiply by the row's
+// reciprocal plus one FMA residual correction; the cap 1/(1/k_max + 1/k_r) is evaluated in exactly that form,
+// 1/k_r = exp(+Ea/RT) / (A N_A t_mult), with v_rcp_f64 and two Newton steps - an overflowing exp gives k = 0, the limit
+// of the reference formula. Deviation from the two-division form: <= (2 |Ea/RT| + 8) * 2^-53 relative (one ulp in the
+// argument of exp is amplified by |Ea/RT|), the bound the parity test applies element by element.
+// Table-driven exp for the rate table (round 2): exp(x) = 2^m * T[j] * e^r with n = rint(x * 512/ln 2) = 512 m + j,
+// r = x - n ln2/512 (two-part constant, n * hi exact: hi has 31 significant bits, |n| < 2^21 after the clamp),
+// |r| <= ln2/1024 = 6.8e-4, e^r - 1 = r (1 + r (1/2 + r (1/6 + r/24))) (remainder r^5/120 < 1.3e-18 relative),
+// T[j] = 2^(j/512) correctly rounded (exp2_tab.inc), kept in LDS. 11 FP64 operations instead of the 19 of exp_lean
+// (degree-13 polynomial): the table kernel is FP64-VALU bound under sustained load. <= 1 ulp.
+__device__ const double kExp2Tab[512] = {
+#include "exp2_tab.inc"
+};
+
+__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ tab_s) {
+  const double n = rint(x * 0x1.71547652b82fep+9);
+  double r = fma(n, -0x1.62e42fec00000p-10, x);
+  r = fma(n, -0x1.d1cf79abc9e3bp-41, r);
+  const int ni = (int)n;
+  const double T = tab_s[ni & 511];
+  double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
+  return ldexp(fma(T, p * r, T), ni >> 9);
 }
 
 // c = A N_A t_mult, inv_c = 1 / c
 __device__ __forceinline__ double arrhenius_fast(double Ea, double c, double inv_c, double RT, double inv_RT, int has_kmax,
-                                                 double inv_kmax) {
+                                                 double inv_kmax, const double* __restrict__ tab_s) {
   double q = Ea * inv_RT;
   q = fma(fma(-q, RT, Ea), inv_RT, q);
-  if (!has_kmax) return c * exp_lean(-q);
-  const double x = fma(inv_c, exp_lean(q), inv_kmax);     // 1/k_max + 1/k_r
+  q = fmin(q, 800.0);                                     // e^800 overflows anyway; keeps n inside the table arithmetic
+  if (!has_kmax) return c * exp_tab(-q, tab_s);
+  const double x = fma(inv_c, exp_tab(q, tab_s), inv_kmax);     // 1/k_max + 1/k_r
   double y = __builtin_amdgcn_rcp(x);
   y = fma(fma(-x, y, 1.0), y, y);
   y = fma(fma(-x, y, 1.0), y, y);
@@ -274,6 +273,9 @@ __global__ __launch_bounds__(256) void rate_table_kernel(int n, int n_stops, con
                                                          double t_mult, const double* __restrict__ T,
                                                          double* __restrict__ table) {
   __shared__ double rt_s[TABLE_ROWS_PER_BLOCK], irt_s[TABLE_ROWS_PER_BLOCK];
+  __shared__ double tab_s[512];
+  tab_s[threadIdx.x] = kExp2Tab[threadIdx.x];
+  tab_s[threadIdx.x + 256] = kExp2Tab[threadIdx.x + 256];
   const int s0 = blockIdx.y * TABLE_ROWS_PER_BLOCK;
   const int s1 = min(n_stops, s0 + TABLE_ROWS_PER_BLOCK);
   if ((int)threadIdx.x < s1 - s0) {
@@ -290,14 +292,14 @@ __global__ __launch_bounds__(256) void rate_table_kernel(int n, int n_stops, con
   const double inv_kmax = 1.0 / k_max;
   for (int s = s0; s < s1; s++) {
     const double RT = rt_s[s - s0], inv_RT = irt_s[s - s0];
-    const double v0 = arrhenius_fast(e0, c0, ic0, RT, inv_RT, has_kmax, inv_kmax);
+    const double v0 = arrhenius_fast(e0, c0, ic0, RT, inv_RT, has_kmax, inv_kmax, tab_s);
     double* row = table + (size_t)s * n;
     if (pair && ((n & 1) == 0)) {
-      const double v1 = arrhenius_fast(e1, c1, ic1, RT, inv_RT, has_kmax, inv_kmax);
+      const double v1 = arrhenius_fast(e1, c1, ic1, RT, inv_RT, has_kmax, inv_kmax, tab_s);
       *reinterpret_cast<double2*>(row + r) = make_double2(v0, v1);
     } else {
       row[r] = v0;
-      if (pair) row[r + 1] = arrhenius_fast(e1, c1, ic1, RT, inv_RT, has_kmax, inv_kmax);
+      if (pair) row[r + 1] = arrhenius_fast(e1, c1, ic1, RT, inv_RT, has_kmax, inv_kmax, tab_s);
     }
   }
 }

@@ -230,17 +230,17 @@ void SparseLU::ensure_slots(int nslots, hipStream_t s) {
   }
 }
 
-void SparseLU::factor(double c, const double* d_jvals, int slot, hipStream_t s) {
+void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipStream_t s) {
   Slot& q = slots[slot];
   double* W = q.W.p;
   // zero everything up to the solve vectors, then scatter I - c*J
   KIN_HIP(hipMemsetAsync(W, 0, (size_t)off_y * sizeof(double), s));
   launch_lu_assemble(nnzJ, jmap.p, d_jvals, c, W, off_S, m, mpad, s);
   for (int r = 0; r < nrounds; r++) {
-    launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W, off_L, off_diag, s);
+    launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W, off_L, off_diag, bad, s);
     launch_segsum(schur[r].view(), SEG_PROD_SUB, W, W, SegExtra{}, s);
   }
-  if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, s);
+  if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, bad, s);
   q.c_fact = c;
   q.valid = true;
 }

@@ -68,7 +68,9 @@ struct SparseLU {
   void analyze(int32_t n, const std::vector<int32_t>& j_ptr, const std::vector<int32_t>& j_col,
                const LUOptions& opt, hipStream_t s);
   // M = I - c*J, factorised into slot `slot`
-  void factor(double c, const double* d_jvals, int slot, hipStream_t s);
+  // `bad`: device flag raised when a pivot vanishes (a multiplier exceeds 1e8 in magnitude or is not finite): pivoting
+  // is static (diagonal), so the caller answers with a fresh Jacobian and a shorter step
+  void factor(double c, const double* d_jvals, int slot, int* bad, hipStream_t s);
   // solves M x = b in place with the factors of `slot`: b was written to W[yloc[v]], x is read from W[xloc[v]]
   // (W = that slot's array). `skip`: optional device flag making every kernel of the solve a no-op.
   void solve(const int* skip, int slot, hipStream_t s);
@@ -77,8 +79,8 @@ struct SparseLU {
 // dense / LU helper kernels (solver_kernels.hip)
 void launch_lu_assemble(int64_t nnzJ, const int32_t* jmap, const double* jvals, double c, double* W,
                         int64_t off_S, int32_t m, int32_t mpad, hipStream_t s);
-void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, hipStream_t s);
-double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, hipStream_t s);
+void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, int* bad, hipStream_t s);
+double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, int* bad, hipStream_t s);
 void launch_gemv(const double* S, int32_t ld, int32_t m, const double* y, double* x, const int* skip, hipStream_t s);
 
 }  // namespace kin

@@ -105,6 +105,7 @@ struct Solver {
       int want = 32;
       double band = 0.35;
       size_t budget_mb = 16384;
+      if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
@@ -296,7 +297,7 @@ struct Solver {
 
   void invalidate_lu() {
     for (auto& q : lu.slots) { q.valid = false; q.c_fact = 0.0; q.last_use = 0; }
-    lu_valid = false; cur_slot = 0; use_clock = 0;
+    lu_valid = false; cur_slot = 0; use_clock = 0; attempt_no = 0;
   }
   // slot whose c_fact is closest (in ratio) to c and within the band; -1: none
   int nearest_slot(double c) const {
@@ -318,8 +319,13 @@ struct Solver {
     for (int i = 1; i < (int)lu.slots.size(); i++) if (lu.slots[i].last_use < lu.slots[v].last_use) v = i;
     return v;
   }
+  bool force_jac_refresh = false;   // a vanished pivot: the next attempt starts from a Jacobian at its own predictor
+  // fault injection for the tests (KIN_INJECT_BAD_PIVOT=n): the n-th step attempt of a solve finds the flag raised, as
+  // if its factorisation had met a vanishing pivot (in accuracy-controlled integration of mass-action kinetics that
+  // needs c J_ii ~ 1 on an autocatalytic species and practically never happens by itself)
+  int64_t inject_bad_pivot_at = -1, attempt_no = 0;
   void factor_into(int slot, double c) {
-    lu.factor(c, jv.p, slot, s);
+    lu.factor(c, jv.p, slot, &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;
     cur_slot = slot;
     st.n_factor++;
@@ -427,6 +433,13 @@ struct Solver {
       const double c = hh / cf.alpha[order];
       if (pre_attempt) pre_attempt(t_new);
       bool converged = false;
+      if (attempt_no++ == inject_bad_pivot_at) KIN_HIP(hipMemsetAsync(&ctrl.p->lu_bad, 1, sizeof(int), s));
+      if (force_jac_refresh) {
+        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+        eval_jac(y.p);
+        jac_current = true;
+        force_jac_refresh = false;
+      }
       // iteration matrix: the cached factorisation closest to this c, else a new one; `fresh` = made in this attempt
       // from the Jacobian of this attempt's predictor
       bool fresh = false;
@@ -452,6 +465,17 @@ struct Solver {
           wait_ctrl(seq_no);
         }
         converged = hc->newton_done && hc->converged && !hc->nonfinite;
+        if (hc->lu_bad) {
+          // a pivot of the factorisation in hand vanished (static pivoting): whatever the corrector did with it is
+          // discarded, the slot is dropped, and the step is retried at half the size from a fresh Jacobian
+          KIN_HIP(hipMemsetAsync(&ctrl.p->lu_bad, 0, sizeof(int), s));
+          lu.slots[cur_slot].valid = false;
+          lu_valid = false;
+          force_jac_refresh = true;
+          st.n_bad_pivot++;
+          converged = false;
+          break;
+        }
         if (converged) break;
         st.n_newton_fail++;
         if (lu_band > 0.0) {
@@ -742,8 +766,20 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   // very start overrides it below
   if (variable && !have_table) { /* rates at T_stops[0] are applied by the loop when tstops[0] == start */ }
 
+  // KIN_PROGRESS=<seconds>: a status line on stderr at most that often (the reference's `progress` option drives a
+  // progress bar from the same place, methods.jl:822-827)
+  const double progress_every = getenv("KIN_PROGRESS") ? std::max(1.0, atof(getenv("KIN_PROGRESS"))) : 0.0;
+  auto progress_last = wall0;
   for (int64_t nc = 0; nc < n_chunks && retcode == KIN_RETCODE_SUCCESS; nc++) {
     S.st.n_chunks++;
+    if (progress_every > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - progress_last).count() >= progress_every) {
+      progress_last = std::chrono::steady_clock::now();
+      fprintf(stderr, "[kin_solve] chunk %lld / %lld, %.1f s, %lld steps, %lld factorisations, %lld restarts\n", (long long)nc,
+              (long long)n_chunks, std::chrono::duration<double>(progress_last - wall0).count(), (long long)S.st.n_steps,
+              (long long)S.st.n_factor, (long long)S.st.n_restarts);
+      fflush(stderr);
+    }
     const double t_start_global = chunks ? p.solve_chunkstep * (double)nc : p.tspan0;
     const double t_end_global = chunks ? t_start_global + p.solve_chunkstep : p.tspan1;
     const double shift = chunks ? (double)nc * p.solve_chunkstep : 0.0;   // global = local + shift
@@ -862,6 +898,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   S.st.lu_dense_dim = S.lu.m; S.st.lu_sparse_rows = S.lu.ns; S.st.lu_rounds = S.lu.nrounds;
   S.st.lu_nnz = 2 * S.lu.nnzU + S.lu.ns + (int64_t)S.lu.m * S.lu.m;
   S.st.lu_slots = S.lu_slots;
+  S.force_jac_refresh = false;
   S.st.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   if (getenv("KIN_TIMING"))
     fprintf(stderr, "[kin_solve] wall %.4f s, of which blocked in step syncs %.4f s (the rest is host-side enqueue); "
@@ -1040,7 +1077,7 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
   const int N = S.N;
   S.y.upload(u, N, s);
   S.eval_jac(S.y.p);
-  S.lu.factor(c, S.jv.p, 0, s);
+  S.lu.factor(c, S.jv.p, 0, &S.ctrl.p->lu_bad, s);
   S.cur_slot = 0;
   std::vector<int32_t> yl(N), xl(N);
   S.lu.yloc.download(yl.data(), N, s);
@@ -1054,7 +1091,15 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
   KIN_HIP(hipMemcpyAsync(S.lu.slots[0].W.p + S.lu.off_y, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice, s));
   S.lu.solve(nullptr, 0, s);
   KIN_HIP(hipMemcpyAsync(tail.data(), S.lu.slots[0].W.p + S.lu.off_y, tail.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  int bad = 0;
+  KIN_HIP(hipMemcpyAsync(&bad, &S.ctrl.p->lu_bad, sizeof(int), hipMemcpyDeviceToHost, s));
   KIN_HIP(hipStreamSynchronize(s));
+  S.invalidate_lu();
+  if (bad) {
+    KIN_HIP(hipMemsetAsync(&S.ctrl.p->lu_bad, 0, sizeof(int), s));
+    KIN_HIP(hipStreamSynchronize(s));
+    throw KinError(ERR_SOLVE_FAILED, "vanishing pivot in the factorisation of I - c J (static diagonal pivoting)");
+  }
   for (int i = 0; i < N; i++) x[i] = tail[xl[i] - S.lu.off_y];
 }
 

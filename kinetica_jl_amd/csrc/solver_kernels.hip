@@ -37,17 +37,26 @@ void launch_lu_assemble(int64_t nnzJ, const int32_t* jmap, const double* jvals, 
 }
 
 // L[:, p] /= diag[p] for the pivots of one round
+// A pivot counts as vanished when a multiplier exceeds PIVOT_GROWTH_MAX in magnitude (or is not finite), or when the pivot
+// itself is below PIVOT_MIN in magnitude: the matrix is I - c J, whose natural scale is 1 (its pivots stay >= ~1 unless an
+// eigenvalue of c J comes close to 1, i.e. the matrix is close to singular).
+constexpr double PIVOT_GROWTH_MAX = 1e8;
+constexpr double PIVOT_MIN = 1e-8;
+
 __global__ __launch_bounds__(256) void lu_scale_kernel(int e0, int e1, const int32_t* __restrict__ ent_pivot, double* W,
-                                                       long long off_L, long long off_diag) {
+                                                       long long off_L, long long off_diag, int* bad) {
   const int e = e0 + blockIdx.x * 256 + threadIdx.x;
   if (e >= e1) return;
-  W[off_L + e] = W[off_L + e] / W[off_diag + ent_pivot[e]];
+  const double w = W[off_L + e], piv = W[off_diag + ent_pivot[e]];
+  const double l = w / piv;
+  if (bad && (!(fabs(piv) >= PIVOT_MIN) || (w != 0.0 && !(fabs(l) <= PIVOT_GROWTH_MAX)))) *bad = 1;   // benign race: every writer stores the same value
+  W[off_L + e] = l;
 }
 
-void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, hipStream_t s) {
+void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, int* bad, hipStream_t s) {
   if (e1 <= e0) return;
   hipLaunchKernelGGL(lu_scale_kernel, dim3((unsigned)ceil_div(e1 - e0, 256)), dim3(256), 0, s, (int)e0, (int)e1, ent_pivot,
-                     W, (long long)off_L, (long long)off_diag);
+                     W, (long long)off_L, (long long)off_diag, bad);
   KIN_HIP(hipGetLastError());
 }
 
@@ -79,7 +88,7 @@ __device__ __forceinline__ double fast_recip(double x) {
 // the next pivot block is the critical path of every gj_update_kernel launch (the tile updates take ~10 us,
 // the launch took 18 us with the earlier version that rewrote the whole block image in LDS every step).
 // The block is in A[0] on entry (A[1] provides the row / column buffers); the result goes to `pinv`.
-__device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1], double* __restrict__ pinv) {
+__device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1], double* __restrict__ pinv, int* bad) {
   const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
   double a[4];
 #pragma unroll
@@ -100,6 +109,9 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1
     __syncthreads();
     const double inv = fast_recip(rb[k]);
     const double aik = cb[r];
+    // vanished pivot: the multiplier of this row exceeds the growth bound (or the pivot is 0 / not finite)
+    if (bad && r != k && aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) *bad = 1;
+    if (bad && r == k && !(fabs(rb[k]) >= PIVOT_MIN)) *bad = 1;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const bool kc = (c0 + j == k);
@@ -111,20 +123,21 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1
   for (int j = 0; j < 4; j++) pinv[r * GJ_NB + c0 + j] = a[j];
 }
 
-__global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv) {
+__global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv, int* bad) {
   __shared__ double A[2][GJ_NB][GJ_NB + 1];
   const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
 #pragma unroll
   for (int j = 0; j < 4; j++) A[0][r][c0 + j] = X[(size_t)(kb * GJ_NB + r) * ld + kb * GJ_NB + c0 + j];
   __syncthreads();
-  gj_invert_block_lds(A, pinv);
+  gj_invert_block_lds(A, pinv, bad);
 }
 
 // grid = (mpad/64, 1 + mpad/64): block row 0 (dispatched first) holds ONE active workgroup (blockIdx.x == 0) that
 // looks ahead: it recomputes only the next pivot block of Y and inverts it into pinv_next while the
 // regular workgroups update their tiles, which takes the pivot inversion off the critical path.
 __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict__ X, double* __restrict__ Y, int ld, int kb,
-                                                        int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next) {
+                                                        int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next,
+                                                        int* bad) {
   __shared__ double RP[GJ_NB][64 + 2];                 // row panel slice of this tile's columns
   __shared__ double A[2][GJ_NB][GJ_NB + 1];            // look-ahead workgroup only
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
       for (int v = 0; v < 4; v++) A[0][16 * rb + 4 * v + lk][16 * cb + li] = xd[v] - acc[v];
     }
     __syncthreads();
-    gj_invert_block_lds(A, pinv_next);
+    gj_invert_block_lds(A, pinv_next, bad);
     return;
   }
   const int r0 = (blockIdx.y - 1) * 64 + 16 * w, c0 = blockIdx.x * 64;
@@ -215,15 +228,15 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
 }
 
 // returns the buffer that holds the inverse (S or S2)
-double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, hipStream_t s) {
+double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, int* bad, hipStream_t s) {
   const int nblk = mpad / GJ_NB;
   double* X = S;
   double* Y = S2;
   double* p_cur = pinv;                 // two 32x32 slots: current / next pivot-block inverse
   double* p_next = pinv + GJ_NB * GJ_NB;
-  hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, s, X, mpad, 0, p_cur);
+  hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(256), 0, s, X, mpad, 0, p_cur, bad);
   for (int kb = 0; kb < nblk; kb++) {
-    hipLaunchKernelGGL(gj_update_kernel, dim3(mpad / 64, mpad / 64 + 1), dim3(256), 0, s, X, Y, mpad, kb, nblk, p_cur, p_next);
+    hipLaunchKernelGGL(gj_update_kernel, dim3(mpad / 64, mpad / 64 + 1), dim3(256), 0, s, X, Y, mpad, kb, nblk, p_cur, p_next, bad);
     std::swap(X, Y);
     std::swap(p_cur, p_next);
   }

@@ -24,6 +24,8 @@ struct BdfCtrl {
   double scratch[3];
   int newton_done, converged, n_iter, nonfinite, any_negative;
   int ticket;   // arrival counter of the multi-workgroup reductions (back to 0 when a launch ends)
+  int lu_bad;   // set by a factorisation that met a vanishing pivot (|multiplier| > 1e8); cleared by the host, NOT by the predictor
+  int pad_;
 };
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,

@@ -139,3 +139,62 @@ def test_return_integrator_with_continuous_rates_and_the_explicit_guard():
     pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0, 0.0], solve_chunks=False, low_k_cutoff="none", solver="RK45")
     with pytest.raises(ValueError):
         S.solve_network(S.StaticODESolve(pars, cs, S.PrecalculatedArrheniusCalculator(Ea, A)), sd, rd, return_integrator=True)
+
+
+def _autocatalytic(order):
+    """A + B -> 2A (species order chosen by `order`): dA/dt = +k A B, so J_AA = k B > 0 and the Newton matrix I - c J has
+    the diagonal entry 1 - c k B, which vanishes at c = 1 / (k B)."""
+    a, b = order
+    net = from_lists(2, [[(a, 1), (b, 1)]], [[(a, 2)]])
+    return net, a, b
+
+
+def test_vanishing_pivot_is_detected_and_answered():
+    """Static (diagonal) pivoting meets a zero pivot: the factorisation raises the device flag (both the sparse
+    elimination and the dense Gauss-Jordan check their multipliers), kin_newton_solve reports it, and kin_solve answers
+    with a fresh Jacobian and half the step instead of iterating on garbage."""
+    # species 0 is eliminated first (sparse round), species 1 ends in the dense Schur block: with A first the zero is the
+    # sparse pivot 1 - c k B (c = 1/4 exactly); with B first it is the 1 x 1 Schur complement, det(I - c J) = 1 - 3 c
+    for order, c_sing in (((0, 1), 0.25), ((1, 0), 1.0 / 3.0)):
+        net, a, b = _autocatalytic(order)
+        h = capi.HipNetwork.from_flat(net)
+        h.set_rates([2.0])
+        u = np.zeros(2); u[a] = 0.5; u[b] = 2.0                      # k B = 4, k A = 1
+        rhs = np.array([1.0, -1.0])
+        x = h.newton_solve(0.125, u, rhs)                            # regular
+        on = orc.OracleNetwork.from_flat(net)
+        M = np.eye(2) - 0.125 * on.jac(np.array([2.0]), u).toarray()
+        np.testing.assert_allclose(M @ x, rhs, rtol=1e-13, atol=1e-15)
+        with pytest.raises(capi.KineticaHipError) as e:
+            h.newton_solve(c_sing, u, rhs)
+        assert e.value.code == capi.KIN_ERR_SOLVE_FAILED and "pivot" in str(e.value)
+        x2 = h.newton_solve(0.125, u, rhs)                           # the handle is usable afterwards
+        np.testing.assert_array_equal(x, x2)
+        h.close()
+    # inside kin_solve: the response to the flag (drop the slot, fresh Jacobian at the next predictor, half the step).
+    # An accuracy-controlled integration of mass-action kinetics keeps c J_ii << 1 even on an autocatalytic species (the
+    # first steps have c k B ~ 3e-5 whatever k is, later ones c k B < 0.1), so the flag is raised by fault injection at
+    # the 6th step attempt; everything downstream of the flag is the production path.
+    net, a, b = _autocatalytic((0, 1))
+    u0 = np.array([1e-3, 2.0])
+    k = 3.0e3
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates([k])
+    t0, ur, rc0, st0, _ = h.solve(kp((0.0, 1e-3), chunks=False, save=1e-4), u0)
+    h.close()
+    os.environ["KIN_INJECT_BAD_PIVOT"] = "5"
+    try:
+        h = capi.HipNetwork.from_flat(net)
+        h.set_rates([k])
+        t, u, rc, st, status = h.solve(kp((0.0, 1e-3), chunks=False, save=1e-4), u0)
+        h.close()
+    finally:
+        del os.environ["KIN_INJECT_BAD_PIVOT"]
+    assert rc0 == 0 and st0["n_bad_pivot"] == 0
+    assert status == capi.KIN_OK and rc == 0 and st["n_bad_pivot"] == 1
+    assert st["n_rejected"] >= 1 and st["n_jac"] >= st0["n_jac"] + 1
+    # logistic growth of A at constant A + B: closed form. The solution grows 337-fold over the span and local errors grow
+    # with it (an unstable direction), hence the wider band than for the decaying test problems
+    S_ = u0.sum()
+    A = S_ / (1.0 + (S_ / u0[0] - 1.0) * np.exp(-k * S_ * t))
+    assert errscale(u[:, 0], A) < 1000 and errscale(ur[:, 0], A) < 1000
