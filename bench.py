@@ -233,6 +233,16 @@ def main():
                          "sustained_frac": None if not sustained_ms else alg_bytes / (sustained_ms * 1e-3) / 8e12},
         }
 
+    # ---- ONE trajectory's RHS with the reactions split over the ranks and an all-reduce of du (N doubles):
+    # measured at N > 1 so that the cost of the single-trajectory decomposition is a number, not an argument
+    if world > 1:
+        from kinetica_jl_amd.distributed import time_rhs_reaction_blocks
+        h.set_rates(k1000)
+        split = time_rhs_reaction_blocks(h, d_u[0].clone(), dist, reps=200)
+        if rank == 0:
+            out["single_trajectory_rhs_allreduce"] = dict(split, note="reaction blocks of one RHS over the ranks + SUM all-reduce of "
+                                                          "du (RCCL) against the whole RHS on one rank: microseconds per evaluation")
+
     # ---- single-state RHS latency (what the integrator sees), rank 0 only
     if rank == 0:
         u1 = 10.0 ** np.random.default_rng(0).uniform(-12, 0, N)

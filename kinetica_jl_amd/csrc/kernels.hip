@@ -41,6 +41,7 @@ __device__ __forceinline__ SegPre seg_pre(const double* out, const double* src, 
   if (dst < 0) return q;
   if (OP == SEG_PROD_SUB) q.o = out[dst];
   else if (OP == SEG_PROD_SUB_DIV) { q.o = out[dst]; q.a = src[aux]; }
+  else if (OP == SEG_PROD_AUXSUB) q.o = src[aux];
   else if (OP == SEG_COEF_BDF) { q.a = ex.psi[aux]; q.b = ex.d[aux]; }
   return q;
 }
@@ -49,9 +50,11 @@ __device__ __forceinline__ void seg_store(double* out, int32_t dst, double acc, 
   if (OP == SEG_COEF_SET) out[dst] = acc;
   else if (OP == SEG_PROD_SUB) out[dst] = q.o - acc;
   else if (OP == SEG_PROD_SUB_DIV) out[dst] = (q.o - acc) / q.a;
+  else if (OP == SEG_PROD_AUXSUB) out[dst] = q.o - acc;
+  else if (OP == SEG_PROD_SET) out[dst] = acc;
   else out[dst] = ex.cscal * acc - q.a - q.b;
 }
-template <int OP> struct seg_is_prod { static constexpr bool v = (OP == SEG_PROD_SUB || OP == SEG_PROD_SUB_DIV); };
+template <int OP> struct seg_is_prod { static constexpr bool v = (OP == SEG_PROD_SUB || OP == SEG_PROD_SUB_DIV || OP == SEG_PROD_AUXSUB || OP == SEG_PROD_SET); };
 
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed butterfly order -> bitwise reproducible
@@ -150,6 +153,8 @@ void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* ou
       case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, src, out, ex); break;
       case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, src, out, ex); break;
       case SEG_PROD_SUB_DIV: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SUB_DIV>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_AUXSUB: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_AUXSUB>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_SET: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SET>, grid, block, 0, s, p, src, out, ex); break;
     }
   }
   if (p.F > 0) {
@@ -159,6 +164,8 @@ void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* ou
       case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, src, out, ex); break;
       case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, src, out, ex); break;
       case SEG_PROD_SUB_DIV: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB_DIV>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_AUXSUB: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_AUXSUB>, grid, block, 0, s, p, src, out, ex); break;
+      case SEG_PROD_SET: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SET>, grid, block, 0, s, p, src, out, ex); break;
     }
   }
   KIN_HIP(hipGetLastError());

@@ -32,6 +32,8 @@ enum SegOp : int {
   SEG_COEF_BDF = 2,   // out[dst]  = cscal * (sum c * src[a]) - psi[aux] - d[aux]   (Newton residual of a BDF step;
                       //            aux = species index, dst = position in the permuted solve vector)
   SEG_PROD_SUB_DIV = 3,  // out[dst] = (out[dst] - sum src[a] * src[b]) / src[aux]        (backward substitution)
+  SEG_PROD_AUXSUB = 4,   // out[dst] = src[aux] - sum src[a] * src[b]     (explicit triangular inverses: y1 = b1 - Z' b1, t = y1 - U12 x2)
+  SEG_PROD_SET = 5,      // out[dst] = sum src[a] * src[b]                 (x1 = V t)
 };
 struct SegExtra {  // extra operands of SEG_COEF_BDF
   const double* psi = nullptr; const double* d = nullptr; double cscal = 0.0;

@@ -1,6 +1,8 @@
 #include "lu.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
 #include <numeric>
 
 namespace kin {
@@ -137,7 +139,92 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   off_S = align(off_L + nnzU);
   off_y = align(off_S + (int64_t)mpad * mpad);
   off_x = align(off_y + n);
-  w_size = align(off_x + mpad + 8);
+  int64_t w_end = align(off_x + mpad + 8);
+
+  // ---- explicit inverses of the sparse triangular blocks (symbolic): monomials along the elimination DAG
+  struct Mono { float sign; std::vector<int32_t> fac; };
+  std::vector<int32_t> m_ent_ptr{0}, m_ptr{0}, m_fac, m_dst;
+  std::vector<float> m_sign;
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> z_cols(ns), v_cols(ns);   // per row: (column, entry slot)
+  explicit_tri = !(getenv("KIN_LU_EXPLICIT") && atoi(getenv("KIN_LU_EXPLICIT")) == 0) && ns > 0;
+  if (explicit_tri) {
+    // rows of L11 and U11 (entries between two sparse pivots)
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> Lrow(ns), Urow(ns);   // (other index, entry e)
+    for (int32_t p = 0; p < ns; p++)
+      for (int32_t e = ent_ptr[p]; e < ent_ptr[p + 1]; e++)
+        if (nbr[e] < ns) { Lrow[nbr[e]].push_back({p, e}); Urow[p].push_back({nbr[e], e}); }
+    const int64_t mono_limit = 4000000;
+    int64_t total = 0;
+    off_dinv = w_end;                       // provisional: positions needed as factor indices below
+    const int64_t dinv0 = off_dinv;
+    // Z = L11^-1: Z[i,:] = e_i - sum_k L[i,k] Z[k,:], rows in increasing order
+    std::vector<std::map<int32_t, std::vector<Mono>>> zr(ns), vr(ns);
+    for (int32_t i = 0; i < ns && explicit_tri; i++)
+      for (auto& ke : Lrow[i]) {
+        if (!explicit_tri) break;
+        const int32_t k = ke.first, le = (int32_t)(off_L + ke.second);
+        zr[i][k].push_back(Mono{-1.0f, {le}});
+        total++;
+        for (auto& pm : zr[k])
+          for (const Mono& mo : pm.second) {
+            if (!explicit_tri) break;
+            Mono nm{-mo.sign, mo.fac};
+            nm.fac.push_back(le);
+            zr[i][pm.first].push_back(std::move(nm));
+            if (++total > mono_limit) { explicit_tri = false; break; }
+          }
+      }
+    // V' = (I + D^-1 U11s)^-1: V'[i,:] = e_i - sum_c (U[i,c] dinv_i) V'[c,:], rows in decreasing order; V = V' D^-1
+    for (int32_t i = ns - 1; i >= 0 && explicit_tri; i--)
+      for (auto& ce : Urow[i]) {
+        if (!explicit_tri) break;
+        const int32_t c = ce.first, ue = (int32_t)(off_U + ce.second), di = (int32_t)(dinv0 + i);
+        vr[i][c].push_back(Mono{-1.0f, {ue, di}});
+        total++;
+        for (auto& jm : vr[c])
+          for (const Mono& mo : jm.second) {
+            if (!explicit_tri) break;
+            Mono nm{-mo.sign, mo.fac};
+            nm.fac.push_back(ue); nm.fac.push_back(di);
+            vr[i][jm.first].push_back(std::move(nm));
+            if (++total > mono_limit) { explicit_tri = false; break; }
+          }
+      }
+    if (explicit_tri) {
+      // entry slots: Z off-diagonals (stored NEGATED: y1_i = b_i - sum Z'[i,p] b_p), then V including its diagonal
+      nnzZ = 0; nnzV = 0;
+      for (int32_t i = 0; i < ns; i++) nnzZ += (int64_t)zr[i].size();
+      for (int32_t i = 0; i < ns; i++) nnzV += (int64_t)vr[i].size() + 1;
+      off_dinv = w_end;
+      off_Z = align(off_dinv + ns);
+      off_V = align(off_Z + nnzZ);
+      off_y1 = align(off_V + nnzV);
+      off_t = align(off_y1 + ns);
+      w_end = align(off_t + ns + 8);
+      int64_t ez = 0, ev = 0;
+      auto emit = [&](int64_t dst_pos, const std::vector<Mono>& monos, float flip, int32_t extra) {
+        for (const Mono& mo : monos) {
+          m_sign.push_back(flip * mo.sign);
+          for (int32_t f : mo.fac) m_fac.push_back(f);
+          if (extra >= 0) m_fac.push_back(extra);
+          m_ptr.push_back((int32_t)m_fac.size());
+        }
+        m_dst.push_back((int32_t)dst_pos);
+        m_ent_ptr.push_back((int32_t)m_sign.size());
+      };
+      for (int32_t i = 0; i < ns; i++)
+        for (auto& pm : zr[i]) { z_cols[i].push_back({pm.first, (int32_t)ez}); emit(off_Z + ez, pm.second, -1.0f, -1); ez++; }
+      for (int32_t i = 0; i < ns; i++) {
+        v_cols[i].push_back({i, (int32_t)ev});
+        emit(off_V + ev, std::vector<Mono>{Mono{1.0f, {}}}, 1.0f, (int32_t)(off_dinv + i));   // V[i,i] = 1 / d_i
+        ev++;
+        for (auto& jm : vr[i]) { v_cols[i].push_back({jm.first, (int32_t)ev}); emit(off_V + ev, jm.second, 1.0f, (int32_t)(off_dinv + jm.first)); ev++; }
+      }
+      n_monomials = (int64_t)m_sign.size();
+      n_mono_ent = (int32_t)m_dst.size();
+    }
+  }
+  w_size = w_end;
   if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
 
   auto pos_of = [&](int32_t j, int32_t c) -> int64_t {  // location of W[j][c] (new indices), j,c later than the pivot
@@ -194,7 +281,44 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
         per_round[round_of(q)].push_back({off_y + q, (int32_t)(off_L + e), (int32_t)(off_y + p)});
       }
     for (int r = 0; r < nrounds; r++) fwd[r].upload(plan_from_triples(per_round[r], false, 0, 0), s);
+    if (explicit_tri)   // the dense rows read y1 from its own vector (the sparse rows are not updated in place any more)
+      for (Triple& t : per_round[nrounds]) t.b = (int32_t)(off_y1 + (t.b - off_y));
     fwd_dense.upload(plan_from_triples(per_round[nrounds], false, 0, 0), s);
+  }
+  if (explicit_tri) {
+    // y1_i = b_i - sum_p Z'[i,p] b_p
+    {
+      std::vector<int32_t> ptr{0}, dst, aux, a, b;
+      for (int32_t i = 0; i < ns; i++) {
+        for (auto& ce : z_cols[i]) { a.push_back((int32_t)(off_Z + ce.second)); b.push_back((int32_t)(off_y + ce.first)); }
+        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y1 + i)); aux.push_back((int32_t)(off_y + i));
+      }
+      a.push_back(0); b.push_back(0);
+      fwdZ.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+    }
+    // t_p = y1_p - sum_{c dense} U[p,c] x2_c
+    {
+      std::vector<int32_t> ptr{0}, dst, aux, a, b;
+      for (int32_t p = 0; p < ns; p++) {
+        for (int32_t e = ent_ptr[p]; e < ent_ptr[p + 1]; e++)
+          if (nbr[e] >= ns) { a.push_back((int32_t)(off_U + e)); b.push_back((int32_t)(off_x + nbr[e] - ns)); }
+        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_t + p)); aux.push_back((int32_t)(off_y1 + p));
+      }
+      a.push_back(0); b.push_back(0);
+      bwdT.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+    }
+    // x1_i = sum_j V[i,j] t_j
+    {
+      std::vector<int32_t> ptr{0}, dst, a, b;
+      for (int32_t i = 0; i < ns; i++) {
+        for (auto& ce : v_cols[i]) { a.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_t + ce.first)); }
+        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y + i));
+      }
+      bwdV.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
+    }
+    mono_ent_ptr.upload(m_ent_ptr, s); mono_ptr.upload(m_ptr, s); mono_fac.upload(m_fac, s); mono_dst.upload(m_dst, s);
+    mono_sign.upload(m_sign, s);
+    KIN_HIP(hipStreamSynchronize(s));
   }
   // ---- backward substitution: x_p = (y_p - sum_c U[p][c] x_c) / diag_p
   for (int r = 0; r < nrounds; r++) {
@@ -240,6 +364,10 @@ void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipSt
     launch_lu_scale(ent_ptr[round_ptr[r]], ent_ptr[round_ptr[r + 1]], ent_pivot.p, W, off_L, off_diag, bad, s);
     launch_segsum(schur[r].view(), SEG_PROD_SUB, W, W, SegExtra{}, s);
   }
+  if (explicit_tri) {
+    launch_lu_recip(ns, W + off_diag, W + off_dinv, s);
+    launch_lu_mono(n_mono_ent, mono_ent_ptr.p, mono_ptr.p, mono_fac.p, mono_sign.p, mono_dst.p, W, s);
+  }
   if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, bad, s);
   q.c_fact = c;
   q.valid = true;
@@ -250,6 +378,16 @@ void SparseLU::solve(const int* skip, int slot, hipStream_t s) {
   double* W = q.W.p;
   SegExtra ex;
   ex.skip = skip;
+  if (explicit_tri) {
+    launch_segsum(fwdZ.view(), SEG_PROD_AUXSUB, W, W, ex, s);
+    if (m > 0) {
+      launch_segsum(fwd_dense.view(), SEG_PROD_SUB, W, W, ex, s);
+      launch_gemv(q.sinv, mpad, m, W + off_y + ns, W + off_x, skip, s);
+    }
+    launch_segsum(bwdT.view(), SEG_PROD_AUXSUB, W, W, ex, s);
+    launch_segsum(bwdV.view(), SEG_PROD_SET, W, W, ex, s);
+    return;
+  }
   for (int r = 1; r < nrounds; r++) launch_segsum(fwd[r].view(), SEG_PROD_SUB, W, W, ex, s);
   if (m > 0) {
     if (ns > 0) launch_segsum(fwd_dense.view(), SEG_PROD_SUB, W, W, ex, s);

@@ -51,6 +51,7 @@ struct SparseLU {
     const double* sinv = nullptr;           // where the inverse of the Schur block ended up (inside W or S2)
     double c_fact = 0.0;
     int64_t last_use = 0;
+    int64_t jac_stamp = 0;                  // restart counter at the time the Jacobian behind this factorisation was evaluated
     bool valid = false;
   };
   std::vector<Slot> slots;
@@ -63,6 +64,18 @@ struct SparseLU {
   std::vector<int32_t> ent_ptr;             // host: entries of pivot p are [ent_ptr[p], ent_ptr[p+1])
   std::vector<SegPlanDev> schur, fwd, bwd;  // per round
   SegPlanDev fwd_dense;
+  // Explicit inverses of the sparse triangular blocks. The sparse-to-sparse parts L11 / U11 of the factors are tiny (7 k
+  // entries at 10k species; the bulk of L and U couples the sparse pivots to the dense block) and shallow (depth = rounds),
+  // so their inverses Z = L11^-1, V = U11^-1 are formed entry by entry at every factorisation (each entry = a short sum
+  // of products along the elimination DAG, one small launch) and a solve becomes
+  //   y1 = Z b1 | y2 = b2 - L21 y1 | x2 = S^-1 y2 | t = y1 - U12 x2 | x1 = V t
+  // = 5 dependent launches instead of 2 * rounds + 3 (15 at 6 rounds): the Newton iteration is a latency chain.
+  bool explicit_tri = false;
+  int64_t off_Z = 0, off_V = 0, off_dinv = 0, off_y1 = 0, off_t = 0, nnzZ = 0, nnzV = 0, n_monomials = 0;
+  int32_t n_mono_ent = 0;
+  DevBuf<int32_t> mono_ent_ptr, mono_ptr, mono_fac, mono_dst;
+  DevBuf<float> mono_sign;
+  SegPlanDev fwdZ, bwdT, bwdV;
   int64_t nnzJ = 0;
 
   void analyze(int32_t n, const std::vector<int32_t>& j_ptr, const std::vector<int32_t>& j_col,
@@ -80,6 +93,9 @@ struct SparseLU {
 void launch_lu_assemble(int64_t nnzJ, const int32_t* jmap, const double* jvals, double c, double* W,
                         int64_t off_S, int32_t m, int32_t mpad, hipStream_t s);
 void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W, int64_t off_L, int64_t off_diag, int* bad, hipStream_t s);
+void launch_lu_recip(int n, const double* diag, double* dinv, hipStream_t s);
+void launch_lu_mono(int n_ent, const int32_t* ent_ptr, const int32_t* mono_ptr, const int32_t* fac, const float* sign,
+                    const int32_t* dst, double* W, hipStream_t s);
 double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, int* bad, hipStream_t s);
 void launch_gemv(const double* S, int32_t ld, int32_t m, const double* y, double* x, const int* skip, hipStream_t s);
 

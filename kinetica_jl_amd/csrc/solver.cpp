@@ -101,11 +101,16 @@ struct Solver {
     if (const char* e = getenv("KIN_LU_MAX_DEGREE")) opt.max_degree = atoi(e);
     lu.analyze(N, H.j_ptr, H.j_col, opt, s);
     {
-      // cache size: KIN_LU_CACHE_SLOTS (default 32), bounded by KIN_LU_CACHE_MB (default 16384) of device memory
-      int want = 32;
+      // cache size: KIN_LU_CACHE_SLOTS (default 128), bounded by KIN_LU_CACHE_MB (default 32768) of device memory. A
+      // restart replays a ramp of step sizes over up to ~12 decades of c; slots sit >= 35 % apart, i.e. ~8 per decade:
+      // the cache must hold the whole ramp (~90 slots), or the cyclic sweep evicts every slot just before its next
+      // use (32 slots: the full C4 run made 405 k factorisations; its first second, a narrower ramp, only 446)
+      int want = 128;
       double band = 0.35;
-      size_t budget_mb = 16384;
+      size_t budget_mb = 32768;
       if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
+      if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
+      if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
@@ -195,7 +200,7 @@ struct Solver {
 
   void rhs(const double* u, double* out) { h->rhs_dev(u, out); st.n_rhs++; }
 
-  void eval_jac(const double* u) { h->jac_dev(u, jv.p); st.n_jac++; lu_valid = false; }
+  void eval_jac(const double* u) { h->jac_dev(u, jv.p); st.n_jac++; lu_valid = false; steps_since_jac = 0; jac_stamp_now = st.n_restarts; }
 
   void change_D(int ord, double factor) {
     double R[6][6], U[6][6];
@@ -263,6 +268,9 @@ struct Solver {
     n_equal = 0;
     lu_valid = false;
     fail_score = 0.0;
+    // three failed attempts in a row: nothing cached is trusted any more either
+    for (auto& q : lu.slots) q.valid = false;
+    force_jac_refresh = true;
   }
 
   // Warm continuation at a segment boundary (chunk start or rate update): the system is autonomous
@@ -281,6 +289,17 @@ struct Solver {
     }
   }
 
+  double reuse_rate_max = 0.1;   // KIN_LU_RATE_MAX: slowest contraction accepted from a reused factorisation
+  // KIN_LU_MAX_AGE: a slot is offered for that many restarts after its Jacobian was evaluated. Unlimited reuse is
+  // UNSAFE: a direction that was stiff when the slot was made (c J ~ 1e6) and is not any more (its species consumed) is
+  // damped to nothing by the old matrix - the corrections vanish, the corrector "converges" at once, and both the
+  // convergence test and the error test (which only see the corrections) are blind to the component being left at its
+  // predictor; the full C4 ramp then ran into DtLessThanMin a few hundred restarts later (with 5 restarts it runs
+  // through). CVODE bounds the same staleness by re-evaluating J at least every 50 steps.
+  int64_t lu_max_age = 5;
+  bool cache_suspended = false;  // a tolerance retry (adaptive_solve!) runs its chunk without the cache
+  int64_t jac_stamp_now = 0;     // restart counter at the last Jacobian evaluation
+  bool slot_is_fresh = false;
   void newton_iteration(int it, double c) {
     const int* skip = &ctrl.p->newton_done;
     SparseLU::Slot& q = lu.slots[cur_slot];
@@ -291,13 +310,18 @@ struct Solver {
     lu.solve(skip, cur_slot, s);
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
     const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
-    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd, ctrl.p, red.p, s);
+    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd,
+                      (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, ctrl.p, red.p, s);
     st.n_rhs++; st.n_linsolve++;
   }
 
+  void invalidate_lu_keep_counters() {
+    for (auto& q : lu.slots) q.valid = false;
+    lu_valid = false; cur_slot = 0; force_fresh_lu = false;
+  }
   void invalidate_lu() {
     for (auto& q : lu.slots) { q.valid = false; q.c_fact = 0.0; q.last_use = 0; }
-    lu_valid = false; cur_slot = 0; use_clock = 0; attempt_no = 0;
+    lu_valid = false; cur_slot = 0; use_clock = 0; attempt_no = 0; force_fresh_lu = false; steps_since_jac = 0; cache_suspended = false;
   }
   // slot whose c_fact is closest (in ratio) to c and within the band; -1: none
   int nearest_slot(double c) const {
@@ -305,7 +329,7 @@ struct Solver {
     double bd = 1e300;
     for (int i = 0; i < (int)lu.slots.size(); i++) {
       const SparseLU::Slot& q = lu.slots[i];
-      if (!q.valid) continue;
+      if (!q.valid || st.n_restarts - q.jac_stamp > lu_max_age) continue;
       const double r = std::fabs(std::log(c / q.c_fact));
       if (r < bd && std::fabs(c / q.c_fact - 1.0) <= lu_band) { bd = r; best = i; }
     }
@@ -313,20 +337,29 @@ struct Solver {
   }
   // a slot for a new factorisation: an unused one (allocated on demand), else the least recently used
   int victim_slot() {
-    for (int i = 0; i < (int)lu.slots.size(); i++) if (!lu.slots[i].valid) return i;
+    for (int i = 0; i < (int)lu.slots.size(); i++)
+      if (!lu.slots[i].valid || st.n_restarts - lu.slots[i].jac_stamp > lu_max_age) return i;
     if ((int)lu.slots.size() < lu_slots) { lu.ensure_slots((int)lu.slots.size() + 1, s); return (int)lu.slots.size() - 1; }
     int v = 0;
     for (int i = 1; i < (int)lu.slots.size(); i++) if (lu.slots[i].last_use < lu.slots[v].last_use) v = i;
     return v;
   }
   bool force_jac_refresh = false;   // a vanished pivot: the next attempt starts from a Jacobian at its own predictor
+  // After an error-test rejection the retry gets a factorisation made for its own c (CVODE's rule: a failed error test
+  // forces a linear-solver setup): a converged corrector whose matrix was reused carries an iteration error that the
+  // rate estimate may understate, and a rejected step moves on to ever older slots at smaller c - without this rule the
+  // full C4 ramp spiralled into DtLessThanMin once the cache held the whole step-size ramp.
+  bool force_fresh_lu = false;
+  int64_t steps_since_jac = 0;
   // fault injection for the tests (KIN_INJECT_BAD_PIVOT=n): the n-th step attempt of a solve finds the flag raised, as
   // if its factorisation had met a vanishing pivot (in accuracy-controlled integration of mass-action kinetics that
   // needs c J_ii ~ 1 on an autocatalytic species and practically never happens by itself)
   int64_t inject_bad_pivot_at = -1, attempt_no = 0;
+  bool trace = false;   // KIN_TRACE_CHUNK=n: one line per corrector attempt of chunk n (diagnostic)
   void factor_into(int slot, double c) {
     lu.factor(c, jv.p, slot, &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;
+    lu.slots[slot].jac_stamp = jac_stamp_now;
     cur_slot = slot;
     st.n_factor++;
   }
@@ -443,16 +476,28 @@ struct Solver {
       // iteration matrix: the cached factorisation closest to this c, else a new one; `fresh` = made in this attempt
       // from the Jacobian of this attempt's predictor
       bool fresh = false;
+      const double lu_band = cache_suspended ? 0.0 : this->lu_band;   // shadows the member for this attempt
       if (lu_band > 0.0) {
         const int hit = nearest_slot(c);
-        if (hit >= 0) { cur_slot = hit; lu.slots[hit].last_use = ++use_clock; st.n_lu_reused++; }
-        else { factor_into(victim_slot(), c); fresh = jac_current; }
+        if (hit >= 0 && !force_fresh_lu) { cur_slot = hit; lu.slots[hit].last_use = ++use_clock; st.n_lu_reused++; }
+        else {
+          if (force_fresh_lu && !jac_current && steps_since_jac > 20) {   // an old Jacobian is refreshed on the way
+            launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+            eval_jac(y.p);
+            jac_current = true;
+          }
+          factor_into(hit >= 0 ? hit : victim_slot(), c);
+          fresh = jac_current;
+        }
+        force_fresh_lu = false;
       } else if (!lu_valid) {
         factor_into(0, c);
         lu_valid = true;
         fresh = jac_current;
       }
       for (;;) {
+        // a matrix made in this attempt for this c counts as fresh even when the Jacobian behind it is a few steps old
+        slot_is_fresh = fresh || lu.slots[cur_slot].c_fact == c;
         launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
         newton_iteration(0, c);
         newton_iteration(1, c);
@@ -465,6 +510,10 @@ struct Solver {
           wait_ctrl(seq_no);
         }
         converged = hc->newton_done && hc->converged && !hc->nonfinite;
+        if (trace)
+          fprintf(stderr, "[trace] t=%.6e h=%.3e order=%d c=%.3e slot=%d c_fact=%.3e fresh=%d jac_cur=%d -> done=%d conv=%d iters=%d dy=%.3e err=%.3e nonfinite=%d lu_bad=%d\n",
+                  t, h_abs, order, c, cur_slot, lu.slots[cur_slot].c_fact, (int)fresh, (int)jac_current, hc->newton_done, hc->converged,
+                  hc->n_iter, hc->dy_norm, hc->err_norm, hc->nonfinite, hc->lu_bad);
         if (hc->lu_bad) {
           // a pivot of the factorisation in hand vanished (static pivoting): whatever the corrector did with it is
           // discarded, the slot is dropped, and the step is retried at half the size from a fresh Jacobian
@@ -510,6 +559,8 @@ struct Solver {
         continue;
       }
       iter_hist[std::min(hc->n_iter, 7)]++;
+      // a reused factorisation that needed every allowed iteration is too stale to be offered again
+      if (lu_band > 0.0 && !fresh && hc->n_iter >= BDF_NEWTON_MAXITER) lu.slots[cur_slot].valid = false;
       safety = 0.9 * (2.0 * BDF_NEWTON_MAXITER + 1.0) / (2.0 * BDF_NEWTON_MAXITER + hc->n_iter);
       err_norm = hc->err_norm;
       if (err_norm > 1.0) {
@@ -517,7 +568,9 @@ struct Solver {
         h_abs *= factor;
         change_D(order, factor);
         n_equal = 0;
-        // the corrector converged with this iteration matrix: it is kept for the retry
+        // without the cache the matrix is kept for the retry (the corrector converged with it; the update is scaled for
+        // the new c); with the cache the retry gets a factorisation of its own
+        force_fresh_lu = lu_band > 0.0;
         st.n_rejected++;
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
@@ -526,6 +579,7 @@ struct Solver {
       }
     }
     st.n_steps++;
+    steps_since_jac++;
     fail_score = std::max(0.0, fail_score - 0.2);
     n_equal++;
     t = t_new;
@@ -770,8 +824,11 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   // progress bar from the same place, methods.jl:822-827)
   const double progress_every = getenv("KIN_PROGRESS") ? std::max(1.0, atof(getenv("KIN_PROGRESS"))) : 0.0;
   auto progress_last = wall0;
+  const long long trace_chunk = getenv("KIN_TRACE_CHUNK") ? atoll(getenv("KIN_TRACE_CHUNK")) : -1;
   for (int64_t nc = 0; nc < n_chunks && retcode == KIN_RETCODE_SUCCESS; nc++) {
     S.st.n_chunks++;
+    S.cache_suspended = false;
+    S.trace = (nc == trace_chunk);
     if (progress_every > 0.0 &&
         std::chrono::duration<double>(std::chrono::steady_clock::now() - progress_last).count() >= progress_every) {
       progress_last = std::chrono::steady_clock::now();
@@ -880,12 +937,17 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
         break;
       }
       // ---- failure: tighten tolerances and redo this chunk from its start state
+      if (progress_every > 0.0 || getenv("KIN_TIMING"))
+        fprintf(stderr, "[kin_solve] chunk %lld attempt %d failed with retcode %d at local t = %.6e (h = %.3e, order %d); tolerances %.1e / %.1e\n",
+                (long long)nc, attempts, retcode, t_seg + S.t, S.h_abs, S.order, abstol, reltol);
       rates_in_force = -1;
       const double mintol = std::numeric_limits<double>::epsilon();
       if (!p.adaptive_tols || attempts >= 5 || abstol / 10 <= mintol || reltol / 10 <= mintol) break;
       abstol /= 10; reltol /= 10;
       S.set_tols(abstol, reltol);
       S.st.n_retries++;
+      S.invalidate_lu_keep_counters();
+      S.cache_suspended = true;
       KIN_HIP(hipMemcpyAsync(S.y.p, chunk_start.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
       h->n_saved = saved_at_chunk_start;
       h->sol_t.resize(times_at_chunk_start);
@@ -1086,7 +1148,7 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
   KIN_HIP(hipStreamSynchronize(s));
   std::vector<double> stage(N);
   // the solve vectors live at the tail of W: write b there element by element
-  std::vector<double> tail(S.lu.w_size - S.lu.off_y, 0.0);
+  std::vector<double> tail((size_t)(S.lu.off_x + S.lu.mpad + 8 - S.lu.off_y), 0.0);   // the solve vectors only
   for (int i = 0; i < N; i++) tail[yl[i] - S.lu.off_y] = b[i];
   KIN_HIP(hipMemcpyAsync(S.lu.slots[0].W.p + S.lu.off_y, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice, s));
   S.lu.solve(nullptr, 0, s);

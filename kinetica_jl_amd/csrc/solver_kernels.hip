@@ -60,6 +60,36 @@ void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W
   KIN_HIP(hipGetLastError());
 }
 
+// dinv[p] = 1 / diag[p] for the sparse pivots
+__global__ __launch_bounds__(256) void lu_recip_kernel(int n, const double* __restrict__ diag, double* __restrict__ dinv) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dinv[i] = 1.0 / diag[i];
+}
+
+// Entries of the explicit inverses of the sparse triangular blocks: out[dst[e]] = sum over the entry's monomials of
+// sign * product of factor values (paths through the elimination DAG; structure built once in SparseLU::analyze)
+__global__ __launch_bounds__(256) void lu_mono_kernel(int n_ent, const int32_t* __restrict__ ent_ptr, const int32_t* __restrict__ mono_ptr,
+                                                      const int32_t* __restrict__ fac, const float* __restrict__ sign,
+                                                      const int32_t* __restrict__ dst, double* W) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_ent) return;
+  double acc = 0.0;
+  for (int32_t m = ent_ptr[e]; m < ent_ptr[e + 1]; m++) {
+    double prod = (double)sign[m];
+    for (int32_t f = mono_ptr[m]; f < mono_ptr[m + 1]; f++) prod *= W[fac[f]];
+    acc += prod;
+  }
+  W[dst[e]] = acc;
+}
+
+void launch_lu_recip(int n, const double* diag, double* dinv, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(lu_recip_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, n, diag, dinv);
+}
+void launch_lu_mono(int n_ent, const int32_t* ent_ptr, const int32_t* mono_ptr, const int32_t* fac, const float* sign,
+                    const int32_t* dst, double* W, hipStream_t s) {
+  if (n_ent > 0) hipLaunchKernelGGL(lu_mono_kernel, dim3((unsigned)ceil_div(n_ent, 256)), dim3(256), 0, s, n_ent, ent_ptr, mono_ptr, fac, sign, dst, W);
+}
+
 // ------------------------------------------------------------------------------------------
 // Blocked Gauss-Jordan inverse of the dense Schur block (no pivoting), NB = 32, 2 m^3 flops.
 // Block step k reads the current matrix X and writes the next one Y (ping-pong, so no tile ever
@@ -358,7 +388,7 @@ __device__ __forceinline__ double sum_partials(const double* part, int n) {
 __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
                                                          const double* __restrict__ W, const double* __restrict__ scale,
                                                          double* __restrict__ y, double* __restrict__ d, double upd,
-                                                         BdfCtrl* ctrl, double* __restrict__ part) {
+                                                         double rate_max, BdfCtrl* ctrl, double* __restrict__ part) {
   __shared__ double sh[4];
   __shared__ int last;
   if (ctrl->newton_done) return;
@@ -396,7 +426,9 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     const bool have_rate = iter > 0;
     const double rate = have_rate ? dy_norm / old : 0.0;
     bool diverged = (nbad > 0.0) || !isfinite(dy_norm);
-    if (!diverged && have_rate && (rate >= 1.0 || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
+    // rate_max < 1 (a reused factorisation): a contraction slower than that means the matrix no longer matches the
+    // Jacobian well enough for the error of the iteration to be judged from two or three corrections
+    if (!diverged && have_rate && (rate >= rate_max || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
     ctrl->n_iter = iter + 1;
     ctrl->dy_norm = dy_norm;
     if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nbad > 0.0; }
@@ -640,8 +672,8 @@ void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, do
 }
 int bdf_reduce_blocks(int N) { return (int)ceil_div(N, RED_ELEMS); }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, double upd, BdfCtrl* ctrl, double* part, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, ctrl, part);
+                       double* y, double* d, double upd, double rate_max, BdfCtrl* ctrl, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, rate_max, ctrl, part);
 }
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
                       const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,

@@ -31,7 +31,7 @@ struct BdfCtrl {
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
                         double* d, double* scale, BdfCtrl* ctrl, hipStream_t s);   // also clears *ctrl
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, double upd, BdfCtrl* ctrl, double* part, hipStream_t s);   // dy = upd * x
+                       double* y, double* d, double upd, double rate_max, BdfCtrl* ctrl, double* part, hipStream_t s);   // dy = upd * x
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
                       const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
                       unsigned long long seq, hipStream_t s);   // host_ctrl / host_seq: device-visible pinned host memory (or null)

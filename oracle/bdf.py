@@ -67,7 +67,7 @@ class OracleBDF:
     """fun(y) -> f, jac(y) -> scipy CSR (autonomous system: the rate constants are frozen
     between restarts, exactly as in the discrete-rate solves of methods.jl:655-865)."""
 
-    def __init__(self, fun, jac, n, atol, rtol, dtmin=0.0, ban_negatives=False, scipy_newton=False, lu_band=0.35, lu_slots=32):
+    def __init__(self, fun, jac, n, atol, rtol, dtmin=0.0, ban_negatives=False, scipy_newton=False, lu_band=0.35, lu_slots=128):
         # scipy_newton=True reproduces SciPy's corrector acceptance (tolerance from Hairer's RADAU5
         # heuristic, no acceptance on the first iteration) and exists only for the step-for-step
         # pin test; the production rule below is the one of the BDF codes themselves.
@@ -78,6 +78,16 @@ class OracleBDF:
         # that used it fails. lu_band = 0: a new factorisation at every change of c (SciPy's behaviour).
         self.lu_band = 0.0 if scipy_newton else lu_band
         self.lu_slots = lu_slots
+        # guards of the cache (solver.cpp): a reused factorisation must contract at least 10-fold per iteration
+        # (lu_rate_max); after an error-test rejection the retry gets a factorisation of its own (force_fresh_lu, with a
+        # new Jacobian if the old one is more than 20 steps old); a reused slot that needed every allowed iteration is dropped
+        self.lu_rate_max = 0.1
+        self.lu_max_age = 5              # restarts a slot stays on offer after its Jacobian was evaluated
+        self.jac_stamp_now = 0
+        self.cache_suspended = False     # a tolerance retry runs its chunk without the cache
+        self.force_fresh_lu = False
+        self.steps_since_jac = 0
+        self.slot_is_fresh = True
         self.slots = []          # dicts: c_fact, LU, last_use
         self.use_clock = 0
         self.c_fact = 0.0
@@ -115,6 +125,8 @@ class OracleBDF:
     def _nearest_slot(self, c):
         best, bd = None, 1e300
         for sl in self.slots:
+            if self.stats["n_restarts"] - sl["jac_stamp"] > self.lu_max_age:
+                continue
             r = abs(math.log(c / sl["c_fact"]))
             if r < bd and abs(c / sl["c_fact"] - 1.0) <= self.lu_band:
                 best, bd = sl, r
@@ -122,13 +134,17 @@ class OracleBDF:
 
     def _factor_into(self, sl, c):
         if sl is None:
-            if len(self.slots) < self.lu_slots:
+            expired = [q for q in self.slots if self.stats["n_restarts"] - q["jac_stamp"] > self.lu_max_age]
+            if expired:
+                sl = expired[0]
+            elif len(self.slots) < self.lu_slots:
                 sl = {}
                 self.slots.append(sl)
             else:
                 sl = min(self.slots, key=lambda q: q["last_use"])
         sl["LU"] = self._factor(c)
         sl["c_fact"] = c
+        sl["jac_stamp"] = self.jac_stamp_now
         self.use_clock += 1
         sl["last_use"] = self.use_clock
         return sl
@@ -138,17 +154,26 @@ class OracleBDF:
         attempt from a current Jacobian refreshes the slot (Jacobian at the predictor, factorisation at this c), one retry."""
         sl = self._nearest_slot(c)
         fresh = False
-        if sl is not None:
+        if sl is not None and not self.force_fresh_lu:
             self.use_clock += 1
             sl["last_use"] = self.use_clock
             self.stats["n_lu_reused"] += 1
         else:
-            sl = self._factor_into(None, c)
+            if self.force_fresh_lu and not self.jac_current and self.steps_since_jac > 20:
+                self.J = self.jac(y_pred); self.stats["n_jac"] += 1
+                self.jac_current = True
+                self.steps_since_jac = 0
+                self.jac_stamp_now = self.stats["n_restarts"]
+            sl = self._factor_into(sl, c)
             fresh = self.jac_current
+        self.force_fresh_lu = False
         while True:
             self.LU, self.c_fact = sl["LU"], sl["c_fact"]
+            self.slot_is_fresh = fresh or sl["c_fact"] == c
             converged, n_iter, y_new, d = self._newton(y_pred, c, psi, scale)
             if converged:
+                if not fresh and n_iter >= NEWTON_MAXITER:
+                    self.slots = [q for q in self.slots if q is not sl]          # too stale to be offered again
                 return converged, n_iter, y_new, d
             self.stats["n_newton_fail"] += 1
             if fresh:
@@ -156,6 +181,8 @@ class OracleBDF:
             if not self.jac_current:
                 self.J = self.jac(y_pred); self.stats["n_jac"] += 1
                 self.jac_current = True
+                self.steps_since_jac = 0
+                self.jac_stamp_now = self.stats["n_restarts"]
             self._factor_into(sl, c)
             fresh = True
 
@@ -195,6 +222,8 @@ class OracleBDF:
         self.order = 1
         self.n_equal = 0
         self.J = self.jac(y0); self.stats["n_jac"] += 1
+        self.steps_since_jac = 0
+        self.jac_stamp_now = self.stats["n_restarts"]
         self.LU = None
         self.jac_current = True
         self.pending = None
@@ -215,6 +244,7 @@ class OracleBDF:
         self.n_equal = 0
         self.LU = None
         self.fail_score = 0.0
+        self.slots = []                   # three failed attempts in a row: nothing cached is trusted any more either
         self.stats["n_resets"] = self.stats.get("n_resets", 0) + 1
 
     def resume(self, rates_changed):
@@ -261,10 +291,11 @@ class OracleBDF:
             if self.pre_attempt is not None:
                 self.pre_attempt(t_new)
             converged = False
-            while self.lu_band > 0:
+            use_cache = self.lu_band > 0 and not self.cache_suspended
+            while use_cache:
                 converged, n_iter, y_new, d = self._corrector_cached(c, y_pred, psi, scale)
                 break
-            while not self.lu_band > 0:
+            while not use_cache:
                 if self.LU is None:
                     self.LU = self._factor(c)
                     self.c_fact = c
@@ -296,7 +327,8 @@ class OracleBDF:
                 self.h_abs *= factor
                 change_D(D, order, factor)
                 self.n_equal = 0
-                # the corrector converged with this iteration matrix: it is kept for the retry
+                # without the cache the matrix is kept for the retry; with it the retry gets a factorisation of its own
+                self.force_fresh_lu = self.lu_band > 0 and not self.cache_suspended
                 self.stats["n_rejected"] += 1
                 self.fail_score += 1.0
                 if self.fail_score >= 3.0 and order > 1:
@@ -305,6 +337,7 @@ class OracleBDF:
             else:
                 accepted = True
         self.stats["n_steps"] += 1
+        self.steps_since_jac += 1
         self.fail_score = max(0.0, self.fail_score - 0.2)
         self.n_equal += 1
         self.t = t_new
@@ -338,7 +371,8 @@ class OracleBDF:
                 break
             dy_norm = rms(dy / scale)
             rate = None if dy_norm_old is None else dy_norm / dy_norm_old
-            if rate is not None and (rate >= 1 or rate ** (NEWTON_MAXITER - k) / (1 - rate) * dy_norm > self.newton_tol):
+            rate_max = self.lu_rate_max if (self.lu_band > 0 and not self.cache_suspended and not self.slot_is_fresh) else 1.0
+            if rate is not None and (rate >= rate_max or rate ** (NEWTON_MAXITER - k) / (1 - rate) * dy_norm > self.newton_tol):
                 break
             y += dy
             d += dy
@@ -477,7 +511,7 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
             dtmin = float(np.spacing(abs(chunkstep if chunks else tspan1)))
         bdf = OracleBDF(lambda y: fun_of_k(state["k"])(y), lambda y: jac_of_k(state["k"])(y), n, abstol, reltol,
                         dtmin=dtmin, ban_negatives=params.get("ban_negatives", False),
-                        lu_band=params.get("lu_band", 0.35), lu_slots=params.get("lu_slots", 32))
+                        lu_band=params.get("lu_band", 0.35), lu_slots=params.get("lu_slots", 128))
     # continuous rate updates (methods.jl:363-653): k re-evaluated at the global time of every step attempt
     seg_origin = [0.0]
     if k_of_time is not None:
@@ -501,6 +535,8 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
         y_start = y.copy()
         n_out_start = len(out_t)
         attempts = 0
+        if hasattr(bdf, "cache_suspended"):
+            bdf.cache_suspended = False
         while True:
             attempts += 1
             if attempts > 1:
@@ -577,6 +613,9 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
             rates_in_force = -1
             bdf.set_tols(abstol, reltol)
             n_retries += 1
+            if hasattr(bdf, "cache_suspended"):
+                bdf.invalidate_lu()
+                bdf.cache_suspended = True
             y = y_start.copy()
             del out_t[n_out_start:]; del out_u[n_out_start:]
         if retcode != RET_SUCCESS:

@@ -416,8 +416,13 @@ struct Bdf {
   // (4 per decade) and reused - across step-size changes AND across restarts - while |c / c_fact - 1| <= lu_reuse,
   // with the update scaled by 2 / (1 + c / c_fact); a slot is refreshed (new Jacobian, new factorisation) only when a
   // corrector that used it fails. lu_cache = number of slots (0: off).
+  double lu_rate_max = 0.1;   // slowest contraction accepted from a reused factorisation
+  bool force_fresh_lu = false, slot_is_fresh = true;
+  int64_t steps_since_jac = 0;
   int lu_cache = 0;
-  struct Slot { double c_fact = 0.0; int64_t last_use = 0; std::vector<double> Lx, Ux, Udiag; };
+  struct Slot { double c_fact = 0.0; int64_t last_use = 0, jac_stamp = 0; std::vector<double> Lx, Ux, Udiag; };
+  int64_t lu_max_age = 5, jac_stamp_now = 0;   // restarts a slot stays on offer after its Jacobian was evaluated
+  bool cache_suspended = false;                // a tolerance retry runs its chunk without the cache
   std::vector<Slot> slots;          // the value arrays of the ACTIVE slot live in `lu` (swapped in)
   int active_slot = -1;
   int64_t use_clock = 0, n_cache_hits = 0;
@@ -425,6 +430,7 @@ struct Bdf {
   int nearest_slot(double c) const {      // the slot whose c_fact is closest to c in ratio, -1 if none within the band
     int best = -1; double bd = 1e300;
     for (int i = 0; i < (int)slots.size(); i++) {
+      if (st.n_restarts - slots[i].jac_stamp > lu_max_age) continue;
       const double r = std::fabs(std::log(c / slots[i].c_fact));
       if (r < bd && std::fabs(c / slots[i].c_fact - 1.0) <= lu_reuse) { bd = r; best = i; }
     }
@@ -439,8 +445,10 @@ struct Bdf {
   int new_slot() {                        // a free slot, else the least recently used one
     if (active_slot >= 0) swap_arrays(slots[active_slot]);
     active_slot = -1;
-    int i;
-    if ((int)slots.size() < lu_cache) { slots.emplace_back(); i = (int)slots.size() - 1; }
+    int i = -1;
+    for (int j = 0; j < (int)slots.size() && i < 0; j++) if (st.n_restarts - slots[j].jac_stamp > lu_max_age) i = j;
+    if (i >= 0) {}
+    else if ((int)slots.size() < lu_cache) { slots.emplace_back(); i = (int)slots.size() - 1; }
     else { i = 0; for (int j = 1; j < (int)slots.size(); j++) if (slots[j].last_use < slots[i].last_use) i = j; }
     swap_arrays(slots[i]);
     // working arrays of the right size (refactor overwrites every entry; the first, pivoting factorisation sizes them)
@@ -478,7 +486,7 @@ struct Bdf {
   double* Drow(int j) { return D.data() + (size_t)j * N; }
   void set_tols(double a, double r) { atol = a; rtol = r; newton_tol = std::max(10.0 * EPS / r, 0.05); }
   void fun(const double* u, double* out) { const double t0 = now_s(); net.rhs(k, u, out); st.n_rhs++; st.t_rhs += now_s() - t0; }
-  void eval_jac(const double* u) { const double t0 = now_s(); net.jac(k, u, J.data()); st.n_jac++; lu_valid = false; st.t_jac += now_s() - t0; }
+  void eval_jac(const double* u) { const double t0 = now_s(); net.jac(k, u, J.data()); st.n_jac++; lu_valid = false; steps_since_jac = 0; jac_stamp_now = st.n_restarts; st.t_jac += now_s() - t0; }
   double rms_scaled(const double* v, const double* sc) const {
     double s = 0.0;
     for (int64_t i = 0; i < N; i++) { const double q = v[i] / sc[i]; s += q * q; }
@@ -555,6 +563,7 @@ struct Bdf {
     std::fill(D.begin(), D.end(), 0.0);
     for (int64_t i = 0; i < N; i++) { D[i] = tmp[i]; D[(size_t)N + i] = f[i] * h_abs; }
     order = 1; n_equal = 0; lu_valid = false; fail_score = 0.0; st.n_resets++;
+    clear_cache();   // three failed attempts in a row: nothing cached is trusted any more either
   }
   // returns converged; n_iter out
   bool newton(double c, int& n_iter) {
@@ -578,7 +587,8 @@ struct Bdf {
       const double dy_norm = rms_scaled(dy.data(), scale.data());
       const bool have_rate = dy_norm_old >= 0.0;
       const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
-      if (have_rate && (rate >= 1.0 || std::pow(rate, NEWTON_MAXITER - kk) / (1.0 - rate) * dy_norm > newton_tol)) break;
+      const double rate_max = (lu_cache > 0 && !cache_suspended && !slot_is_fresh) ? lu_rate_max : 1.0;
+      if (have_rate && (rate >= rate_max || std::pow(rate, NEWTON_MAXITER - kk) / (1.0 - rate) * dy_norm > newton_tol)) break;
       for (int64_t i = 0; i < N; i++) { y[i] += dy[i]; d[i] += dy[i]; }
       if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < newton_tol) || (!have_rate && dy_norm < newton_tol)) {
         converged = true;
@@ -594,30 +604,39 @@ struct Bdf {
   bool corrector_cached(double c, int& n_iter) {
     bool fresh = false;
     int i = nearest_slot(c);
-    if (i >= 0) {
+    if (i >= 0 && !force_fresh_lu) {
       activate(i);
       n_cache_hits++;
     } else {
-      if (getenv("CPUB_TRACE")) fprintf(stderr, "[cache] miss c=%.3e\n", c);
-      i = new_slot();
+      if (force_fresh_lu && !jac_current && steps_since_jac > 20) { eval_jac(ypred.data()); jac_current = true; }
+      if (i >= 0) activate(i); else i = new_slot();
       const int64_t pb = lu.n_full;
       if (!factor(c)) return false;
       if (lu.n_full != pb && pb != 0) { keep_only_active(); i = 0; }
-      slots[i].c_fact = c; fresh = jac_current;
+      slots[i].c_fact = c; slots[i].jac_stamp = jac_stamp_now; fresh = jac_current;
     }
+    force_fresh_lu = false;
     slots[i].last_use = ++use_clock;
     c_fact = slots[i].c_fact;
+    slot_is_fresh = fresh || c_fact == c;
     bool converged = newton(c, n_iter);
-    if (converged) return true;
+    if (converged) {
+      if (!fresh && n_iter >= NEWTON_MAXITER) {   // too stale to be offered again
+        if (active_slot >= 0) swap_arrays(slots[active_slot]);
+        slots.erase(slots.begin() + i);
+        active_slot = -1;
+      }
+      return true;
+    }
     st.n_newton_fail++;
     if (fresh) return false;            // current Jacobian, matrix made for this c: the step itself is too long
-    if (getenv("CPUB_TRACE")) fprintf(stderr, "[cache] refresh-after-failure c=%.3e c/c_fact=%.3f n_iter=%d\n", c, c / c_fact, n_iter);
     if (!jac_current) { eval_jac(ypred.data()); jac_current = true; }
     const int64_t pb = lu.n_full;
     if (!factor(c)) return false;
     if (lu.n_full != pb) { keep_only_active(); i = 0; }
-    slots[i].c_fact = c; slots[i].last_use = ++use_clock;
+    slots[i].c_fact = c; slots[i].last_use = ++use_clock; slots[i].jac_stamp = jac_stamp_now;
     c_fact = c;
+    slot_is_fresh = true;
     converged = newton(c, n_iter);
     if (!converged) st.n_newton_fail++;
     return converged;
@@ -652,7 +671,7 @@ struct Bdf {
       const double c = h / ALPHA[order];
       bool converged = false;
       int n_iter = 0;
-      if (lu_cache > 0) {
+      if (lu_cache > 0 && !cache_suspended) {
         converged = corrector_cached(c, n_iter);
       } else
       for (;;) {
@@ -694,7 +713,7 @@ struct Bdf {
         h_abs *= factor;
         change_D(order, factor);
         n_equal = 0;
-        if (lu_reuse > 0.0) { /* kept if the new c stays inside the reuse band */ }
+        force_fresh_lu = lu_cache > 0 && !cache_suspended;
         st.n_rejected++;
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
@@ -703,6 +722,7 @@ struct Bdf {
       }
     }
     st.n_steps++;
+    steps_since_jac++;
     fail_score = std::max(0.0, fail_score - 0.2);
     n_equal++;
     t = t_new;
@@ -813,7 +833,7 @@ int solve(Handle& H, const CpuParams& p, const double* u0, const double* k0, con
   B.lu_reuse = p.lu_reuse;
   B.step_thresh = p.step_thresh;
   B.lu_cache = (int)p.lu_cache;
-  B.clear_cache(); B.n_cache_hits = 0;
+  B.clear_cache(); B.n_cache_hits = 0; B.force_fresh_lu = false; B.steps_since_jac = 0;
   {
     const double xx = std::fabs(chunks ? p.solve_chunkstep : p.tspan1);
     B.dtmin = p.dtmin > 0.0 ? p.dtmin : std::nextafter(xx, INF) - xx;
@@ -831,6 +851,7 @@ int solve(Handle& H, const CpuParams& p, const double* u0, const double* k0, con
     const double shift = chunks ? (double)nc * p.solve_chunkstep : 0.0;
     const double t_loc0 = chunks ? 0.0 : p.tspan0, t_loc1 = chunks ? p.solve_chunkstep : p.tspan1;
     y_start = y;
+    B.cache_suspended = false;
     const size_t n_out_start = H.sol_t.size();
     int attempts = 0;
     for (;;) {
@@ -891,6 +912,7 @@ int solve(Handle& H, const CpuParams& p, const double* u0, const double* k0, con
       rates_in_force = -1;
       B.set_tols(abstol, reltol);
       B.st.n_retries++;
+      B.clear_cache(); B.lu_valid = false; B.cache_suspended = true;
       y = y_start;
       H.sol_t.resize(n_out_start);
       H.sol_u.resize(n_out_start * (size_t)N);

@@ -118,7 +118,7 @@ class CpuSolver:
                       solve_chunkstep=params.get("solve_chunkstep", 1e-3), maxiters=int(params.get("maxiters", 100000)),
                       save_interval=-1.0 if si is None else si, dtmin=params.get("dtmin", 0.0),
                       lu_reuse=params.get("lu_band", 0.35), step_thresh=params.get("step_thresh", 0.0),
-                      lu_cache=int(params.get("lu_slots", 32)))
+                      lu_cache=int(params.get("lu_slots", 128)))
         u0 = _f64(u0)
         n_stops = 0
         if tstops is not None and len(tstops):

@@ -33,8 +33,8 @@ sweep = [r for r in rows if "kin::sweep_" in r["Name"]][0]
 line = [l for l in open(os.path.join(out, "bench_stats.log")) if l.startswith("{")][-1]
 bench = json.loads(line)
 summary = {
-    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --solve-chunks 5 --cpu-solve-chunks 0 ; "
-               "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 5 --solve-chunks 0 --no-cpu",
+    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --solve-chunks 20 --cpu-solve-chunks 0 --no-pmc --sustain-seconds 0.5 ; "
+               "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 5 --solve-chunks 0 --no-cpu --no-pmc --sustain-seconds 0",
     "workload": bench["config"]["workload"],
     "kernel": sweep["Name"].split("(")[0],
     "calls": int(sweep["Calls"]), "avg_ns_rocprof": float(sweep["AverageNs"]),
