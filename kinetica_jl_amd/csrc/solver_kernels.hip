@@ -125,6 +125,7 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1
   for (int j = 0; j < 4; j++) a[j] = A[0][r][c0 + j];
   double* rowbuf = &A[1][0][0];                 // [2][GJ_NB]
   double* colbuf = rowbuf + 2 * GJ_NB;          // [2][GJ_NB]
+  bool vanished = false;                        // pivot guard: kept in a register, one store after the loop
   for (int k = 0; k < GJ_NB; k++) {
     double* rb = rowbuf + (k & 1) * GJ_NB;
     double* cb = colbuf + (k & 1) * GJ_NB;
@@ -139,9 +140,8 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1
     __syncthreads();
     const double inv = fast_recip(rb[k]);
     const double aik = cb[r];
-    // vanished pivot: the multiplier of this row exceeds the growth bound (or the pivot is 0 / not finite)
-    if (bad && r != k && aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) *bad = 1;
-    if (bad && r == k && !(fabs(rb[k]) >= PIVOT_MIN)) *bad = 1;
+    // vanished pivot: the multiplier of this row exceeds the growth bound, or the pivot is tiny / 0 / not finite
+    vanished |= (r != k) ? (aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) : !(fabs(rb[k]) >= PIVOT_MIN);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const bool kc = (c0 + j == k);
@@ -151,6 +151,7 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) pinv[r * GJ_NB + c0 + j] = a[j];
+  if (bad && vanished) *bad = 1;                // benign race: every writer stores the same value
 }
 
 __global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv, int* bad) {

@@ -14,6 +14,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg_stats" -- python3 tools/run_configs.py c5sweep table > "$OUT/cfg_stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cfg_fetch" -- python3 tools/run_configs.py c5sweep table > "$OUT/cfg_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cfg_write" -- python3 tools/run_configs.py c5sweep table > "$OUT/cfg_write.log" 2>&1
+# the implicit solve alone (C3, 20 chunks): per-kernel time of the BDF step chain
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solve_stats" -- python3 tools/solve_stats.py 10000 50000 20 > "$OUT/solve_stats.log" 2>&1
 python3 tools/summarize_profiles.py "$OUT" "$TAG"
 # keep the merge-back small
 find "$OUT" -name "*kernel_trace.csv" -delete

@@ -75,3 +75,16 @@ if cfg_stats:
                                "hbm_bytes_per_launch_corrected": hbm, "traffic_over_algorithmic": hbm / alg})
     json.dump(cfg, open(os.path.join(dst, f"{tag}_c5_table_pmc.json"), "w"), indent=1)
     print(json.dumps(cfg["kernels"], indent=1))
+
+
+# ---- the implicit solve (tools/solve_stats.py 10000 50000 20 = warm-up solve + timed solve)
+sol = glob.glob(os.path.join(out, "solve_stats", "**", "*kernel_stats.csv"), recursive=True)
+if sol:
+    srows = list(csv.DictReader(open(sol[0])))
+    with open(os.path.join(dst, f"{tag}_solve_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=srows[0].keys())
+        w.writeheader()
+        w.writerows([r for r in srows if "kin::" in r["Name"]])
+    rec = [l for l in open(os.path.join(out, "solve_stats.log")) if l.startswith("{")]
+    if rec:
+        open(os.path.join(dst, f"{tag}_solve_stats.json"), "w").write(rec[-1])
