@@ -136,6 +136,7 @@ typedef struct kin_stats {
   int64_t n_lu_reused;   /* step attempts that started on a cached factorisation (the solver's LU cache) */
   int64_t lu_slots;      /* size of that cache */
   int64_t n_bad_pivot;   /* factorisations dropped because a pivot vanished (answered by a fresh Jacobian and half the step) */
+  int64_t n_lu_dropped;  /* cached factorisations dropped at a restart because the Jacobian's diagonal had drifted */
 } kin_stats;
 
 /* ---- A4/A5/A9/A10: the solve --------------------------------------------------------- */

@@ -42,7 +42,7 @@ class KinStats(ctypes.Structure):
     _fields_ = [(n, c_int64) for n in ("n_steps", "n_rejected", "n_rhs", "n_jac", "n_factor", "n_linsolve",
                                         "n_newton_fail", "n_chunks", "n_restarts", "n_retries")] + \
                [("final_abstol", c_double), ("final_reltol", c_double), ("wall_seconds", c_double)] + \
-               [(n, c_int64) for n in ("lu_dense_dim", "lu_sparse_rows", "lu_rounds", "lu_nnz", "n_lu_reused", "lu_slots", "n_bad_pivot")]
+               [(n, c_int64) for n in ("lu_dense_dim", "lu_sparse_rows", "lu_rounds", "lu_nnz", "n_lu_reused", "lu_slots", "n_bad_pivot", "n_lu_dropped")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -48,6 +48,7 @@ struct SparseLU {
   // 10k species, 157 MB at 50k) and are reused across step-size changes and across restarts.
   struct Slot {
     DevBuf<double> W, S2;
+    DevBuf<double> jd;                      // diag(J) of the Jacobian behind this factorisation (drift test of the LU cache)
     const double* sinv = nullptr;           // where the inverse of the Schur block ended up (inside W or S2)
     double c_fact = 0.0;
     int64_t last_use = 0;

@@ -111,11 +111,15 @@ struct Solver {
       if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
       if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
       if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
+      if (const char* e = getenv("KIN_LU_DRIFT")) lu_drift_max = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
       const size_t fit = std::max<size_t>(1, budget_mb * 1024 * 1024 / std::max<size_t>(1, lu.slot_bytes()));
-      lu_slots = (int)std::min<size_t>((size_t)want, fit);
+      lu_slots = (int)std::min<size_t>(std::min<size_t>((size_t)want, fit), (size_t)LU_MAX_SLOTS);
+      d_jdiag.upload(H.j_diag, s);
+      d_drift.alloc(LU_MAX_SLOTS);
+      KIN_HIP(hipHostMalloc((void**)&h_drift, LU_MAX_SLOTS * sizeof(double), hipHostMallocDefault));
       lu_band = lu_slots > 1 ? band : 0.0;
       if (lu_slots == 1 && getenv("KIN_LU_BAND")) lu_band = band;   // single slot with a reuse band: CVODE's own scheme
     }
@@ -146,7 +150,7 @@ struct Solver {
     for (int j = 0; j <= BDF_MAX_ORDER; j++) cf.error_const[j] = KAPPA[j] * cf.gamma[j] + 1.0 / (j + 1);
     cf.error_const[BDF_MAX_ORDER + 1] = 0.0;
   }
-  ~Solver() { if (hc) (void)hipHostFree(hc); if (hseq) (void)hipHostFree(hseq); }
+  ~Solver() { if (hc) (void)hipHostFree(hc); if (hseq) (void)hipHostFree(hseq); if (h_drift) (void)hipHostFree(h_drift); }
 
   void set_tols(double a, double r) {
     atol = a; rtol = r;
@@ -221,9 +225,25 @@ struct Solver {
   bool restart(double t0, double t_bound) {
     t = t0;
     st.n_restarts++;
+    // the Jacobian of the restart state first (it does not depend on the step size chosen below): the drift test of the
+    // LU cache then rides on the first synchronisation of the restart
+    int n_checked = 0;
+    if (!explicit_mode) {
+      eval_jac(y.p);
+      jac_current = true;
+      if (lu_band > 0.0 && lu_drift_max > 0.0) {
+        SlotDriftArgs a;
+        n_checked = (int)lu.slots.size();
+        for (int i = 0; i < n_checked; i++) { a.jd[i] = lu.slots[i].valid ? lu.slots[i].jd.p : nullptr; a.c[i] = lu.slots[i].c_fact; }
+        launch_slot_drift(N, n_checked, jv.p, d_jdiag.p, a, d_drift.p, s);
+        KIN_HIP(hipMemcpyAsync(h_drift, d_drift.p, (size_t)n_checked * sizeof(double), hipMemcpyDeviceToHost, s));
+      }
+    }
     rhs(y.p, f0.p);
     launch_bdf_norms(N, y.p, f0.p, nullptr, atol, rtol, ctrl.p, s);
     sync_ctrl();
+    for (int i = 0; i < n_checked; i++)
+      if (lu.slots[i].valid && !(h_drift[i] <= lu_drift_max)) { lu.slots[i].valid = false; st.n_lu_dropped++; }
     if (hc->nonfinite) return false;
     const double interval = std::fabs(t_bound - t0);
     const double d0 = hc->scratch[0], d1 = hc->scratch[1];
@@ -252,8 +272,6 @@ struct Solver {
     order = 1;
     n_equal = 0;
     fail_score = 0.0;
-    eval_jac(y.p);
-    jac_current = true;
     return true;
   }
 
@@ -296,7 +314,16 @@ struct Solver {
   // convergence test and the error test (which only see the corrections) are blind to the component being left at its
   // predictor; the full C4 ramp then ran into DtLessThanMin a few hundred restarts later (with 5 restarts it runs
   // through). CVODE bounds the same staleness by re-evaluating J at least every 50 steps.
-  int64_t lu_max_age = 5;
+  int64_t lu_max_age = 50;
+  // Drift guard (KIN_LU_DRIFT, default 0.25): at every restart the Jacobian is fresh; one kernel compares, for every slot,
+  // diag(I - c_s J) as it was when the slot was made with what today's Jacobian gives at the same c_s, and slots whose
+  // diagonal moved by more than 25 % (either way) are dropped. For mass-action kinetics a column's off-diagonal entries
+  // are bounded by its diagonal (a reactant's loss terms), so the diagonal is a sound proxy for "a direction that was
+  // stiff in the slot and is not any more" - the unsafe case described above.
+  double lu_drift_max = 0.25;
+  DevBuf<int32_t> d_jdiag;
+  DevBuf<double> d_drift;
+  double* h_drift = nullptr;     // pinned
   bool cache_suspended = false;  // a tolerance retry (adaptive_solve!) runs its chunk without the cache
   int64_t jac_stamp_now = 0;     // restart counter at the last Jacobian evaluation
   bool slot_is_fresh = false;
@@ -360,6 +387,10 @@ struct Solver {
     lu.factor(c, jv.p, slot, &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;
     lu.slots[slot].jac_stamp = jac_stamp_now;
+    if (lu_band > 0.0) {
+      lu.slots[slot].jd.alloc(N);
+      launch_jac_diag(N, jv.p, d_jdiag.p, lu.slots[slot].jd.p, s);
+    }
     cur_slot = slot;
     st.n_factor++;
   }

@@ -60,6 +60,48 @@ void launch_lu_scale(int64_t e0, int64_t e1, const int32_t* ent_pivot, double* W
   KIN_HIP(hipGetLastError());
 }
 
+// jd[i] = J[i][i] (copy of the Jacobian's diagonal kept with a factorisation)
+__global__ __launch_bounds__(256) void jac_diag_kernel(int N, const double* __restrict__ jv, const int32_t* __restrict__ j_diag,
+                                                       double* __restrict__ jd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) jd[i] = jv[j_diag[i]];
+}
+
+// Drift of the Newton matrix's diagonal since slot s was made: out[s] = max_i max(q, 1/q) - 1 with
+// q = (1 - c_s Jd_s[i]) / (1 - c_s Jd_now[i]) - how far diag(I - c_s J) of the slot is from what today's Jacobian gives at
+// the same c. One 1024-thread workgroup per slot (blockIdx.x = slot).
+__global__ __launch_bounds__(1024) void slot_drift_kernel(int N, const double* __restrict__ jv, const int32_t* __restrict__ j_diag,
+                                                          SlotDriftArgs a, double* __restrict__ out) {
+  __shared__ double sh[17];
+  const double* jd = a.jd[blockIdx.x];
+  const double c = a.c[blockIdx.x];
+  double worst = 1.0;
+  if (jd) {
+    for (int i = threadIdx.x; i < N; i += 1024) {
+      const double m_old = 1.0 - c * jd[i], m_new = 1.0 - c * jv[j_diag[i]];
+      const double q = m_old / m_new;
+      const double dev = (q > 0.0) ? fmax(q, 1.0 / q) : 1e300;   // a sign change or a NaN counts as unbounded drift
+      worst = fmax(worst, dev == dev ? dev : 1e300);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_down(worst, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double w = 1.0;
+    for (int i = 0; i < 16; i++) w = fmax(w, sh[i]);
+    out[blockIdx.x] = w - 1.0;
+  }
+}
+
+void launch_jac_diag(int N, const double* jv, const int32_t* j_diag, double* jd, hipStream_t s) {
+  hipLaunchKernelGGL(jac_diag_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, N, jv, j_diag, jd);
+}
+void launch_slot_drift(int N, int n_slots, const double* jv, const int32_t* j_diag, const SlotDriftArgs& a, double* out, hipStream_t s) {
+  if (n_slots > 0) hipLaunchKernelGGL(slot_drift_kernel, dim3(n_slots), dim3(1024), 0, s, N, jv, j_diag, a, out);
+}
+
 // dinv[p] = 1 / diag[p] for the sparse pivots
 __global__ __launch_bounds__(256) void lu_recip_kernel(int n, const double* __restrict__ diag, double* __restrict__ dinv) {
   const int i = blockIdx.x * 256 + threadIdx.x;

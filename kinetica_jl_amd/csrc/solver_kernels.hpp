@@ -28,6 +28,12 @@ struct BdfCtrl {
   int pad_;
 };
 
+// LU cache: per-slot copies of diag(J) and the drift test of Solver::restart (at most LU_MAX_SLOTS slots)
+constexpr int LU_MAX_SLOTS = 128;
+struct SlotDriftArgs { const double* jd[LU_MAX_SLOTS]; double c[LU_MAX_SLOTS]; };
+void launch_jac_diag(int N, const double* jv, const int32_t* j_diag, double* jd, hipStream_t s);
+void launch_slot_drift(int N, int n_slots, const double* jv, const int32_t* j_diag, const SlotDriftArgs& a, double* out, hipStream_t s);
+
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
                         double* d, double* scale, BdfCtrl* ctrl, hipStream_t s);   // also clears *ctrl
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,

@@ -82,7 +82,8 @@ class OracleBDF:
         # (lu_rate_max); after an error-test rejection the retry gets a factorisation of its own (force_fresh_lu, with a
         # new Jacobian if the old one is more than 20 steps old); a reused slot that needed every allowed iteration is dropped
         self.lu_rate_max = 0.1
-        self.lu_max_age = 5              # restarts a slot stays on offer after its Jacobian was evaluated
+        self.lu_max_age = 50             # restarts a slot stays on offer after its Jacobian was evaluated
+        self.lu_drift_max = 0.25         # drift guard: see Solver::restart (solver.cpp)
         self.jac_stamp_now = 0
         self.cache_suspended = False     # a tolerance retry runs its chunk without the cache
         self.force_fresh_lu = False
@@ -144,6 +145,7 @@ class OracleBDF:
                 sl = min(self.slots, key=lambda q: q["last_use"])
         sl["LU"] = self._factor(c)
         sl["c_fact"] = c
+        sl["jd"] = self.J.diagonal().copy()
         sl["jac_stamp"] = self.jac_stamp_now
         self.use_clock += 1
         sl["last_use"] = self.use_clock
@@ -224,6 +226,18 @@ class OracleBDF:
         self.J = self.jac(y0); self.stats["n_jac"] += 1
         self.steps_since_jac = 0
         self.jac_stamp_now = self.stats["n_restarts"]
+        if self.lu_band > 0 and self.lu_drift_max > 0 and self.slots:
+            # drift of diag(I - c_s J) of every slot against today's Jacobian at the same c_s
+            jd_now = self.J.diagonal()
+            keep = []
+            for sl in self.slots:
+                with np.errstate(all="ignore"):
+                    q = (1.0 - sl["c_fact"] * sl["jd"]) / (1.0 - sl["c_fact"] * jd_now)
+                    dev = np.where(q > 0.0, np.maximum(q, 1.0 / q), 1e300)
+                    dev = np.where(np.isnan(dev), 1e300, dev)
+                if dev.max() - 1.0 <= self.lu_drift_max:
+                    keep.append(sl)
+            self.slots = keep
         self.LU = None
         self.jac_current = True
         self.pending = None

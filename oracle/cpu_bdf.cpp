@@ -420,8 +420,9 @@ struct Bdf {
   bool force_fresh_lu = false, slot_is_fresh = true;
   int64_t steps_since_jac = 0;
   int lu_cache = 0;
-  struct Slot { double c_fact = 0.0; int64_t last_use = 0, jac_stamp = 0; std::vector<double> Lx, Ux, Udiag; };
-  int64_t lu_max_age = 5, jac_stamp_now = 0;   // restarts a slot stays on offer after its Jacobian was evaluated
+  struct Slot { double c_fact = 0.0; int64_t last_use = 0, jac_stamp = 0; std::vector<double> Lx, Ux, Udiag, jd; };
+  int64_t lu_max_age = 50, jac_stamp_now = 0;
+  double lu_drift_max = 0.25;                   // drift guard: see Solver::restart (solver.cpp)   // restarts a slot stays on offer after its Jacobian was evaluated
   bool cache_suspended = false;                // a tolerance retry runs its chunk without the cache
   std::vector<Slot> slots;          // the value arrays of the ACTIVE slot live in `lu` (swapped in)
   int active_slot = -1;
@@ -462,6 +463,31 @@ struct Bdf {
     slots.clear(); slots.push_back(mine); active_slot = 0;
   }
   void clear_cache() { slots.clear(); active_slot = -1; }
+  std::vector<double> jac_diag() const {
+    std::vector<double> jd(N);
+    for (int64_t j = 0; j < N; j++) {
+      auto b = net.jri.begin() + net.jcp[j], e = net.jri.begin() + net.jcp[j + 1];
+      jd[j] = J[std::lower_bound(b, e, (int32_t)j) - net.jri.begin()];
+    }
+    return jd;
+  }
+  // drops the slots whose diag(I - c_s J) moved by more than lu_drift_max against the Jacobian just evaluated
+  void drift_check() {
+    if (lu_cache <= 0 || lu_drift_max <= 0.0 || slots.empty()) return;
+    const std::vector<double> now = jac_diag();
+    if (active_slot >= 0) { swap_arrays(slots[active_slot]); active_slot = -1; }
+    std::vector<Slot> keep;
+    for (Slot& sl : slots) {
+      double worst = 1.0;
+      for (int64_t i = 0; i < N; i++) {
+        const double q = (1.0 - sl.c_fact * sl.jd[i]) / (1.0 - sl.c_fact * now[i]);
+        const double dev = q > 0.0 ? std::max(q, 1.0 / q) : 1e300;
+        worst = std::max(worst, dev == dev ? dev : 1e300);
+      }
+      if (worst - 1.0 <= lu_drift_max) keep.push_back(std::move(sl));
+    }
+    slots.swap(keep);
+  }
   double GAMMA[7], ALPHA[7], ERRC[7];
   std::vector<double> D, y, ypred, psi, d, scale, f, rhsv, dy, J, M, work, tmp;
   double t = 0, h_abs = 0, c_fact = 0;
@@ -554,6 +580,7 @@ struct Bdf {
     for (int64_t i = 0; i < N; i++) { D[i] = y[i]; D[(size_t)N + i] = f[i] * h_abs; }
     order = 1; n_equal = 0;
     eval_jac(y.data());
+    drift_check();
     jac_current = true; have_pending = false; fail_score = 0.0;
     return true;
   }
@@ -613,7 +640,7 @@ struct Bdf {
       const int64_t pb = lu.n_full;
       if (!factor(c)) return false;
       if (lu.n_full != pb && pb != 0) { keep_only_active(); i = 0; }
-      slots[i].c_fact = c; slots[i].jac_stamp = jac_stamp_now; fresh = jac_current;
+      slots[i].c_fact = c; slots[i].jac_stamp = jac_stamp_now; slots[i].jd = jac_diag(); fresh = jac_current;
     }
     force_fresh_lu = false;
     slots[i].last_use = ++use_clock;
@@ -634,7 +661,7 @@ struct Bdf {
     const int64_t pb = lu.n_full;
     if (!factor(c)) return false;
     if (lu.n_full != pb) { keep_only_active(); i = 0; }
-    slots[i].c_fact = c; slots[i].last_use = ++use_clock; slots[i].jac_stamp = jac_stamp_now;
+    slots[i].c_fact = c; slots[i].last_use = ++use_clock; slots[i].jac_stamp = jac_stamp_now; slots[i].jd = jac_diag();
     c_fact = c;
     slot_is_fresh = true;
     converged = newton(c, n_iter);
