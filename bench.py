@@ -252,6 +252,18 @@ def main():
         for _ in range(200):
             h.rhs(u1)
         out["single_state_rhs_us_host_roundtrip"] = (time.perf_counter() - t1) / 200 * 1e6
+        # the same evaluation on device-resident buffers, back to back (what the integrator pays per RHS: two dependent
+        # launches, no copies, no synchronisation in between)
+        d_u1 = torch.tensor(u1, dtype=torch.float64, device=dev)
+        d_du1 = torch.empty_like(d_u1)
+        for _ in range(10):
+            h.rhs_block_dev(0, R, d_u1.data_ptr(), d_du1.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2000):
+            h.rhs_block_dev(0, R, d_u1.data_ptr(), d_du1.data_ptr(), stream)
+        torch.cuda.synchronize()
+        out["single_state_rhs_us_device_resident"] = (time.perf_counter() - t1) / 2000 * 1e6
 
     # ---- wall-clock per solve_network (C3: static 1000 K, chunkwise, defaults of params.jl:55-75). Every rank solves
     # its own replica (rank r at 1000 + 10 r K: independent trajectories); the reported wall-clock is
