@@ -53,6 +53,7 @@ struct SparseLU {
     double c_fact = 0.0;
     int64_t last_use = 0;
     int64_t jac_stamp = 0;                  // restart counter at the time the Jacobian behind this factorisation was evaluated
+    int64_t step_stamp = 0;                 // accepted-step counter at that time
     bool valid = false;
   };
   std::vector<Slot> slots;

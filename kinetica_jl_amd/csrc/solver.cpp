@@ -357,6 +357,9 @@ struct Solver {
     for (int i = 0; i < (int)lu.slots.size(); i++) {
       const SparseLU::Slot& q = lu.slots[i];
       if (!q.valid || st.n_restarts - q.jac_stamp > lu_max_age) continue;
+      // continuous rate updates: k(t) moves inside a segment and no restart re-validates the slots - the Jacobian behind
+      // a slot may be at most 50 accepted steps old (CVODE's bound on the age of its Jacobian)
+      if (pre_attempt && st.n_steps - q.step_stamp > 50) continue;
       const double r = std::fabs(std::log(c / q.c_fact));
       if (r < bd && std::fabs(c / q.c_fact - 1.0) <= lu_band) { bd = r; best = i; }
     }
@@ -387,6 +390,7 @@ struct Solver {
     lu.factor(c, jv.p, slot, &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;
     lu.slots[slot].jac_stamp = jac_stamp_now;
+    lu.slots[slot].step_stamp = st.n_steps - steps_since_jac;
     if (lu_band > 0.0) {
       lu.slots[slot].jd.alloc(N);
       launch_jac_diag(N, jv.p, d_jdiag.p, lu.slots[slot].jd.p, s);

@@ -128,6 +128,8 @@ class OracleBDF:
         for sl in self.slots:
             if self.stats["n_restarts"] - sl["jac_stamp"] > self.lu_max_age:
                 continue
+            if self.pre_attempt is not None and self.stats["n_steps"] - sl["step_stamp"] > 50:
+                continue          # continuous rate updates: the Jacobian behind a slot is at most 50 accepted steps old
             r = abs(math.log(c / sl["c_fact"]))
             if r < bd and abs(c / sl["c_fact"] - 1.0) <= self.lu_band:
                 best, bd = sl, r
@@ -147,6 +149,7 @@ class OracleBDF:
         sl["c_fact"] = c
         sl["jd"] = self.J.diagonal().copy()
         sl["jac_stamp"] = self.jac_stamp_now
+        sl["step_stamp"] = self.stats["n_steps"] - self.steps_since_jac
         self.use_clock += 1
         sl["last_use"] = self.use_clock
         return sl

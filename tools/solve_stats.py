@@ -23,6 +23,6 @@ t0 = time.perf_counter()
 t, u, rc, st, status = h.solve(p, u0)
 wall = time.perf_counter() - t0
 print(json.dumps({"N": N, "R": R, "chunks": nch, "rc": rc, "wall_s": wall, **{q: st[q] for q in
-      ("n_steps", "n_rejected", "n_factor", "n_linsolve", "n_newton_fail", "n_jac", "n_restarts", "n_lu_reused", "lu_slots", "lu_dense_dim")}}))
+      ("n_steps", "n_rejected", "n_factor", "n_linsolve", "n_newton_fail", "n_jac", "n_restarts", "n_lu_reused", "n_lu_dropped", "lu_slots", "lu_dense_dim")}}))
 if len(sys.argv) > 4:
     np.save(sys.argv[4], u)
