@@ -20,7 +20,14 @@ void kin_network::rhs_dev(const double* d_u, double* d_du) {
 }
 
 void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, double* d_du, hipStream_t s) {
-  if (host.big_H > 0) {
+  if (host.N >= 65535) {
+    // the packed sweep records hold species ids in 16 bits; wider networks take the single-state kernels
+    // (32-bit ids) state after state on the same stream - correct at any size, one state per launch pair
+    for (int64_t b = 0; b < B; b++) {
+      launch_rates(host.R, d_k ? d_k + b * host.R : k.p, d_u + b * host.N, x0.p, x1.p, rate.p, s);
+      launch_segsum(rhs_plan.view(), SEG_COEF_SET, rate.p, d_du + b * host.N, SegExtra{}, s);
+    }
+  } else if (host.big_H > 0) {
     big_scratch.alloc((size_t)launch_sweep_big_grid(B) * (size_t)(host.N - host.big_H + host.n_pairs()));
     launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, (int32_t)host.big_tail_ptr.size() - 1,
                      big_rec8.p, big_rec.p, big_expl.p, (int32_t)host.big_expl.size(), sweep_k.p, big_spec.p, big_tptr.p, big_tent.p,
@@ -217,7 +224,6 @@ int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const doub
   require(B > 0, ERR_INVALID_ARG, "B must be positive");
   require(d_u && d_du, ERR_INVALID_ARG, "null device buffer");
   require(d_k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
-  require(h->host.N < 65535, ERR_UNSUPPORTED, "batched sweep packs species ids in 16 bits (N < 65535)");
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   h->sweep_dev(B, d_u, d_k, d_du, s);
   KIN_CATCH(h)
@@ -228,7 +234,6 @@ int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k,
   KIN_TRY(h)
   require(B > 0 && u && du, ERR_INVALID_ARG, "bad arguments");
   require(k || h->has_rates, ERR_STATE, "rates were never set and no per-state k given");
-  require(h->host.N < 65535, ERR_UNSUPPORTED, "batched sweep packs species ids in 16 bits (N < 65535)");
   const int64_t N = h->host.N, R = h->host.R;
   hipStream_t s = h->stream;
   h->b_u.upload(u, (size_t)B * N, s);

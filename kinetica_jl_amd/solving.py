@@ -24,7 +24,7 @@ from .synth import FlatNetwork, from_lists
 __all__ = ["SpeciesData", "RxData", "RxFilter", "get_filter_mask", "DummyKineticCalculator",
            "PrecalculatedArrheniusCalculator", "PrecalculatedLindemannCalculator", "allows_continuous",
            "has_conditions", "setup_network", "ODESimulationParams", "StaticODESolve", "VariableODESolve",
-           "solve_network", "insert_inert", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
+           "solve_network", "identify_next_seeds", "insert_inert", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
            "get_max_rates", "get_initial_rates", "calculate_discrete_rates"]
 
 _T_UNIT = {  # src/utils.jl:77-97
@@ -48,10 +48,12 @@ class SpeciesData:
     toInt: Dict[str, int]      # SMILES -> species id (1-based, as in the reference)
     toStr: Dict[int, str]
     n: int
+    xyz: Optional[Dict[int, dict]] = None     # per-species geometry frames; the solve side only reads "N_atoms"
 
     @classmethod
-    def from_names(cls, names: Sequence[str]):
-        return cls({s: i + 1 for i, s in enumerate(names)}, {i + 1: s for i, s in enumerate(names)}, len(names))
+    def from_names(cls, names: Sequence[str], n_atoms: Optional[Sequence[int]] = None):
+        xyz = None if n_atoms is None else {i + 1: {"N_atoms": int(a)} for i, a in enumerate(n_atoms)}
+        return cls({s: i + 1 for i, s in enumerate(names)}, {i + 1: s for i, s in enumerate(names)}, len(names), xyz)
 
 
 @dataclass
@@ -382,6 +384,7 @@ class ODESolution:
     retcode: str
     k: Optional[object] = None
     stats: dict = field(default_factory=dict)
+    umax: Optional[np.ndarray] = None    # max over saved times per species, reduced on the device (kin_solution_max)
 
     def __call__(self, tq):
         """Linear interpolation res.sol(t) (docs/src/getting-started.md:232-236)."""
@@ -534,8 +537,79 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
                     sol_vcs[sym] = np.interp(t, prof.sol.t, prof.sol.u)
         if pars.update_tols and st["final_abstol"] != pars.abstol:
             pars.abstol, pars.reltol = st["final_abstol"], st["final_reltol"]   # solve_utils.jl:397-401
+        umax = h.solution_max()      # what identify_next_seeds reads, reduced where the trajectory lives
     finally:
         if h is not None:
             h.close()
-    sol = ODESolution(t, u, capi.RETCODE_NAMES[rc], k=sol_k, stats=st)
+    sol = ODESolution(t, u, capi.RETCODE_NAMES[rc], k=sol_k, stats=st, umax=umax)
     return ODESolveOutput(sd_a, rd_a, sol, sol_k, sol_vcs, pars, conditions)
+
+
+# ---- the consumer of a level's solve (src/exploration/explore_utils.jl:338-406) ---------------------------
+def identify_next_seeds(sol, sd: SpeciesData, seed_conc: Optional[float] = None, *, elim_small_na: int = 0,
+                        ignore: Optional[Sequence[str]] = (), saveto: Optional[str] = None) -> List[str]:
+    """identify_next_seeds(sol, sd, seed_conc; elim_small_na, ignore, saveto) and the three-argument-less method
+    without `seed_conc` (explore_utils.jl:338-374, 376-406): species whose maximum concentration over the saved
+    trajectory reaches `seed_conc` (all species when it is None), minus `ignore`d SMILES and, with
+    `elim_small_na > 0`, species of fewer atoms (`sd.xyz[i]["N_atoms"]`). `saveto` writes the reference's seeds.out
+    table. The per-species maxima are `sol.umax` - reduced on the device by `kin_solution_max` when `sol` comes from
+    `solve_network`, so the trajectory is never scanned on the host; a solution read back from disk (`load_output`)
+    has no device side and its saved `u` is reduced here."""
+    umax = getattr(sol, "umax", None)
+    if umax is None:
+        umax = np.max(np.asarray(sol.u, dtype=float), axis=0)
+    if len(umax) != sd.n:
+        raise ValueError("solution and SpeciesData disagree on the number of species")
+    if elim_small_na > 0 and sd.xyz is None:
+        raise ValueError("elim_small_na needs SpeciesData.xyz (N_atoms per species)")
+    ignore = set(ignore or ())
+    seeds, concs = [], []
+    for sid in range(1, sd.n + 1):
+        smi = sd.toStr[sid]
+        if smi in ignore:
+            continue
+        c = float(umax[sid - 1])
+        if seed_conc is not None and not c >= seed_conc:
+            continue
+        if elim_small_na > 0 and sd.xyz[sid]["N_atoms"] < elim_small_na:
+            continue
+        seeds.append(smi); concs.append(c)
+    if saveto is not None:
+        w = max(len(x) for x in seeds)      # an empty selection raises here as `maximum` of an empty list does there
+        with open(saveto, "w") as f:
+            f.write(f"{len(seeds)}\n")
+            f.write(f"SID   {'SMILES'.ljust(w)}   Max. Conc.\n")
+            for i, (smi, c) in enumerate(zip(seeds, concs), start=1):
+                f.write(f"{str(i).ljust(5)} {smi.ljust(w)}   {_julia_float(c)}\n")
+    return seeds
+
+
+def _julia_float(x: float) -> str:
+    """Julia's `print(::Float64)`: shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e6, else `d.ddde±x`."""
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "Inf" if x > 0 else "-Inf"
+    if x == 0:
+        return "-0.0" if str(x).startswith("-") else "0.0"
+    r = repr(float(x))
+    mant, _, ex = r.partition("e")
+    sign = "-" if mant.startswith("-") else ""
+    mant = mant.lstrip("-")
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0") or "0"
+    # decimal exponent of the first significant digit
+    if ex:
+        e10 = int(ex) + len(ip) - 1 if ip.strip("0") else int(ex) - (len(fp) - len(fp.lstrip("0"))) - 1
+    else:
+        e10 = len(ip) - 1 if ip.strip("0") else -(len(fp) - len(fp.lstrip("0"))) - 1
+    digits = digits.rstrip("0") or "0"
+    if -5 < e10 < 6:
+        if e10 >= 0:
+            whole = digits[: e10 + 1].ljust(e10 + 1, "0")
+            frac = digits[e10 + 1:] or "0"
+        else:
+            whole, frac = "0", "0" * (-e10 - 1) + digits
+        return f"{sign}{whole}.{frac}"
+    m = digits[0] + "." + (digits[1:] or "0")
+    return f"{sign}{m}e{e10}"

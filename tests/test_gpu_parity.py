@@ -381,3 +381,22 @@ def test_batched_sweep_size_boundaries(layout):
             sc = on.abs_rhs(K[b], U[b]) + 1e-300
             assert (np.abs(got[b] - on.rhs(K[b], U[b])) / sc).max() < TOL, (layout, n, "per-state k", b)
         h.close()
+
+
+def test_batched_sweep_beyond_16_bit_species_ids():
+    """Networks of 65 535 species and more do not fit the packed sweep records (16-bit ids): the batched entry point
+    then runs the single-state kernels per state instead of refusing the call. Same answers as the oracle."""
+    rng = np.random.default_rng(11)
+    for n in (65534, 65535, 70001):
+        net = _random_net(rng, n, 4000, "adjacent")
+        h = capi.HipNetwork.from_flat(net)
+        on = orc.OracleNetwork.from_flat(net)
+        k = rng.uniform(0.5, 2.0, net.n_reactions)
+        h.set_rates(k)
+        U = 10.0 ** rng.uniform(-6, 0, (3, n))
+        K = k[None, :] * rng.uniform(0.5, 2.0, (3, 1))
+        for got, kk in ((h.rhs_batched(U), [k, k, k]), (h.rhs_batched(U, K), K)):
+            for b in range(3):
+                sc = on.abs_rhs(kk[b], U[b]) + 1e-300
+                assert (np.abs(got[b] - on.rhs(kk[b], U[b])) / sc).max() < TOL, (n, b)
+        h.close()

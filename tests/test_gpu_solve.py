@@ -520,6 +520,11 @@ def test_inert_collision_partner_n4():
     kf, kr = 2.0 * 3.0, 0.5 * 3.0
     a = kr / (kf + kr) + (1.0 - kr / (kf + kr)) * np.exp(-(kf + kr) * t)
     assert errscale(u[:, 0], a) < 100
+    # the seeds of the next exploration level come from the device-side maxima (explore_utils.jl:338-374)
+    assert res.sol.umax is not None and np.array_equal(res.sol.umax, u.max(axis=0))
+    assert S.identify_next_seeds(res.sol, sd, 0.5) == ["A", "B", "Ar"]
+    assert S.identify_next_seeds(res.sol, sd, 0.5, ignore=["Ar"]) == ["A", "B"]
+    assert S.identify_next_seeds(res.sol, sd, 0.9) == ["A", "Ar"]
     # the batched sweep on the same network
     h = capi.HipNetwork(*rd.flat(sd.n), index_base=1)
     h.set_rates([2.0, 0.5])

@@ -179,3 +179,38 @@ def test_insert_inert_topology():
     S.insert_inert(rd, sd, ["Ar", "He"])
     assert sd.n == 4 and rd.nr == 2 and rd.dH == [0.5, 0.5]
     assert rd.id_reacs == [[1, 4], [1, 3]] and rd.id_prods == [[2, 4], [2, 3]]
+
+
+def test_identify_next_seeds_selection_and_seeds_out(tmp_path):
+    """identify_next_seeds (explore_utils.jl:338-406) on a host-side solution (no device maxima attached): threshold,
+    `ignore`, `elim_small_na`, the method without a threshold, and the seeds.out table (explore_utils.jl:363-372:
+    count, header padded to the longest SMILES, `rpad(sid, 5)`, Julia's Float64 printing)."""
+    sd = S.SpeciesData.from_names(["C", "CC", "[H][H]", "C=C", "CCCC"], n_atoms=[5, 8, 2, 6, 14])
+    u = np.array([[1.0, 0.0, 0.0, 0.0, 0.0],
+                  [0.6, 0.2, 0.05, 1e-7, 0.004],
+                  [0.3, 0.15, 0.3, 2.5e-7, 0.001]])
+    sol = S.ODESolution(np.array([0.0, 1.0, 2.0]), u, "Success")
+    assert S.identify_next_seeds(sol, sd, 0.1) == ["C", "CC", "[H][H]"]
+    assert S.identify_next_seeds(sol, sd, 0.2) == ["C", "CC", "[H][H]"]          # >= : a maximum AT the threshold counts
+    assert S.identify_next_seeds(sol, sd, 0.1, ignore=["CC"]) == ["C", "[H][H]"]
+    assert S.identify_next_seeds(sol, sd, 0.1, elim_small_na=5) == ["C", "CC"]
+    assert S.identify_next_seeds(sol, sd) == ["C", "CC", "[H][H]", "C=C", "CCCC"]
+    assert S.identify_next_seeds(sol, sd, elim_small_na=6, ignore=["CCCC"]) == ["CC", "C=C"]
+    out = tmp_path / "seeds.out"
+    S.identify_next_seeds(sol, sd, 1e-7, saveto=str(out))
+    assert out.read_text().splitlines() == [
+        "5",
+        "SID   SMILES   Max. Conc.",
+        "1     C        1.0",
+        "2     CC       0.2",
+        "3     [H][H]   0.3",
+        "4     C=C      2.5e-7",
+        "5     CCCC     0.004",
+    ]
+    with pytest.raises(ValueError):
+        S.identify_next_seeds(sol, S.SpeciesData.from_names(["a", "b", "c", "d", "e"]), 0.1, elim_small_na=3)
+    with pytest.raises(ValueError):
+        S.identify_next_seeds(sol, S.SpeciesData.from_names(["a", "b"]), 0.1)
+    # a device-reduced maximum, when attached, is what is read (the trajectory is not scanned)
+    sol2 = S.ODESolution(np.array([0.0]), u[:1], "Success", umax=np.array([0.0, 0.0, 0.0, 0.0, 7.0]))
+    assert S.identify_next_seeds(sol2, sd, 0.1) == ["CCCC"]
