@@ -16,15 +16,14 @@ void SegPlanDev::upload(const SegPlanHost& h, hipStream_t s) {
   ell_a.upload(h.ell_a, s); ell_b.upload(h.ell_b, s); ell_c.upload(h.ell_c, s);
   seg_beg.upload(h.seg_beg, s); seg_end.upload(h.seg_end, s); seg_dst.upload(h.seg_dst, s); seg_aux.upload(h.seg_aux, s);
   long_a.upload(h.long_a, s); long_b.upload(h.long_b, s); long_c.upload(h.long_c, s);
-  fix_dst.upload(h.fix_dst, s); fix_aux.upload(h.fix_aux, s); fix_ptr.upload(h.fix_ptr, s);
-  partials.alloc((size_t)h.n_partials + 1);
-  G = h.n_groups(); S = h.n_segs(); F = h.n_fix();
+  blk_beg.upload(h.blk_beg, s); blk_end.upload(h.blk_end, s); blk_dst.upload(h.blk_dst, s); blk_aux.upload(h.blk_aux, s);
+  G = h.n_groups(); S = h.n_segs(); B = h.n_blks();
   KIN_HIP(hipStreamSynchronize(s));  // host vectors may die after this call
 }
 
 SegPlanView SegPlanDev::view() const {
   return SegPlanView{grp_off.p, grp_dst.p, grp_aux.p, ell_a.p, ell_b.p, ell_c.p, seg_beg.p, seg_end.p, seg_dst.p, seg_aux.p,
-                     long_a.p, long_b.p, long_c.p, fix_dst.p, fix_aux.p, fix_ptr.p, partials.p, G, S, F};
+                     blk_beg.p, blk_end.p, blk_dst.p, blk_aux.p, long_a.p, long_b.p, long_c.p, G, S, B};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -33,7 +32,9 @@ SegPlanView SegPlanDev::view() const {
 // The store operands that do not depend on the sum (old value, pivot, psi, d) are loaded by seg_pre
 // BEFORE the gather loop: these kernels are a chain of dependent global loads on a few thousand rows,
 // so every load taken off the critical path is ~1 us per launch. The same goes for the skip flag
-// (blind-enqueued Newton iterations): it is loaded first but only tested right before the store.
+// (blind-enqueued Newton iterations): it is loaded together with the row descriptors and tested when those
+// are back - a skipped launch (47 % of the second iterations at C3) ends after ONE round of loads instead of
+// three, an active one does not wait for the flag any longer than it waits for its descriptors anyway.
 struct SegPre { double o, a, b; };
 template <int OP>
 __device__ __forceinline__ SegPre seg_pre(const double* out, const double* src, int32_t dst, int32_t aux, const SegExtra& ex) {
@@ -52,9 +53,10 @@ __device__ __forceinline__ void seg_store(double* out, int32_t dst, double acc, 
   else if (OP == SEG_PROD_SUB_DIV) out[dst] = (q.o - acc) / q.a;
   else if (OP == SEG_PROD_AUXSUB) out[dst] = q.o - acc;
   else if (OP == SEG_PROD_SET) out[dst] = acc;
+  else if (OP == SEG_PROD_NEG) out[dst] = -acc;
   else out[dst] = ex.cscal * acc - q.a - q.b;
 }
-template <int OP> struct seg_is_prod { static constexpr bool v = (OP == SEG_PROD_SUB || OP == SEG_PROD_SUB_DIV || OP == SEG_PROD_AUXSUB || OP == SEG_PROD_SET); };
+template <int OP> struct seg_is_prod { static constexpr bool v = (OP == SEG_PROD_SUB || OP == SEG_PROD_SUB_DIV || OP == SEG_PROD_AUXSUB || OP == SEG_PROD_SET || OP == SEG_PROD_NEG); };
 
 __device__ __forceinline__ double wave_sum(double v) {
   // fixed butterfly order -> bitwise reproducible
@@ -63,15 +65,62 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int OP>
-__global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
+// grid of 1024-thread workgroups: the first p.B take one LONG row each (whole workgroup, BLK_PASS entries per pass, so
+// that all but the very longest rows are ONE round of index loads + gathers), the others sixteen wavefront tasks each
+// (an ELL group of 64 short rows, or one medium row)
+// (plans without long rows are launched with 256-thread workgroups: small workgroups start ~1.5 us sooner)
+template <int OP, int SEG_WG>
+__global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
+  constexpr int SEG_WAVES = SEG_WG / 64, BLK_PER_THREAD = SegPlanHost::BLK_PASS / 1024;
   const int skip = ex.skip ? *ex.skip : 0;
   const int lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (SEG_WG == 1024 && (int)blockIdx.x < p.B) {
+    __shared__ double sh[SEG_WAVES];
+    const int r = blockIdx.x;
+    const int32_t e0 = p.blk_beg[r], e1 = p.blk_end[r];
+    const int32_t bdst = p.blk_dst[r];
+    const int32_t baux = p.blk_aux[r];
+    if (skip) return;      // (whole workgroup: the flag is uniform) tested once the first round of loads is back, see below
+    const SegPre pre = seg_pre<OP>(out, src, threadIdx.x == 0 ? bdst : -1, baux, ex);
+    double acc = 0.0;
+    for (int32_t base = e0; base < e1; base += SegPlanHost::BLK_PASS) {
+      float c[BLK_PER_THREAD]; int32_t ia[BLK_PER_THREAD], ib[BLK_PER_THREAD]; double va[BLK_PER_THREAD], vb[BLK_PER_THREAD];
+#pragma unroll
+      for (int x = 0; x < BLK_PER_THREAD; x++) {
+        const int32_t e = base + (int32_t)threadIdx.x + 1024 * x;
+        const bool ok = e < e1;
+        c[x] = ok ? p.long_c[e] : 0.0f;
+        ia[x] = ok ? p.long_a[e] : 0;
+        ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
+      }
+#pragma unroll
+      for (int x = 0; x < BLK_PER_THREAD; x++) {
+        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
+        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
+      }
+#pragma unroll
+      for (int x = 0; x < BLK_PER_THREAD; x++) {
+        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
+        else acc += (double)c[x] * va[x];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && !skip) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < SEG_WAVES; w++) tot += sh[w];     // fixed order
+      seg_store<OP>(out, bdst, tot, pre, ex);
+    }
+    return;
+  }
+  const int task = ((int)blockIdx.x - p.B) * SEG_WAVES + (threadIdx.x >> 6);
   if (task < p.G) {
     const int32_t dst = p.grp_dst[task * 64 + lane];
     const int32_t aux = p.grp_aux[task * 64 + lane];
     const int32_t c0 = p.grp_off[task], c1 = p.grp_off[task + 1];
+    if (skip) return;
     const SegPre pre = seg_pre<OP>(out, src, dst, aux, ex);
     double acc = 0.0;
     for (int32_t col = c0; col < c1; col += 8) {
@@ -102,72 +151,74 @@ __global__ __launch_bounds__(256) void segsum_kernel(SegPlanView p, const double
     const int sidx = task - p.G;
     const int32_t e0 = p.seg_beg[sidx], e1 = p.seg_end[sidx];
     const int32_t sdst = p.seg_dst[sidx];
-    const SegPre pre = seg_pre<OP>(out, src, lane == 0 ? sdst : -1, sdst >= 0 ? p.seg_aux[sidx] : 0, ex);
-    // SEG_LEN = 256: at most four entries per lane, all loads in flight together
-    float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-      const int32_t e = e0 + lane + 64 * x;
-      const bool ok = e < e1;
-      c[x] = ok ? p.long_c[e] : 0.0f;
-      ia[x] = ok ? p.long_a[e] : 0;
-      ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
-    }
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-      va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
-      vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
-    }
+    const int32_t saux = p.seg_aux[sidx];
+    if (skip) return;
+    const SegPre pre = seg_pre<OP>(out, src, lane == 0 ? sdst : -1, saux, ex);
+    // up to 256 entries: four per lane; up to SEG_LEN = 1024: sixteen per lane - either way ONE round of index loads
+    // and ONE round of gathers, all in flight together
     double acc = 0.0;
+    if (e1 - e0 <= 256) {
+      float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
-      if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
-      else acc += (double)c[x] * va[x];
+      for (int x = 0; x < 4; x++) {
+        const int32_t e = e0 + lane + 64 * x;
+        const bool ok = e < e1;
+        c[x] = ok ? p.long_c[e] : 0.0f;
+        ia[x] = ok ? p.long_a[e] : 0;
+        ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
+        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
+        else acc += (double)c[x] * va[x];
+      }
+    } else {
+      float c[16]; int32_t ia[16], ib[16]; double va[16], vb[16];
+#pragma unroll
+      for (int x = 0; x < 16; x++) {
+        const int32_t e = e0 + lane + 64 * x;
+        const bool ok = e < e1;
+        c[x] = ok ? p.long_c[e] : 0.0f;
+        ia[x] = ok ? p.long_a[e] : 0;
+        ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
+      }
+#pragma unroll
+      for (int x = 0; x < 16; x++) {
+        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
+        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
+      }
+#pragma unroll
+      for (int x = 0; x < 16; x++) {
+        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
+        else acc += (double)c[x] * va[x];
+      }
     }
     acc = wave_sum(acc);
-    if (lane == 0 && !skip) {
-      if (sdst >= 0) seg_store<OP>(out, sdst, acc, pre, ex);
-      else p.partials[-sdst - 1] = acc;
-    }
+    if (lane == 0 && !skip) seg_store<OP>(out, sdst, acc, pre, ex);
   }
-}
-
-template <int OP>
-__global__ void segsum_fix_kernel(SegPlanView p, const double* src, double* out, SegExtra ex) {
-  const int skip = ex.skip ? *ex.skip : 0;
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= p.F) return;
-  const int32_t dst = p.fix_dst[f];
-  const SegPre pre = seg_pre<OP>(out, src, dst, p.fix_aux[f], ex);
-  double acc = 0.0;
-  for (int32_t q = p.fix_ptr[f]; q < p.fix_ptr[f + 1]; q++) acc += p.partials[q];
-  if (!skip) seg_store<OP>(out, dst, acc, pre, ex);
 }
 
 void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* out, const SegExtra& ex, hipStream_t s) {
   const int tasks = p.G + p.S;
-  if (tasks > 0) {
-    dim3 grid((unsigned)ceil_div(tasks, 4)), block(256);
-    switch (op) {
-      case SEG_COEF_SET: hipLaunchKernelGGL(segsum_kernel<SEG_COEF_SET>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_SUB_DIV: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SUB_DIV>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_AUXSUB: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_AUXSUB>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_SET: hipLaunchKernelGGL(segsum_kernel<SEG_PROD_SET>, grid, block, 0, s, p, src, out, ex); break;
-    }
+  if (tasks + p.B == 0) return;
+#define KIN_SEG_LAUNCH(OPX)                                                                                              \
+  if (p.B > 0) hipLaunchKernelGGL((segsum_kernel<OPX, 1024>), dim3((unsigned)(p.B + ceil_div(tasks, 16))), dim3(1024), 0, s, p, src, out, ex); \
+  else hipLaunchKernelGGL((segsum_kernel<OPX, 256>), dim3((unsigned)ceil_div(tasks, 4)), dim3(256), 0, s, p, src, out, ex);
+  switch (op) {
+    case SEG_COEF_SET: KIN_SEG_LAUNCH(SEG_COEF_SET) break;
+    case SEG_PROD_SUB: KIN_SEG_LAUNCH(SEG_PROD_SUB) break;
+    case SEG_COEF_BDF: KIN_SEG_LAUNCH(SEG_COEF_BDF) break;
+    case SEG_PROD_SUB_DIV: KIN_SEG_LAUNCH(SEG_PROD_SUB_DIV) break;
+    case SEG_PROD_AUXSUB: KIN_SEG_LAUNCH(SEG_PROD_AUXSUB) break;
+    case SEG_PROD_SET: KIN_SEG_LAUNCH(SEG_PROD_SET) break;
+    case SEG_PROD_NEG: KIN_SEG_LAUNCH(SEG_PROD_NEG) break;
   }
-  if (p.F > 0) {
-    dim3 grid((unsigned)ceil_div(p.F, 64)), block(64);
-    switch (op) {
-      case SEG_COEF_SET: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_SET>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_SUB: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_COEF_BDF: hipLaunchKernelGGL(segsum_fix_kernel<SEG_COEF_BDF>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_SUB_DIV: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SUB_DIV>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_AUXSUB: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_AUXSUB>, grid, block, 0, s, p, src, out, ex); break;
-      case SEG_PROD_SET: hipLaunchKernelGGL(segsum_fix_kernel<SEG_PROD_SET>, grid, block, 0, s, p, src, out, ex); break;
-    }
-  }
+#undef KIN_SEG_LAUNCH
   KIN_HIP(hipGetLastError());
 }
 

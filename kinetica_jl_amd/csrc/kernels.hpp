@@ -10,17 +10,15 @@ struct SegPlanView {
   const int32_t* grp_off; const int32_t* grp_dst; const int32_t* grp_aux;
   const int32_t* ell_a; const int32_t* ell_b; const float* ell_c;
   const int32_t* seg_beg; const int32_t* seg_end; const int32_t* seg_dst; const int32_t* seg_aux;
+  const int32_t* blk_beg; const int32_t* blk_end; const int32_t* blk_dst; const int32_t* blk_aux;
   const int32_t* long_a; const int32_t* long_b; const float* long_c;
-  const int32_t* fix_dst; const int32_t* fix_aux; const int32_t* fix_ptr;
-  double* partials;
-  int32_t G, S, F;
+  int32_t G, S, B;
 };
 
 struct SegPlanDev {
-  DevBuf<int32_t> grp_off, grp_dst, grp_aux, ell_a, ell_b, seg_beg, seg_end, seg_dst, seg_aux, long_a, long_b, fix_dst, fix_aux, fix_ptr;
+  DevBuf<int32_t> grp_off, grp_dst, grp_aux, ell_a, ell_b, seg_beg, seg_end, seg_dst, seg_aux, blk_beg, blk_end, blk_dst, blk_aux, long_a, long_b;
   DevBuf<float> ell_c, long_c;
-  DevBuf<double> partials;
-  int32_t G = 0, S = 0, F = 0;
+  int32_t G = 0, S = 0, B = 0;
   void upload(const SegPlanHost& h, hipStream_t s);
   SegPlanView view() const;
 };
@@ -34,6 +32,7 @@ enum SegOp : int {
   SEG_PROD_SUB_DIV = 3,  // out[dst] = (out[dst] - sum src[a] * src[b]) / src[aux]        (backward substitution)
   SEG_PROD_AUXSUB = 4,   // out[dst] = src[aux] - sum src[a] * src[b]     (explicit triangular inverses: y1 = b1 - Z' b1, t = y1 - U12 x2)
   SEG_PROD_SET = 5,      // out[dst] = sum src[a] * src[b]                 (x1 = V t)
+  SEG_PROD_NEG = 6,      // out[dst] = - sum src[a] * src[b]               (NVU = -(V U12) of the fused solve)
 };
 struct SegExtra {  // extra operands of SEG_COEF_BDF
   const double* psi = nullptr; const double* d = nullptr; double cscal = 0.0;

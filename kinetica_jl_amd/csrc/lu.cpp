@@ -1,6 +1,7 @@
 #include "lu.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <numeric>
@@ -224,6 +225,68 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       n_mono_ent = (int32_t)m_dst.size();
     }
   }
+  // ---- fused solve (symbolic): LZ = L21 * L11^-1 and NVU = -(U11^-1 * U12), so that a solve is three dependent
+  // launches: [y1 = Z b1 ; y2 = b2 - LZ b1] | x2 = S^-1 y2 | x1 = V y1 + NVU x2
+  struct Prod { int32_t a, b; };
+  std::vector<std::map<int32_t, std::pair<int32_t, std::vector<Prod>>>> lz_rows, nvu_rows;   // per row: col -> (direct pos | -1, products)
+  fused_tri = explicit_tri && m > 0 && !(getenv("KIN_LU_FUSED") && atoi(getenv("KIN_LU_FUSED")) == 0);
+  if (fused_tri) {
+    const int64_t prod_limit = 16000000;
+    int64_t nprod = 0;
+    lz_rows.resize(m); nvu_rows.resize(ns);
+    for (int32_t k = 0; k < ns && fused_tri; k++)
+      for (int32_t e = ent_ptr[k]; e < ent_ptr[k + 1]; e++) {
+        if (nbr[e] < ns) continue;
+        auto& row = lz_rows[nbr[e] - ns];
+        auto it = row.find(k);
+        if (it == row.end()) row[k] = {(int32_t)(off_L + e), {}}; else it->second.first = (int32_t)(off_L + e);
+        for (auto& ce : z_cols[k]) {                 // Z'[k, ce.first], ce.first < k
+          auto jt = row.find(ce.first);
+          if (jt == row.end()) jt = row.emplace(ce.first, std::make_pair((int32_t)-1, std::vector<Prod>{})).first;
+          jt->second.second.push_back({(int32_t)(off_L + e), (int32_t)(off_Z + ce.second)});
+          if (++nprod > prod_limit) { fused_tri = false; break; }
+        }
+        if (!fused_tri) break;
+      }
+    for (int32_t i = 0; i < ns && fused_tri; i++)
+      for (auto& je : v_cols[i]) {                   // V[i, je.first], je.first >= i
+        const int32_t j = je.first;
+        for (int32_t e = ent_ptr[j]; e < ent_ptr[j + 1]; e++) {
+          if (nbr[e] < ns) continue;
+          auto& ent = nvu_rows[i][nbr[e] - ns];
+          ent.first = -1;
+          ent.second.push_back({(int32_t)(off_V + je.second), (int32_t)(off_U + e)});
+          if (++nprod > prod_limit) { fused_tri = false; break; }
+        }
+        if (!fused_tri) break;
+      }
+    if (fused_tri) {
+      nnzLZ = 0; nnzNVU = 0;
+      for (auto& r : lz_rows) nnzLZ += (int64_t)r.size();
+      for (auto& r : nvu_rows) nnzNVU += (int64_t)r.size();
+      off_LZ = w_end;
+      off_NVU = align(off_LZ + nnzLZ);
+      off_zero = align(off_NVU + nnzNVU);
+      w_end = align(off_zero + 8);
+      n_fused_products = nprod;
+    }
+  }
+  if (getenv("KIN_LU_DEBUG") && fused_tri) {
+    auto hist = [](const char* name, const std::vector<std::map<int32_t, std::pair<int32_t, std::vector<Prod>>>>& rows) {
+      long long h[6] = {0, 0, 0, 0, 0, 0}, mx = 0;
+      for (auto& r : rows) {
+        const long long l = (long long)r.size();
+        mx = std::max(mx, l);
+        h[l <= 8 ? 0 : l <= 64 ? 1 : l <= 256 ? 2 : l <= 1024 ? 3 : l <= 4096 ? 4 : 5]++;
+      }
+      fprintf(stderr, "[lu] %s row lengths: <=8:%lld <=64:%lld <=256:%lld <=1024:%lld <=4096:%lld more:%lld max:%lld\n", name, h[0], h[1], h[2], h[3], h[4], h[5], mx);
+    };
+    hist("LZ", lz_rows); hist("NVU", nvu_rows);
+  }
+  if (getenv("KIN_LU_DEBUG"))
+    fprintf(stderr, "[lu] n=%d ns=%d m=%d rounds=%d nnzU=%lld nnzZ=%lld nnzV=%lld monomials=%lld explicit=%d fused=%d nnzLZ=%lld nnzNVU=%lld products=%lld\n",
+            n, ns, m, nrounds, (long long)nnzU, (long long)nnzZ, (long long)nnzV, (long long)n_monomials, (int)explicit_tri, (int)fused_tri,
+            (long long)nnzLZ, (long long)nnzNVU, (long long)n_fused_products);
   w_size = w_end;
   if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
 
@@ -320,6 +383,64 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     mono_sign.upload(m_sign, s);
     KIN_HIP(hipStreamSynchronize(s));
   }
+  if (fused_tri) {
+    // numeric products of a factorisation: LZ[j,p] = L21[j,p] - sum_k L21[j,k] Z'[k,p] ; NVU[i,c] = - sum_j V[i,j] U12[j,c]
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> lz_cols(m), nvu_cols(ns);     // (column, value position)
+    {
+      std::vector<int32_t> ptr{0}, dst, aux, a, b;
+      int64_t idx = 0;
+      for (int32_t j = 0; j < m; j++)
+        for (auto& ce : lz_rows[j]) {
+          for (const Prod& pr : ce.second.second) { a.push_back(pr.a); b.push_back(pr.b); }
+          ptr.push_back((int32_t)a.size());
+          dst.push_back((int32_t)(off_LZ + idx));
+          aux.push_back(ce.second.first >= 0 ? ce.second.first : (int32_t)off_zero);
+          lz_cols[j].push_back({ce.first, (int32_t)(off_LZ + idx)});
+          idx++;
+        }
+      a.push_back(0); b.push_back(0);
+      lz_build.upload(build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+    }
+    {
+      std::vector<int32_t> ptr{0}, dst, a, b;
+      int64_t idx = 0;
+      for (int32_t i = 0; i < ns; i++)
+        for (auto& ce : nvu_rows[i]) {
+          for (const Prod& pr : ce.second.second) { a.push_back(pr.a); b.push_back(pr.b); }
+          ptr.push_back((int32_t)a.size());
+          dst.push_back((int32_t)(off_NVU + idx));
+          nvu_cols[i].push_back({ce.first, (int32_t)(off_NVU + idx)});
+          idx++;
+        }
+      a.push_back(0); b.push_back(0);
+      nvu_build.upload(build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
+    }
+    // stage A: y1_i = b_i - sum_p Z'[i,p] b_p (sparse rows) ; y2_j = b2_j - sum_p LZ[j,p] b_p (dense rows, in place)
+    {
+      std::vector<int32_t> ptr{0}, dst, aux, a, b;
+      for (int32_t i = 0; i < ns; i++) {
+        for (auto& ce : z_cols[i]) { a.push_back((int32_t)(off_Z + ce.second)); b.push_back((int32_t)(off_y + ce.first)); }
+        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y1 + i)); aux.push_back((int32_t)(off_y + i));
+      }
+      for (int32_t j = 0; j < m; j++) {
+        for (auto& ce : lz_cols[j]) { a.push_back(ce.second); b.push_back((int32_t)(off_y + ce.first)); }
+        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y + ns + j)); aux.push_back((int32_t)(off_y + ns + j));
+      }
+      a.push_back(0); b.push_back(0);
+      stageA.upload(build_seg_plan((int64_t)ns + m, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+    }
+    // stage C: x1_i = sum_j V[i,j] y1_j + sum_c NVU[i,c] x2_c
+    {
+      std::vector<int32_t> ptr{0}, dst, a, b;
+      for (int32_t i = 0; i < ns; i++) {
+        for (auto& ce : v_cols[i]) { a.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_y1 + ce.first)); }
+        for (auto& ce : nvu_cols[i]) { a.push_back(ce.second); b.push_back((int32_t)(off_x + ce.first)); }
+        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y + i));
+      }
+      stageC.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
+    }
+    KIN_HIP(hipStreamSynchronize(s));
+  }
   // ---- backward substitution: x_p = (y_p - sum_c U[p][c] x_c) / diag_p
   for (int r = 0; r < nrounds; r++) {
     int32_t p0 = round_ptr[r], p1 = round_ptr[r + 1];
@@ -367,6 +488,10 @@ void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipSt
   if (explicit_tri) {
     launch_lu_recip(ns, W + off_diag, W + off_dinv, s);
     launch_lu_mono(n_mono_ent, mono_ent_ptr.p, mono_ptr.p, mono_fac.p, mono_sign.p, mono_dst.p, W, s);
+    if (fused_tri) {
+      launch_segsum(lz_build.view(), SEG_PROD_AUXSUB, W, W, SegExtra{}, s);
+      launch_segsum(nvu_build.view(), SEG_PROD_NEG, W, W, SegExtra{}, s);
+    }
   }
   if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, bad, s);
   q.c_fact = c;
@@ -378,6 +503,12 @@ void SparseLU::solve(const int* skip, int slot, hipStream_t s) {
   double* W = q.W.p;
   SegExtra ex;
   ex.skip = skip;
+  if (fused_tri) {
+    launch_segsum(stageA.view(), SEG_PROD_AUXSUB, W, W, ex, s);
+    launch_gemv(q.sinv, mpad, m, W + off_y + ns, W + off_x, skip, s);
+    launch_segsum(stageC.view(), SEG_PROD_SET, W, W, ex, s);
+    return;
+  }
   if (explicit_tri) {
     launch_segsum(fwdZ.view(), SEG_PROD_AUXSUB, W, W, ex, s);
     if (m > 0) {

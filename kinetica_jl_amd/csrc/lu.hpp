@@ -78,6 +78,12 @@ struct SparseLU {
   DevBuf<int32_t> mono_ent_ptr, mono_ptr, mono_fac, mono_dst;
   DevBuf<float> mono_sign;
   SegPlanDev fwdZ, bwdT, bwdV;
+  // Fused solve: with LZ = L21 * L11^-1 and NVU = -(U11^-1 * U12) formed at every factorisation (two more gather
+  // launches, entries = short sums of products of factor values) the solve is THREE dependent launches:
+  //   [y1 = Z b1 ; y2 = b2 - LZ b1] | x2 = S^-1 y2 | x1 = V y1 + NVU x2
+  bool fused_tri = false;
+  int64_t off_LZ = 0, off_NVU = 0, off_zero = 0, nnzLZ = 0, nnzNVU = 0, n_fused_products = 0;
+  SegPlanDev lz_build, nvu_build, stageA, stageC;
   int64_t nnzJ = 0;
 
   void analyze(int32_t n, const std::vector<int32_t>& j_ptr, const std::vector<int32_t>& j_col,

@@ -43,30 +43,21 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     }
     P.grp_off.push_back(P.grp_off.back() + width);
   }
-  // long rows -> segments
-  P.fix_ptr.push_back(0);
+  // medium rows -> one segment (one wavefront); long rows -> one workgroup. Longest first: the long tasks start first.
+  std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) { return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y]; });
   for (int32_t row : longs) {
-    int32_t len = ptr[row + 1] - ptr[row];
-    int32_t nseg = (int32_t)ceil_div(len, SegPlanHost::SEG_LEN);
-    int32_t out = dst ? dst[row] : row;
-    for (int32_t s = 0; s < nseg; s++) {
-      int32_t e0 = ptr[row] + s * SegPlanHost::SEG_LEN;
-      int32_t e1 = std::min(ptr[row + 1], e0 + SegPlanHost::SEG_LEN);
-      P.seg_beg.push_back((int32_t)P.long_a.size());
-      for (int32_t e = e0; e < e1; e++) {
-        P.long_a.push_back(a[e]);
-        if (b) P.long_b.push_back(b[e]);
-        P.long_c.push_back(c ? c[e] : 1.0f);
-      }
-      P.seg_end.push_back((int32_t)P.long_a.size());
-      P.seg_dst.push_back(nseg == 1 ? out : -(P.n_partials++) - 1);
-      P.seg_aux.push_back(aux ? aux[row] : 0);
+    const int32_t len = ptr[row + 1] - ptr[row];
+    const int32_t out = dst ? dst[row] : row;
+    const bool blk = len > SegPlanHost::SEG_LEN;
+    (blk ? P.blk_beg : P.seg_beg).push_back((int32_t)P.long_a.size());
+    for (int32_t e = ptr[row]; e < ptr[row + 1]; e++) {
+      P.long_a.push_back(a[e]);
+      if (b) P.long_b.push_back(b[e]);
+      P.long_c.push_back(c ? c[e] : 1.0f);
     }
-    if (nseg > 1) {
-      P.fix_dst.push_back(out);
-      P.fix_aux.push_back(aux ? aux[row] : 0);
-      P.fix_ptr.push_back(P.n_partials);
-    }
+    (blk ? P.blk_end : P.seg_end).push_back((int32_t)P.long_a.size());
+    (blk ? P.blk_dst : P.seg_dst).push_back(out);
+    (blk ? P.blk_aux : P.seg_aux).push_back(aux ? aux[row] : 0);
   }
   return P;
 }

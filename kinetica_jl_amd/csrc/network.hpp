@@ -21,27 +21,28 @@ struct SegPlanHost {
   // longest dependent chain per wavefront: ELL rows are walked 4 columns at a time with all loads
   // in flight, a segment is consumed in ONE pass of 4 entries per lane.
   static constexpr int SHORT_MAX = 8;    // rows up to this many entries go to the ELL groups
-  static constexpr int SEG_LEN = 256;    // entries per long-row segment (4 per lane)
+  static constexpr int SEG_LEN = 256;    // longest row one wavefront takes (4 entries per lane; the kernel also handles up to 1024 at 16 per lane,
+                                         // measured slower than a workgroup per row: 0.650 vs 0.614 s on the C3 solve)
+  static constexpr int BLK_PASS = 12288; // entries a 1024-thread workgroup consumes per pass of a long row (12 per thread)
   // ELL groups
   std::vector<int32_t> grp_off;  // G+1: first ELL column of each group
   std::vector<int32_t> grp_dst;  // G*64: output index per lane (-1 = idle lane)
   std::vector<int32_t> grp_aux;  // G*64: optional per-row auxiliary index (divisor position)
   std::vector<int32_t> ell_a, ell_b;
   std::vector<float> ell_c;      // 0.0f marks padding
-  // long-row segments (payload copied contiguously)
+  // medium rows (9 .. SEG_LEN entries): one wavefront each, payload copied contiguously (sorted by length, so that the
+  // four / sixteen tasks of a workgroup are of a kind)
   std::vector<int32_t> seg_beg, seg_end;  // S
-  std::vector<int32_t> seg_dst;           // S: >=0 output index (single-segment row), <0: -(partial slot)-1
+  std::vector<int32_t> seg_dst;           // S: output index
   std::vector<int32_t> seg_aux;           // S
-  std::vector<int32_t> long_a, long_b;
+  // long rows (> SEG_LEN entries): one whole workgroup each, BLK_PASS entries per pass, fixed-order reduction -
+  // no partial sums in memory and no second (fix-up) launch behind the gather
+  std::vector<int32_t> blk_beg, blk_end, blk_dst, blk_aux;   // B
+  std::vector<int32_t> long_a, long_b;    // payload of segments and long rows
   std::vector<float> long_c;
-  // fix-up for multi-segment rows
-  std::vector<int32_t> fix_dst;           // F output index
-  std::vector<int32_t> fix_aux;           // F
-  std::vector<int32_t> fix_ptr;           // F+1 ranges of partial slots
-  int32_t n_partials = 0;
   int32_t n_groups() const { return (int32_t)grp_off.size() - 1; }
   int32_t n_segs() const { return (int32_t)seg_beg.size(); }
-  int32_t n_fix() const { return (int32_t)fix_dst.size(); }
+  int32_t n_blks() const { return (int32_t)blk_beg.size(); }
 };
 
 // Build a plan from CSR rows. `dst[row]` is the output index of a row; rows with no entries
