@@ -89,7 +89,7 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
       for (int x = 0; x < BLK_PER_THREAD; x++) {
         const int32_t e = base + (int32_t)threadIdx.x + 1024 * x;
         const bool ok = e < e1;
-        c[x] = ok ? p.long_c[e] : 0.0f;
+        c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);     // product plans carry no coefficients
         ia[x] = ok ? p.long_a[e] : 0;
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
       }
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
       for (int x = 0; x < 8; x++) {
         const size_t idx = (size_t)(col + x) * 64 + lane;
         const bool ok = col + x < c1;
-        c[x] = ok ? p.ell_c[idx] : 0.0f;
-        ia[x] = ok ? p.ell_a[idx] : 0;
+        ia[x] = ok ? p.ell_a[idx] : (seg_is_prod<OP>::v ? -1 : 0);
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.ell_b[idx] : 0;
+        c[x] = seg_is_prod<OP>::v ? (ia[x] >= 0 ? 1.0f : 0.0f) : (ok ? p.ell_c[idx] : 0.0f);   // product plans: padding = a < 0
       }
 #pragma unroll
       for (int x = 0; x < 8; x++) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
       for (int x = 0; x < 4; x++) {
         const int32_t e = e0 + lane + 64 * x;
         const bool ok = e < e1;
-        c[x] = ok ? p.long_c[e] : 0.0f;
+        c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);
         ia[x] = ok ? p.long_a[e] : 0;
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
       }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
       for (int x = 0; x < 16; x++) {
         const int32_t e = e0 + lane + 64 * x;
         const bool ok = e < e1;
-        c[x] = ok ? p.long_c[e] : 0.0f;
+        c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);
         ia[x] = ok ? p.long_a[e] : 0;
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
       }

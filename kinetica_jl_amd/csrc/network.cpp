@@ -25,9 +25,9 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     int32_t width = 0;
     for (size_t q = g0; q < g1; q++) width = std::max(width, ptr[shorts[q] + 1] - ptr[shorts[q]]);
     size_t base = P.ell_a.size();
-    P.ell_a.resize(base + (size_t)width * 64, 0);
+    P.ell_a.resize(base + (size_t)width * 64, b ? -1 : 0);      // product plans mark padding by a < 0 (they never read c)
     if (b) P.ell_b.resize(base + (size_t)width * 64, 0);
-    P.ell_c.resize(base + (size_t)width * 64, 0.0f);
+    if (!b) P.ell_c.resize(base + (size_t)width * 64, 0.0f);
     for (int lane = 0; lane < 64; lane++) {
       size_t q = g0 + lane;
       if (q >= g1) { P.grp_dst.push_back(-1); P.grp_aux.push_back(0); continue; }
@@ -38,7 +38,7 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
         size_t pos = base + (size_t)col * 64 + lane;
         P.ell_a[pos] = a[e];
         if (b) P.ell_b[pos] = b[e];
-        P.ell_c[pos] = c ? c[e] : 1.0f;
+        if (!b) P.ell_c[pos] = c ? c[e] : 1.0f;
       }
     }
     P.grp_off.push_back(P.grp_off.back() + width);
@@ -53,7 +53,7 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     for (int32_t e = ptr[row]; e < ptr[row + 1]; e++) {
       P.long_a.push_back(a[e]);
       if (b) P.long_b.push_back(b[e]);
-      P.long_c.push_back(c ? c[e] : 1.0f);
+      if (!b) P.long_c.push_back(c ? c[e] : 1.0f);
     }
     (blk ? P.blk_end : P.seg_end).push_back((int32_t)P.long_a.size());
     (blk ? P.blk_dst : P.seg_dst).push_back(out);
