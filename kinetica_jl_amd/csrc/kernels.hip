@@ -17,13 +17,13 @@ void SegPlanDev::upload(const SegPlanHost& h, hipStream_t s) {
   seg_beg.upload(h.seg_beg, s); seg_end.upload(h.seg_end, s); seg_dst.upload(h.seg_dst, s); seg_aux.upload(h.seg_aux, s);
   long_a.upload(h.long_a, s); long_b.upload(h.long_b, s); long_c.upload(h.long_c, s);
   blk_beg.upload(h.blk_beg, s); blk_end.upload(h.blk_end, s); blk_dst.upload(h.blk_dst, s); blk_aux.upload(h.blk_aux, s);
-  G = h.n_groups(); S = h.n_segs(); B = h.n_blks();
+  G = h.n_groups(); S = h.n_segs(); B = h.n_blks(); val_base = h.val_base; ell_total = h.ell_total;
   KIN_HIP(hipStreamSynchronize(s));  // host vectors may die after this call
 }
 
 SegPlanView SegPlanDev::view() const {
   return SegPlanView{grp_off.p, grp_dst.p, grp_aux.p, ell_a.p, ell_b.p, ell_c.p, seg_beg.p, seg_end.p, seg_dst.p, seg_aux.p,
-                     blk_beg.p, blk_end.p, blk_dst.p, blk_aux.p, long_a.p, long_b.p, long_c.p, G, S, B};
+                     blk_beg.p, blk_end.p, blk_dst.p, blk_aux.p, long_a.p, long_b.p, long_c.p, G, S, B, val_base, ell_total};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -74,6 +74,8 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
   constexpr int SEG_WAVES = SEG_WG / 64, BLK_PER_THREAD = SegPlanHost::BLK_PASS / 1024;
   const int skip = ex.skip ? *ex.skip : 0;
   const int lane = threadIdx.x & 63;
+  const bool impl = p.val_base >= 0;                    // value-ordered plan: first factor of slot q = src[val_base + q]
+  const int32_t lbase = p.val_base + p.ell_total;
   if (SEG_WG == 1024 && (int)blockIdx.x < p.B) {
     __shared__ double sh[SEG_WAVES];
     const int r = blockIdx.x;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
         const int32_t e = base + (int32_t)threadIdx.x + 1024 * x;
         const bool ok = e < e1;
         c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);     // product plans carry no coefficients
-        ia[x] = ok ? p.long_a[e] : 0;
+        if (seg_is_prod<OP>::v && impl) ia[x] = lbase + e; else ia[x] = ok ? p.long_a[e] : 0;
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
       }
 #pragma unroll
@@ -131,9 +133,9 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
       for (int x = 0; x < 8; x++) {
         const size_t idx = (size_t)(col + x) * 64 + lane;
         const bool ok = col + x < c1;
-        ia[x] = ok ? p.ell_a[idx] : (seg_is_prod<OP>::v ? -1 : 0);
-        ib[x] = (seg_is_prod<OP>::v && ok) ? p.ell_b[idx] : 0;
-        c[x] = seg_is_prod<OP>::v ? (ia[x] >= 0 ? 1.0f : 0.0f) : (ok ? p.ell_c[idx] : 0.0f);   // product plans: padding = a < 0
+        if (seg_is_prod<OP>::v && impl) ia[x] = p.val_base + (int32_t)idx; else ia[x] = ok ? p.ell_a[idx] : 0;
+        ib[x] = (seg_is_prod<OP>::v && ok) ? p.ell_b[idx] : -1;
+        c[x] = seg_is_prod<OP>::v ? (ib[x] >= 0 ? 1.0f : 0.0f) : (ok ? p.ell_c[idx] : 0.0f);   // product plans: padding = b < 0
       }
 #pragma unroll
       for (int x = 0; x < 8; x++) {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
         const int32_t e = e0 + lane + 64 * x;
         const bool ok = e < e1;
         c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);
-        ia[x] = ok ? p.long_a[e] : 0;
+        if (seg_is_prod<OP>::v && impl) ia[x] = lbase + e; else ia[x] = ok ? p.long_a[e] : 0;
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
       }
 #pragma unroll
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
         const int32_t e = e0 + lane + 64 * x;
         const bool ok = e < e1;
         c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);
-        ia[x] = ok ? p.long_a[e] : 0;
+        if (seg_is_prod<OP>::v && impl) ia[x] = lbase + e; else ia[x] = ok ? p.long_a[e] : 0;
         ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
       }
 #pragma unroll

@@ -13,12 +13,13 @@ struct SegPlanView {
   const int32_t* blk_beg; const int32_t* blk_end; const int32_t* blk_dst; const int32_t* blk_aux;
   const int32_t* long_a; const int32_t* long_b; const float* long_c;
   int32_t G, S, B;
+  int32_t val_base, ell_total;   // value-ordered product plans (SegPlanHost::val_base), else val_base < 0
 };
 
 struct SegPlanDev {
   DevBuf<int32_t> grp_off, grp_dst, grp_aux, ell_a, ell_b, seg_beg, seg_end, seg_dst, seg_aux, blk_beg, blk_end, blk_dst, blk_aux, long_a, long_b;
   DevBuf<float> ell_c, long_c;
-  int32_t G = 0, S = 0, B = 0;
+  int32_t G = 0, S = 0, B = 0, val_base = -1, ell_total = 0;
   void upload(const SegPlanHost& h, hipStream_t s);
   SegPlanView view() const;
 };

@@ -264,9 +264,12 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       nnzLZ = 0; nnzNVU = 0;
       for (auto& r : lz_rows) nnzLZ += (int64_t)r.size();
       for (auto& r : nvu_rows) nnzNVU += (int64_t)r.size();
-      off_LZ = w_end;
-      off_NVU = align(off_LZ + nnzLZ);
-      off_zero = align(off_NVU + nnzNVU);
+      // LZ / NVU entries get IDs in a virtual range first; their storage is assigned below, in the order in which
+      // the solve reads them (value-ordered plans)
+      off_LZ = (int64_t)1 << 30;
+      off_NVU = off_LZ + nnzLZ;
+      if (off_NVU + nnzNVU >= ((int64_t)1 << 31)) throw KinError(ERR_UNSUPPORTED, "fused solve: too many entries");
+      off_zero = w_end;
       w_end = align(off_zero + 8);
       n_fused_products = nprod;
     }
@@ -287,9 +290,6 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     fprintf(stderr, "[lu] n=%d ns=%d m=%d rounds=%d nnzU=%lld nnzZ=%lld nnzV=%lld monomials=%lld explicit=%d fused=%d nnzLZ=%lld nnzNVU=%lld products=%lld\n",
             n, ns, m, nrounds, (long long)nnzU, (long long)nnzZ, (long long)nnzV, (long long)n_monomials, (int)explicit_tri, (int)fused_tri,
             (long long)nnzLZ, (long long)nnzNVU, (long long)n_fused_products);
-  w_size = w_end;
-  if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
-
   auto pos_of = [&](int32_t j, int32_t c) -> int64_t {  // location of W[j][c] (new indices), j,c later than the pivot
     if (j == c) return j < ns ? off_diag + j : off_S + (int64_t)(j - ns) * mpad + (j - ns);
     if (j >= ns && c >= ns) return off_S + (int64_t)(j - ns) * mpad + (c - ns);
@@ -348,7 +348,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       for (Triple& t : per_round[nrounds]) t.b = (int32_t)(off_y1 + (t.b - off_y));
     fwd_dense.upload(plan_from_triples(per_round[nrounds], false, 0, 0), s);
   }
-  if (explicit_tri) {
+  if (explicit_tri && !fused_tri) {
     // y1_i = b_i - sum_p Z'[i,p] b_p
     {
       std::vector<int32_t> ptr{0}, dst, aux, a, b;
@@ -379,23 +379,75 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       }
       bwdV.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
     }
-    mono_ent_ptr.upload(m_ent_ptr, s); mono_ptr.upload(m_ptr, s); mono_fac.upload(m_fac, s); mono_dst.upload(m_dst, s);
-    mono_sign.upload(m_sign, s);
-    KIN_HIP(hipStreamSynchronize(s));
   }
   if (fused_tri) {
+    // The two gather stages of the solve read each factor value exactly once, so the values are STORED in the order the
+    // stages read them (value-ordered plans: no index array for the first factor, coalesced value stream). Step 1: the
+    // stage structures with value IDs; step 2: storage positions from the plans' payload slots; step 3: every producer
+    // (monomial kernel for Z and V, the LZ / NVU product launches) writes to the relocated positions.
+    std::vector<int32_t> idA, idC, slotA, slotC;
+    SegPlanHost PA, PC;
+    {   // stage A: y1_i = b_i - sum_p Z'[i,p] b_p (sparse rows) ; y2_j = b2_j - sum_p LZ[j,p] b_p (dense rows, in place)
+      std::vector<int32_t> ptr{0}, dst, aux, b;
+      for (int32_t i = 0; i < ns; i++) {
+        for (auto& ce : z_cols[i]) { idA.push_back((int32_t)(off_Z + ce.second)); b.push_back((int32_t)(off_y + ce.first)); }
+        ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y1 + i)); aux.push_back((int32_t)(off_y + i));
+      }
+      int64_t idx = 0;
+      for (int32_t j = 0; j < m; j++) {
+        for (auto& ce : lz_rows[j]) { idA.push_back((int32_t)(off_LZ + idx++)); b.push_back((int32_t)(off_y + ce.first)); }
+        ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y + ns + j)); aux.push_back((int32_t)(off_y + ns + j));
+      }
+      b.push_back(0);
+      PA = build_seg_plan((int64_t)ns + m, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, aux.data(), &slotA);
+    }
+    {   // stage C: x1_i = sum_j V[i,j] y1_j + sum_c NVU[i,c] x2_c
+      std::vector<int32_t> ptr{0}, dst, b;
+      int64_t idx = 0;
+      for (int32_t i = 0; i < ns; i++) {
+        for (auto& ce : v_cols[i]) { idC.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_y1 + ce.first)); }
+        for (auto& ce : nvu_rows[i]) { idC.push_back((int32_t)(off_NVU + idx++)); b.push_back((int32_t)(off_x + ce.first)); }
+        ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y + i));
+      }
+      b.push_back(0);
+      PC = build_seg_plan(ns, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, nullptr, &slotC);
+    }
+    off_VA = w_end;
+    off_VC = align(off_VA + PA.ell_total + PA.long_total);
+    w_end = align(off_VC + PC.ell_total + PC.long_total + 8);
+    if (w_end >= ((int64_t)1 << 30)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
+    PA.val_base = (int32_t)off_VA; PC.val_base = (int32_t)off_VC;
+    stageA.upload(PA, s); stageC.upload(PC, s);
+    // relocation of the value IDs
+    std::vector<int32_t> relZ(nnzZ, -1), relV(nnzV, -1), relLZ(nnzLZ, -1), relNVU(nnzNVU, -1);
+    auto place = [&](int32_t id, int32_t pos) {
+      if (id >= off_NVU) relNVU[id - off_NVU] = pos;
+      else if (id >= off_LZ) relLZ[id - off_LZ] = pos;
+      else if (id >= off_V) relV[id - off_V] = pos;
+      else relZ[id - off_Z] = pos;
+    };
+    for (size_t e = 0; e < idA.size(); e++) place(idA[e], (int32_t)(off_VA + slotA[e]));
+    for (size_t e = 0; e < idC.size(); e++) place(idC[e], (int32_t)(off_VC + slotC[e]));
+    auto R = [&](int32_t pos) -> int32_t {
+      int32_t r = pos;
+      if (pos >= off_NVU) r = relNVU[pos - off_NVU];
+      else if (pos >= off_LZ) r = relLZ[pos - off_LZ];
+      else if (pos >= off_V && pos < off_V + nnzV) r = relV[pos - off_V];
+      else if (pos >= off_Z && pos < off_Z + nnzZ) r = relZ[pos - off_Z];
+      if (r < 0) throw KinError(ERR_DEVICE, "internal: fused solve value without a storage position");
+      return r;
+    };
+    for (int32_t& d : m_dst) d = R(d);
     // numeric products of a factorisation: LZ[j,p] = L21[j,p] - sum_k L21[j,k] Z'[k,p] ; NVU[i,c] = - sum_j V[i,j] U12[j,c]
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> lz_cols(m), nvu_cols(ns);     // (column, value position)
     {
       std::vector<int32_t> ptr{0}, dst, aux, a, b;
       int64_t idx = 0;
       for (int32_t j = 0; j < m; j++)
         for (auto& ce : lz_rows[j]) {
-          for (const Prod& pr : ce.second.second) { a.push_back(pr.a); b.push_back(pr.b); }
+          for (const Prod& pr : ce.second.second) { a.push_back(pr.a); b.push_back(R(pr.b)); }
           ptr.push_back((int32_t)a.size());
-          dst.push_back((int32_t)(off_LZ + idx));
+          dst.push_back(R((int32_t)(off_LZ + idx)));
           aux.push_back(ce.second.first >= 0 ? ce.second.first : (int32_t)off_zero);
-          lz_cols[j].push_back({ce.first, (int32_t)(off_LZ + idx)});
           idx++;
         }
       a.push_back(0); b.push_back(0);
@@ -406,41 +458,23 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       int64_t idx = 0;
       for (int32_t i = 0; i < ns; i++)
         for (auto& ce : nvu_rows[i]) {
-          for (const Prod& pr : ce.second.second) { a.push_back(pr.a); b.push_back(pr.b); }
+          for (const Prod& pr : ce.second.second) { a.push_back(R(pr.a)); b.push_back(pr.b); }
           ptr.push_back((int32_t)a.size());
-          dst.push_back((int32_t)(off_NVU + idx));
-          nvu_cols[i].push_back({ce.first, (int32_t)(off_NVU + idx)});
+          dst.push_back(R((int32_t)(off_NVU + idx)));
           idx++;
         }
       a.push_back(0); b.push_back(0);
       nvu_build.upload(build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
     }
-    // stage A: y1_i = b_i - sum_p Z'[i,p] b_p (sparse rows) ; y2_j = b2_j - sum_p LZ[j,p] b_p (dense rows, in place)
-    {
-      std::vector<int32_t> ptr{0}, dst, aux, a, b;
-      for (int32_t i = 0; i < ns; i++) {
-        for (auto& ce : z_cols[i]) { a.push_back((int32_t)(off_Z + ce.second)); b.push_back((int32_t)(off_y + ce.first)); }
-        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y1 + i)); aux.push_back((int32_t)(off_y + i));
-      }
-      for (int32_t j = 0; j < m; j++) {
-        for (auto& ce : lz_cols[j]) { a.push_back(ce.second); b.push_back((int32_t)(off_y + ce.first)); }
-        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y + ns + j)); aux.push_back((int32_t)(off_y + ns + j));
-      }
-      a.push_back(0); b.push_back(0);
-      stageA.upload(build_seg_plan((int64_t)ns + m, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
-    }
-    // stage C: x1_i = sum_j V[i,j] y1_j + sum_c NVU[i,c] x2_c
-    {
-      std::vector<int32_t> ptr{0}, dst, a, b;
-      for (int32_t i = 0; i < ns; i++) {
-        for (auto& ce : v_cols[i]) { a.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_y1 + ce.first)); }
-        for (auto& ce : nvu_cols[i]) { a.push_back(ce.second); b.push_back((int32_t)(off_x + ce.first)); }
-        ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y + i));
-      }
-      stageC.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
-    }
     KIN_HIP(hipStreamSynchronize(s));
   }
+  if (explicit_tri) {
+    mono_ent_ptr.upload(m_ent_ptr, s); mono_ptr.upload(m_ptr, s); mono_fac.upload(m_fac, s); mono_dst.upload(m_dst, s);
+    mono_sign.upload(m_sign, s);
+    KIN_HIP(hipStreamSynchronize(s));
+  }
+  w_size = w_end;
+  if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
   // ---- backward substitution: x_p = (y_p - sum_c U[p][c] x_c) / diag_p
   for (int r = 0; r < nrounds; r++) {
     int32_t p0 = round_ptr[r], p1 = round_ptr[r + 1];

@@ -82,7 +82,7 @@ struct SparseLU {
   // launches, entries = short sums of products of factor values) the solve is THREE dependent launches:
   //   [y1 = Z b1 ; y2 = b2 - LZ b1] | x2 = S^-1 y2 | x1 = V y1 + NVU x2
   bool fused_tri = false;
-  int64_t off_LZ = 0, off_NVU = 0, off_zero = 0, nnzLZ = 0, nnzNVU = 0, n_fused_products = 0;
+  int64_t off_LZ = 0, off_NVU = 0, off_zero = 0, off_VA = 0, off_VC = 0, nnzLZ = 0, nnzNVU = 0, n_fused_products = 0;
   SegPlanDev lz_build, nvu_build, stageA, stageC;
   int64_t nnzJ = 0;
 

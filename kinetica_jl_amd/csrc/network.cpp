@@ -8,8 +8,10 @@
 namespace kin {
 
 SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
-                           const int32_t* b, const float* c, bool skip_empty, const int32_t* aux) {
+                           const int32_t* b, const float* c, bool skip_empty, const int32_t* aux,
+                           std::vector<int32_t>* slot_of_entry) {
   SegPlanHost P;
+  if (slot_of_entry) slot_of_entry->assign((size_t)ptr[n_rows], -1);
   std::vector<int32_t> shorts, longs;
   for (int64_t i = 0; i < n_rows; i++) {
     int32_t len = ptr[i + 1] - ptr[i];
@@ -24,10 +26,10 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     size_t g1 = std::min(shorts.size(), g0 + 64);
     int32_t width = 0;
     for (size_t q = g0; q < g1; q++) width = std::max(width, ptr[shorts[q] + 1] - ptr[shorts[q]]);
-    size_t base = P.ell_a.size();
-    P.ell_a.resize(base + (size_t)width * 64, b ? -1 : 0);      // product plans mark padding by a < 0 (they never read c)
-    if (b) P.ell_b.resize(base + (size_t)width * 64, 0);
-    if (!b) P.ell_c.resize(base + (size_t)width * 64, 0.0f);
+    const size_t ell_base = (size_t)P.grp_off.back() * 64;
+    if (a) P.ell_a.resize(ell_base + (size_t)width * 64, 0);
+    if (b) P.ell_b.resize(ell_base + (size_t)width * 64, -1);    // product plans mark padding by b < 0 (they never read c)
+    if (!b) P.ell_c.resize(ell_base + (size_t)width * 64, 0.0f);
     for (int lane = 0; lane < 64; lane++) {
       size_t q = g0 + lane;
       if (q >= g1) { P.grp_dst.push_back(-1); P.grp_aux.push_back(0); continue; }
@@ -35,8 +37,9 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
       P.grp_dst.push_back(dst ? dst[row] : row);
       P.grp_aux.push_back(aux ? aux[row] : 0);
       for (int32_t e = ptr[row], col = 0; e < ptr[row + 1]; e++, col++) {
-        size_t pos = base + (size_t)col * 64 + lane;
-        P.ell_a[pos] = a[e];
+        size_t pos = ell_base + (size_t)col * 64 + lane;
+        if (a) P.ell_a[pos] = a[e];
+        if (slot_of_entry) (*slot_of_entry)[e] = (int32_t)pos;
         if (b) P.ell_b[pos] = b[e];
         if (!b) P.ell_c[pos] = c ? c[e] : 1.0f;
       }
@@ -45,20 +48,26 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
   }
   // medium rows -> one segment (one wavefront); long rows -> one workgroup. Longest first: the long tasks start first.
   std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) { return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y]; });
+  const int32_t ell_total = P.grp_off.back() * 64;
+  P.ell_total = ell_total;
+  int32_t long_total = 0;
   for (int32_t row : longs) {
     const int32_t len = ptr[row + 1] - ptr[row];
     const int32_t out = dst ? dst[row] : row;
     const bool blk = len > SegPlanHost::SEG_LEN;
-    (blk ? P.blk_beg : P.seg_beg).push_back((int32_t)P.long_a.size());
+    (blk ? P.blk_beg : P.seg_beg).push_back(long_total);
     for (int32_t e = ptr[row]; e < ptr[row + 1]; e++) {
-      P.long_a.push_back(a[e]);
+      if (a) P.long_a.push_back(a[e]);
       if (b) P.long_b.push_back(b[e]);
       if (!b) P.long_c.push_back(c ? c[e] : 1.0f);
+      if (slot_of_entry) (*slot_of_entry)[e] = ell_total + long_total;
+      long_total++;
     }
-    (blk ? P.blk_end : P.seg_end).push_back((int32_t)P.long_a.size());
+    (blk ? P.blk_end : P.seg_end).push_back(long_total);
     (blk ? P.blk_dst : P.seg_dst).push_back(out);
     (blk ? P.blk_aux : P.seg_aux).push_back(aux ? aux[row] : 0);
   }
+  P.long_total = long_total;
   return P;
 }
 

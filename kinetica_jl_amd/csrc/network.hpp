@@ -40,6 +40,11 @@ struct SegPlanHost {
   std::vector<int32_t> blk_beg, blk_end, blk_dst, blk_aux;   // B
   std::vector<int32_t> long_a, long_b;    // payload of segments and long rows
   std::vector<float> long_c;
+  // Value-ordered product plans: when val_base >= 0 the first factor of payload slot q is src[val_base + q] (ELL slots
+  // first, then the long payload) - no `a` index array, and the values are read as a coalesced stream instead of a
+  // gather. The producers of those values write them at val_base + slot (build_seg_plan reports each entry's slot).
+  int32_t val_base = -1;
+  int32_t ell_total = 0, long_total = 0;     // payload slots of the ELL part / of the medium + long rows
   int32_t n_groups() const { return (int32_t)grp_off.size() - 1; }
   int32_t n_segs() const { return (int32_t)seg_beg.size(); }
   int32_t n_blks() const { return (int32_t)blk_beg.size(); }
@@ -47,8 +52,11 @@ struct SegPlanHost {
 
 // Build a plan from CSR rows. `dst[row]` is the output index of a row; rows with no entries
 // are still scheduled (they produce 0) unless skip_empty. `b` and `c` may be null.
+// `slot_of_entry` (optional, product plans): payload slot of every input entry (see SegPlanHost::val_base); with it
+// given and `a` null the plan is built value-ordered (the caller sets val_base afterwards).
 SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
-                           const int32_t* b, const float* c, bool skip_empty, const int32_t* aux = nullptr);
+                           const int32_t* b, const float* c, bool skip_empty, const int32_t* aux = nullptr,
+                           std::vector<int32_t>* slot_of_entry = nullptr);
 
 struct NetworkHost {
   int64_t N = 0, R = 0;
