@@ -65,6 +65,40 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// One round of NX entries per lane: all index loads, then all gathers, then the sum in slot order (two dependent loads on
+// the critical path). `idx_of(x)` = payload index of this lane's x-th entry, or -1. ELL = entries of an ELL group (padding
+// inside the group is marked in the payload), else the contiguous payload of medium / long rows.
+template <int OP, int NX, bool ELL, class F>
+__device__ __forceinline__ double seg_gather(const SegPlanView& p, const double* src, const SegExtra& ex, bool impl, F idx_of) {
+  constexpr bool PROD = seg_is_prod<OP>::v;
+  const int32_t* A = ELL ? p.ell_a : p.long_a;
+  const int32_t* Bp = ELL ? p.ell_b : p.long_b;
+  const float* C = ELL ? p.ell_c : p.long_c;
+  const int32_t vbase = ELL ? p.val_base : p.val_base + p.ell_total;
+  float c[NX]; int32_t ia[NX], ib[NX]; double va[NX], vb[NX];
+#pragma unroll
+  for (int x = 0; x < NX; x++) {
+    const int32_t e = idx_of(x);
+    const bool ok = e >= 0;
+    ib[x] = (PROD && ok) ? Bp[e] : -1;
+    if (PROD && impl) ia[x] = vbase + e; else ia[x] = ok ? A[e] : 0;
+    c[x] = PROD ? (ib[x] >= 0 ? 1.0f : 0.0f) : (ok ? C[e] : 0.0f);   // product plans carry no coefficients: padding = b < 0
+  }
+#pragma unroll
+  for (int x = 0; x < NX; x++) {
+    const bool on = c[x] != 0.0f;
+    va[x] = on ? src[ia[x]] : 0.0;
+    vb[x] = (PROD && on) ? src[ib[x]] : 0.0;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int x = 0; x < NX; x++) {
+    if (PROD) acc += va[x] * vb[x];
+    else acc += (double)c[x] * va[x];
+  }
+  return acc;
+}
+
 // grid of 1024-thread workgroups: the first p.B take one LONG row each (whole workgroup, BLK_PASS entries per pass, so
 // that all but the very longest rows are ONE round of index loads + gathers), the others sixteen wavefront tasks each
 // (an ELL group of 64 short rows, or one medium row)
@@ -75,41 +109,24 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
   const int skip = ex.skip ? *ex.skip : 0;
   const int lane = threadIdx.x & 63;
   const bool impl = p.val_base >= 0;                    // value-ordered plan: first factor of slot q = src[val_base + q]
-  const int32_t lbase = p.val_base + p.ell_total;
   if (SEG_WG == 1024 && (int)blockIdx.x < p.B) {
     __shared__ double sh[SEG_WAVES];
     const int r = blockIdx.x;
     const int32_t e0 = p.blk_beg[r], e1 = p.blk_end[r];
     const int32_t bdst = p.blk_dst[r];
     const int32_t baux = p.blk_aux[r];
-    if (skip) return;      // (whole workgroup: the flag is uniform) tested once the first round of loads is back, see below
+    if (skip) return;      // (whole workgroup: the flag is uniform) tested once the first round of loads is back, see above
     const SegPre pre = seg_pre<OP>(out, src, threadIdx.x == 0 ? bdst : -1, baux, ex);
     double acc = 0.0;
-    for (int32_t base = e0; base < e1; base += SegPlanHost::BLK_PASS) {
-      float c[BLK_PER_THREAD]; int32_t ia[BLK_PER_THREAD], ib[BLK_PER_THREAD]; double va[BLK_PER_THREAD], vb[BLK_PER_THREAD];
-#pragma unroll
-      for (int x = 0; x < BLK_PER_THREAD; x++) {
+    for (int32_t base = e0; base < e1; base += SegPlanHost::BLK_PASS)
+      acc += seg_gather<OP, BLK_PER_THREAD, false>(p, src, ex, impl, [&](int x) {
         const int32_t e = base + (int32_t)threadIdx.x + 1024 * x;
-        const bool ok = e < e1;
-        c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);     // product plans carry no coefficients
-        if (seg_is_prod<OP>::v && impl) ia[x] = lbase + e; else ia[x] = ok ? p.long_a[e] : 0;
-        ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
-      }
-#pragma unroll
-      for (int x = 0; x < BLK_PER_THREAD; x++) {
-        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
-        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
-      }
-#pragma unroll
-      for (int x = 0; x < BLK_PER_THREAD; x++) {
-        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
-        else acc += (double)c[x] * va[x];
-      }
-    }
+        return e < e1 ? e : -1;
+      });
     acc = wave_sum(acc);
     if (lane == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0 && !skip) {
+    if (threadIdx.x == 0) {
       double tot = 0.0;
 #pragma unroll
       for (int w = 0; w < SEG_WAVES; w++) tot += sh[w];     // fixed order
@@ -125,30 +142,9 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
     if (skip) return;
     const SegPre pre = seg_pre<OP>(out, src, dst, aux, ex);
     double acc = 0.0;
-    for (int32_t col = c0; col < c1; col += 8) {
-      // issue the index loads of up to eight columns (a whole ELL group: rows have <= 8 entries), then
-      // their gathers, then accumulate in order: two dependent loads on the critical path, not four
-      float c[8]; int32_t ia[8], ib[8]; double va[8], vb[8];
-#pragma unroll
-      for (int x = 0; x < 8; x++) {
-        const size_t idx = (size_t)(col + x) * 64 + lane;
-        const bool ok = col + x < c1;
-        if (seg_is_prod<OP>::v && impl) ia[x] = p.val_base + (int32_t)idx; else ia[x] = ok ? p.ell_a[idx] : 0;
-        ib[x] = (seg_is_prod<OP>::v && ok) ? p.ell_b[idx] : -1;
-        c[x] = seg_is_prod<OP>::v ? (ib[x] >= 0 ? 1.0f : 0.0f) : (ok ? p.ell_c[idx] : 0.0f);   // product plans: padding = b < 0
-      }
-#pragma unroll
-      for (int x = 0; x < 8; x++) {
-        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
-        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
-      }
-#pragma unroll
-      for (int x = 0; x < 8; x++) {
-        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
-        else acc += (double)c[x] * va[x];
-      }
-    }
-    if (dst >= 0 && !skip) seg_store<OP>(out, dst, acc, pre, ex);
+    for (int32_t col = c0; col < c1; col += 8)       // a whole ELL group in one round: rows have <= 8 entries
+      acc += seg_gather<OP, 8, true>(p, src, ex, impl, [&](int x) { return col + x < c1 ? (col + x) * 64 + lane : -1; });
+    if (dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
   } else if (task < p.G + p.S) {
     const int sidx = task - p.G;
     const int32_t e0 = p.seg_beg[sidx], e1 = p.seg_end[sidx];
@@ -156,52 +152,15 @@ __global__ __launch_bounds__(SEG_WG) void segsum_kernel(SegPlanView p, const dou
     const int32_t saux = p.seg_aux[sidx];
     if (skip) return;
     const SegPre pre = seg_pre<OP>(out, src, lane == 0 ? sdst : -1, saux, ex);
-    // up to 256 entries: four per lane; up to SEG_LEN = 1024: sixteen per lane - either way ONE round of index loads
-    // and ONE round of gathers, all in flight together
-    double acc = 0.0;
-    if (e1 - e0 <= 256) {
-      float c[4]; int32_t ia[4], ib[4]; double va[4], vb[4];
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        const int32_t e = e0 + lane + 64 * x;
-        const bool ok = e < e1;
-        c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);
-        if (seg_is_prod<OP>::v && impl) ia[x] = lbase + e; else ia[x] = ok ? p.long_a[e] : 0;
-        ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
-        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
-        else acc += (double)c[x] * va[x];
-      }
-    } else {
-      float c[16]; int32_t ia[16], ib[16]; double va[16], vb[16];
-#pragma unroll
-      for (int x = 0; x < 16; x++) {
-        const int32_t e = e0 + lane + 64 * x;
-        const bool ok = e < e1;
-        c[x] = seg_is_prod<OP>::v ? (ok ? 1.0f : 0.0f) : (ok ? p.long_c[e] : 0.0f);
-        if (seg_is_prod<OP>::v && impl) ia[x] = lbase + e; else ia[x] = ok ? p.long_a[e] : 0;
-        ib[x] = (seg_is_prod<OP>::v && ok) ? p.long_b[e] : 0;
-      }
-#pragma unroll
-      for (int x = 0; x < 16; x++) {
-        va[x] = c[x] != 0.0f ? src[ia[x]] : 0.0;
-        vb[x] = (seg_is_prod<OP>::v && c[x] != 0.0f) ? src[ib[x]] : 0.0;
-      }
-#pragma unroll
-      for (int x = 0; x < 16; x++) {
-        if (seg_is_prod<OP>::v) acc += va[x] * vb[x];
-        else acc += (double)c[x] * va[x];
-      }
-    }
+    // up to 256 entries: four per lane; up to 1024: sixteen per lane - either way ONE round of index loads and ONE
+    // round of gathers, all in flight together
+    double acc;
+    if (e1 - e0 <= 256)
+      acc = seg_gather<OP, 4, false>(p, src, ex, impl, [&](int x) { const int32_t e = e0 + lane + 64 * x; return e < e1 ? e : -1; });
+    else
+      acc = seg_gather<OP, 16, false>(p, src, ex, impl, [&](int x) { const int32_t e = e0 + lane + 64 * x; return e < e1 ? e : -1; });
     acc = wave_sum(acc);
-    if (lane == 0 && !skip) seg_store<OP>(out, sdst, acc, pre, ex);
+    if (lane == 0) seg_store<OP>(out, sdst, acc, pre, ex);
   }
 }
 

@@ -11,6 +11,7 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
                            const int32_t* b, const float* c, bool skip_empty, const int32_t* aux,
                            std::vector<int32_t>* slot_of_entry) {
   SegPlanHost P;
+  const bool prod = b != nullptr; // product plan: no coefficients, padding marked by b < 0
   if (slot_of_entry) slot_of_entry->assign((size_t)ptr[n_rows], -1);
   std::vector<int32_t> shorts, longs;
   for (int64_t i = 0; i < n_rows; i++) {
@@ -28,8 +29,8 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     for (size_t q = g0; q < g1; q++) width = std::max(width, ptr[shorts[q] + 1] - ptr[shorts[q]]);
     const size_t ell_base = (size_t)P.grp_off.back() * 64;
     if (a) P.ell_a.resize(ell_base + (size_t)width * 64, 0);
-    if (b) P.ell_b.resize(ell_base + (size_t)width * 64, -1);    // product plans mark padding by b < 0 (they never read c)
-    if (!b) P.ell_c.resize(ell_base + (size_t)width * 64, 0.0f);
+    if (b) P.ell_b.resize(ell_base + (size_t)width * 64, prod ? -1 : 0);
+    if (!prod) P.ell_c.resize(ell_base + (size_t)width * 64, 0.0f);
     for (int lane = 0; lane < 64; lane++) {
       size_t q = g0 + lane;
       if (q >= g1) { P.grp_dst.push_back(-1); P.grp_aux.push_back(0); continue; }
@@ -41,7 +42,7 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
         if (a) P.ell_a[pos] = a[e];
         if (slot_of_entry) (*slot_of_entry)[e] = (int32_t)pos;
         if (b) P.ell_b[pos] = b[e];
-        if (!b) P.ell_c[pos] = c ? c[e] : 1.0f;
+        if (!prod) P.ell_c[pos] = c ? c[e] : 1.0f;
       }
     }
     P.grp_off.push_back(P.grp_off.back() + width);
@@ -59,7 +60,7 @@ SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* ds
     for (int32_t e = ptr[row]; e < ptr[row + 1]; e++) {
       if (a) P.long_a.push_back(a[e]);
       if (b) P.long_b.push_back(b[e]);
-      if (!b) P.long_c.push_back(c ? c[e] : 1.0f);
+      if (!prod) P.long_c.push_back(c ? c[e] : 1.0f);
       if (slot_of_entry) (*slot_of_entry)[e] = ell_total + long_total;
       long_total++;
     }

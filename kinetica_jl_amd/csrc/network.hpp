@@ -51,7 +51,8 @@ struct SegPlanHost {
 };
 
 // Build a plan from CSR rows. `dst[row]` is the output index of a row; rows with no entries
-// are still scheduled (they produce 0) unless skip_empty. `b` and `c` may be null.
+// are still scheduled (they produce 0) unless skip_empty. `b` and `c` may be null. With `b` the plan is a
+// product plan (entries src[a] * src[b], no coefficients).
 // `slot_of_entry` (optional, product plans): payload slot of every input entry (see SegPlanHost::val_base); with it
 // given and `a` null the plan is built value-ordered (the caller sets val_base afterwards).
 SegPlanHost build_seg_plan(int64_t n_rows, const int32_t* ptr, const int32_t* dst, const int32_t* a,
