@@ -454,45 +454,51 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
   __shared__ int last;
   if (ctrl->newton_done) return;
   const int G = gridDim.x;
+  // A non-finite update makes the sum of squares non-finite: one reduction carries both the norm and the flag.
   double s = 0.0;
-  int bad = 0;
-  {
-    const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
-    int32_t xl[4]; double dy[4], sc[4], yy[4], dd[4];
+  const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
+  int32_t xl[4]; double dy[4], sc[4], yy[4], dd[4];
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
-      const int i = i0 + 256 * x;
-      xl[x] = i < N ? xloc[i] : -1; sc[x] = i < N ? scale[i] : 1.0;
-      yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
-    }
+  for (int x = 0; x < 4; x++) {
+    const int i = i0 + 256 * x;
+    xl[x] = i < N ? xloc[i] : -1; sc[x] = i < N ? scale[i] : 1.0;
+    yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
+  }
 #pragma unroll
-    for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
+  for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
-      const int i = i0 + 256 * x;
-      if (!isfinite(dy[x])) bad = 1;
-      const double q = dy[x] / sc[x];
-      s += q * q;
-      if (i < N) { y[i] = yy[x] + dy[x]; d[i] = dd[x] + dy[x]; }
-    }
+  for (int x = 0; x < 4; x++) {
+    const double q = dy[x] / sc[x];
+    s += q * q;
   }
   const double ps = block_sum_256(s, sh);
-  const double pb = block_sum_256((double)bad, sh);
-  if (threadIdx.x == 0) { store_partial(part + blockIdx.x, ps); store_partial(part + G + blockIdx.x, pb); }
-  if (!last_block_arrives(ctrl, &last)) return;
+  if (threadIdx.x == 0) store_partial(part + blockIdx.x, ps);
+  const bool is_last = last_block_arrives(ctrl, &last);
+  // the state update is off the critical path of the decision: its stores go out while the ticket travels
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int i = i0 + 256 * x;
+    if (i < N) { y[i] = yy[x] + dy[x]; d[i] = dd[x] + dy[x]; }
+  }
+  if (!is_last) return;
   if (threadIdx.x == 0) {
-    const double tot = sum_partials(part, G), nbad = sum_partials(part + G, G);
+    const double tot = sum_partials(part, G);
     const double old = ctrl->dy_norm_old;
     const double dy_norm = sqrt(tot / (double)N);
+    const bool nonfinite = !isfinite(tot);
     const bool have_rate = iter > 0;
     const double rate = have_rate ? dy_norm / old : 0.0;
-    bool diverged = (nbad > 0.0) || !isfinite(dy_norm);
+    bool diverged = nonfinite;
     // rate_max < 1 (a reused factorisation): a contraction slower than that means the matrix no longer matches the
     // Jacobian well enough for the error of the iteration to be judged from two or three corrections
-    if (!diverged && have_rate && (rate >= rate_max || pow(rate, (double)(maxit - iter)) / (1.0 - rate) * dy_norm > tol)) diverged = true;
+    if (!diverged && have_rate) {
+      double rp = rate;                                     // rate^(maxit - iter), 1 <= maxit - iter <= 3
+      for (int e = 1; e < maxit - iter; e++) rp *= rate;
+      if (rate >= rate_max || rp / (1.0 - rate) * dy_norm > tol) diverged = true;
+    }
     ctrl->n_iter = iter + 1;
     ctrl->dy_norm = dy_norm;
-    if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nbad > 0.0; }
+    if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nonfinite; }
     else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) || (!have_rate && dy_norm < tol)) {
       ctrl->newton_done = 1; ctrl->converged = 1;   // (first-iteration acceptance as in ode15s / CVODE)
     }
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const 
                                                         const double* __restrict__ d, double atol, double rtol, BdfCoef cf,
                                                         BdfCtrl* ctrl, double* __restrict__ part, BdfCtrl* host_ctrl,
                                                         unsigned long long* host_seq, unsigned long long seq) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   __shared__ int last;
   // The attempt ends with this kernel: its last action publishes the control block straight into pinned host
   // memory and bumps a sequence number the host spins on - no D2H copy, no stream synchronisation on the
@@ -521,8 +527,7 @@ __global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const 
     return;
   }
   const int G = gridDim.x;
-  double se = 0.0, sm = 0.0, sp = 0.0;
-  int neg = 0, bad = 0;
+  double se = 0.0, sm = 0.0, sp = 0.0, neg = 0.0;
   {
     const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
     double yi[4], di[4], dm[4], dp[4];
@@ -537,28 +542,39 @@ __global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const 
 #pragma unroll
     for (int x = 0; x < 4; x++) {
       if (i0 + 256 * x >= N) continue;
-      if (yi[x] < 0.0) neg = 1;
-      if (!isfinite(yi[x])) bad = 1;
+      if (yi[x] < 0.0) neg = 1.0;
+      // a non-finite state makes its scale, hence the sum of squares, non-finite: no separate flag reduction
       const double sc = atol + rtol * fabs(yi[x]);
       const double e = cf.error_const[order] * di[x] / sc;
-      se += e * e;
+      se += e * e + (isfinite(yi[x]) ? 0.0 : INFINITY);
       if (order > 1) { const double em = cf.error_const[order - 1] * (dm[x] + di[x]) / sc; sm += em * em; }
       if (order < 5) { const double ep = cf.error_const[order + 1] * (di[x] - dp[x]) / sc; sp += ep * ep; }
     }
   }
-  const double pe = block_sum_256(se, sh), pm = block_sum_256(sm, sh), pp = block_sum_256(sp, sh);
-  const double pn = block_sum_256((double)neg, sh), pb = block_sum_256((double)bad, sh);
+  // four sums, one pair of barriers
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    se += __shfl_down(se, off, 64); sm += __shfl_down(sm, off, 64); sp += __shfl_down(sp, off, 64); neg += __shfl_down(neg, off, 64);
+  }
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[4 * w] = se; sh[4 * w + 1] = sm; sh[4 * w + 2] = sp; sh[4 * w + 3] = neg; }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    store_partial(part + blockIdx.x, pe); store_partial(part + G + blockIdx.x, pm); store_partial(part + 2 * G + blockIdx.x, pp);
-    store_partial(part + 3 * G + blockIdx.x, pn); store_partial(part + 4 * G + blockIdx.x, pb);
+    store_partial(part + blockIdx.x, (sh[0] + sh[4]) + (sh[8] + sh[12]));
+    store_partial(part + G + blockIdx.x, (sh[1] + sh[5]) + (sh[9] + sh[13]));
+    store_partial(part + 2 * G + blockIdx.x, (sh[2] + sh[6]) + (sh[10] + sh[14]));
+    store_partial(part + 3 * G + blockIdx.x, (sh[3] + sh[7]) + (sh[11] + sh[15]));
   }
   if (!last_block_arrives(ctrl, &last)) return;
   if (threadIdx.x == 0) {
-    ctrl->err_norm = sqrt(sum_partials(part, G) / (double)N);
+    const double te = sum_partials(part, G);
+    ctrl->err_norm = sqrt(te / (double)N);
     ctrl->err_m_norm = sqrt(sum_partials(part + G, G) / (double)N);
     ctrl->err_p_norm = sqrt(sum_partials(part + 2 * G, G) / (double)N);
     ctrl->any_negative = sum_partials(part + 3 * G, G) > 0.0;
-    if (sum_partials(part + 4 * G, G) > 0.0) ctrl->nonfinite = 1;
+    if (!isfinite(te)) ctrl->nonfinite = 1;
     if (host_ctrl) {
       *host_ctrl = *ctrl;
       __threadfence_system();
