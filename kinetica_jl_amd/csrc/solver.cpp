@@ -307,7 +307,8 @@ struct Solver {
     }
   }
 
-  double reuse_rate_max = 0.1;   // KIN_LU_RATE_MAX: slowest contraction accepted from a reused factorisation
+  double reuse_rate_max = 0.2;   // KIN_LU_RATE_MAX: slowest contraction accepted from a reused factorisation (0.1: 12 % slower on C3,
+                                 // 0.5: 17 % slower on the C4 ramp - slow contractions leave iteration error in the error estimates)
   // KIN_LU_MAX_AGE: a slot is offered for that many restarts after its Jacobian was evaluated. Unlimited reuse is
   // UNSAFE: a direction that was stiff when the slot was made (c J ~ 1e6) and is not any more (its species consumed) is
   // damped to nothing by the old matrix - the corrections vanish, the corrector "converges" at once, and both the

@@ -81,7 +81,7 @@ class OracleBDF:
         # guards of the cache (solver.cpp): a reused factorisation must contract at least 10-fold per iteration
         # (lu_rate_max); after an error-test rejection the retry gets a factorisation of its own (force_fresh_lu, with a
         # new Jacobian if the old one is more than 20 steps old); a reused slot that needed every allowed iteration is dropped
-        self.lu_rate_max = 0.1
+        self.lu_rate_max = 0.2
         self.lu_max_age = 50             # restarts a slot stays on offer after its Jacobian was evaluated
         self.lu_drift_max = 0.25         # drift guard: see Solver::restart (solver.cpp)
         self.jac_stamp_now = 0

@@ -416,7 +416,7 @@ struct Bdf {
   // (4 per decade) and reused - across step-size changes AND across restarts - while |c / c_fact - 1| <= lu_reuse,
   // with the update scaled by 2 / (1 + c / c_fact); a slot is refreshed (new Jacobian, new factorisation) only when a
   // corrector that used it fails. lu_cache = number of slots (0: off).
-  double lu_rate_max = 0.1;   // slowest contraction accepted from a reused factorisation
+  double lu_rate_max = 0.2;   // slowest contraction accepted from a reused factorisation
   bool force_fresh_lu = false, slot_is_fresh = true;
   int64_t steps_since_jac = 0;
   int lu_cache = 0;
