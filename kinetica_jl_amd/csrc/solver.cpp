@@ -206,7 +206,34 @@ struct Solver {
 
   void eval_jac(const double* u) { h->jac_dev(u, jv.p); st.n_jac++; lu_valid = false; steps_since_jac = 0; jac_stamp_now = st.n_restarts; }
 
+  // The accept of a step (D <- D + d, new difference rows) is deferred and rides in the next step's predictor launch
+  // (bdf_accept_predict_kernel: both are one pass over the same columns of D); so does the copy of the new state into
+  // the solution buffer when every step is saved. Everything else that reads D calls flush_accept() first.
+  bool accept_pending = false;
+  int accept_order = 0;
+  double* accept_copy = nullptr;
+  void flush_accept() {
+    if (!accept_pending) return;
+    launch_bdf_accept(N, accept_order, D.p, d.p, accept_copy, s);
+    accept_pending = false; accept_copy = nullptr;
+  }
+  void predict() {
+    if (accept_pending) {
+      launch_bdf_accept_predict(N, accept_order, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, accept_copy, s);
+      accept_pending = false; accept_copy = nullptr;
+    } else
+      launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+  }
+  // the state after the last accepted step (D[0]), for readers outside the integrator
+  double* state_ptr() { flush_accept(); return D.p; }
+  // copy of that state into `dst` (a row of the solution buffer): rides with the pending accept when there is one
+  void save_state(double* dst) {
+    if (accept_pending && !accept_copy) accept_copy = dst;
+    else KIN_HIP(hipMemcpyAsync(dst, state_ptr(), (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+
   void change_D(int ord, double factor) {
+    flush_accept();
     double R[6][6], U[6][6];
     compute_R(ord, factor, R);
     compute_R(ord, 1.0, U);
@@ -223,6 +250,7 @@ struct Solver {
   // (re)start the integrator at time t0 from the state in y (reinit! semantics: order 1, fresh
   // initial step, fresh Jacobian). Returns false when f(y0) is not finite.
   bool restart(double t0, double t_bound) {
+    flush_accept();
     t = t0;
     st.n_restarts++;
     // the Jacobian of the restart state first (it does not depend on the step size chosen below): the drift test of the
@@ -279,6 +307,7 @@ struct Solver {
   // to order 1 and rebuild it from f at the current state, keeping the (already reduced) step size -
   // CVODE's strategy after MXNEF1 error-test failures (oracle/bdf.py: _reset_history).
   void reset_history() {
+    flush_accept();
     KIN_HIP(hipMemcpyAsync(ytmp.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
     rhs(ytmp.p, f0.p);
     launch_bdf_init_D(N, BDF_D_ROWS, ytmp.p, f0.p, h_abs, D.p, s);
@@ -300,6 +329,7 @@ struct Solver {
   void resume(bool rates_changed) {
     t = 0.0;
     st.n_restarts++;
+    flush_accept();
     if (rates_changed) {
       KIN_HIP(hipMemcpyAsync(y.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
       eval_jac(y.p);
@@ -506,7 +536,7 @@ struct Solver {
       bool converged = false;
       if (attempt_no++ == inject_bad_pivot_at) KIN_HIP(hipMemsetAsync(&ctrl.p->lu_bad, 1, sizeof(int), s));
       if (force_jac_refresh) {
-        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+        predict();
         eval_jac(y.p);
         jac_current = true;
         force_jac_refresh = false;
@@ -520,7 +550,7 @@ struct Solver {
         if (hit >= 0 && !force_fresh_lu) { cur_slot = hit; lu.slots[hit].last_use = ++use_clock; st.n_lu_reused++; }
         else {
           if (force_fresh_lu && !jac_current && steps_since_jac > 20) {   // an old Jacobian is refreshed on the way
-            launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+            predict();
             eval_jac(y.p);
             jac_current = true;
           }
@@ -536,7 +566,7 @@ struct Solver {
       for (;;) {
         // a matrix made in this attempt for this c counts as fresh even when the Jacobian behind it is a few steps old
         slot_is_fresh = fresh || lu.slots[cur_slot].c_fact == c;
-        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+        predict();
         newton_iteration(0, c);
         newton_iteration(1, c);
         launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
@@ -570,7 +600,7 @@ struct Solver {
           // slot is refreshed: Jacobian at the predictor (if not current), factorisation at this c, one retry
           if (fresh) break;
           if (!jac_current) {
-            launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+            predict();
             eval_jac(y.p);
             jac_current = true;
           }
@@ -579,7 +609,7 @@ struct Solver {
           continue;
         }
         if (jac_current) break;
-        launch_bdf_predict(N, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, s);
+        predict();
         eval_jac(y.p);
         jac_current = true;
         factor_into(0, c);
@@ -621,7 +651,7 @@ struct Solver {
     fail_score = std::max(0.0, fail_score - 0.2);
     n_equal++;
     t = t_new;
-    launch_bdf_accept(N, order, D.p, d.p, s);
+    accept_pending = true; accept_order = order; accept_copy = nullptr;   // rides in the next predictor launch
     jac_current = false;
     pending_order_change = (n_equal >= order + 1);
     if (pending_order_change) {
@@ -680,6 +710,7 @@ struct Solver {
       launch_rk_combine(N, 7, w, rk_yold.p, rk_K.p, out, s);
       return;
     }
+    flush_accept();
     BdfVec p;
     double prod = 1.0;
     for (int j = 0; j < order; j++) {
@@ -955,14 +986,14 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
               }
             } else {
               sb.reserve(h->n_saved + 1);
-              KIN_HIP(hipMemcpyAsync(sb.row(h->n_saved), S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+              S.save_state(sb.row(h->n_saved));
               sb.push_time(t_abs + shift);
             }
             S.select_order();
           }
           if (failed) break;
           // state at the segment end = D[0]
-          KIN_HIP(hipMemcpyAsync(S.y.p, S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+          KIN_HIP(hipMemcpyAsync(S.y.p, S.state_ptr(), N * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         t_seg = seg_end;
         if (ends_at_stop) { apply_rates(h, T_stops, have_table, stop_i); rates_in_force = stop_i; stop_i++; rates_changed = true; }
@@ -1137,7 +1168,7 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
     S.select_order();
     taken++;
     if (S.t >= seg_len) {   // segment finished: state = D[0]; switch the rates at a tstop
-      KIN_HIP(hipMemcpyAsync(S.y.p, S.D.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+      KIN_HIP(hipMemcpyAsync(S.y.p, S.state_ptr(), N * sizeof(double), hipMemcpyDeviceToDevice, s));
       I.t_seg = I.seg_end;
       I.in_segment = false;
       S.t = 0.0;
@@ -1154,6 +1185,7 @@ void integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, ki
   IntegratorState& I = *h->integ;
   if (t) *t = I.in_segment ? I.t_seg + S.t : I.t_seg;
   if (u) {
+    if (I.in_segment) S.flush_accept();
     (I.in_segment ? S.D : S.y).download(u, h->host.N, h->stream);   // D[0] = state after the last accepted step
     KIN_HIP(hipStreamSynchronize(h->stream));
   }

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const 
   }
 }
 
-__global__ __launch_bounds__(256) void bdf_accept_kernel(int N, int order, double* __restrict__ D, const double* __restrict__ d) {
+__global__ __launch_bounds__(256) void bdf_accept_kernel(int N, int order, double* __restrict__ D, const double* __restrict__ d,
+                                                         double* __restrict__ copy_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const double di = d[i];
@@ -594,6 +595,52 @@ __global__ __launch_bounds__(256) void bdf_accept_kernel(int N, int order, doubl
     carry += D[(size_t)j * N + i];
     D[(size_t)j * N + i] = carry;
   }
+  if (copy_out) copy_out[i] = carry;     // the new state D[0]
+}
+
+// The accept of the previous step and the predictor of the next one in one pass over the columns of D (the host defers
+// the accept until it knows what follows it; when a step-size change or a dense-output save comes first, the plain
+// accept kernel runs instead). `ao` = order of the accepted step, `order` = order of the step being predicted.
+__global__ __launch_bounds__(256) void bdf_accept_predict_kernel(int N, int ao, int order, double* __restrict__ D, BdfCoef cf,
+                                                                 double atol, double rtol, double* __restrict__ y,
+                                                                 double* __restrict__ psi, double* __restrict__ d,
+                                                                 double* __restrict__ scale, BdfCtrl* ctrl,
+                                                                 double* __restrict__ copy_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    ctrl->newton_done = 0; ctrl->converged = 0; ctrl->n_iter = 0; ctrl->nonfinite = 0; ctrl->any_negative = 0; ctrl->ticket = 0;
+    ctrl->dy_norm_old = 0.0; ctrl->dy_norm = 0.0; ctrl->err_norm = 0.0; ctrl->err_m_norm = 0.0; ctrl->err_p_norm = 0.0;
+  }
+  if (i >= N) return;
+  double col[BDF_D_ROWS];
+  const double di = d[i];
+#pragma unroll
+  for (int j = 0; j < BDF_D_ROWS; j++) col[j] = j <= ao + 1 ? D[(size_t)j * N + i] : 0.0;
+  // accept (bdf_accept_kernel)
+#pragma unroll
+  for (int j = BDF_D_ROWS - 1; j >= 1; j--) {
+    if (j == ao + 2) col[j] = di - col[j - 1];
+  }
+#pragma unroll
+  for (int j = 0; j < BDF_D_ROWS; j++) if (j == ao + 1) col[j] = di;
+  double carry = di;
+#pragma unroll
+  for (int j = BDF_D_ROWS - 1; j >= 0; j--) {
+    if (j <= ao) { carry += col[j]; col[j] = carry; }
+  }
+#pragma unroll
+  for (int j = 0; j < BDF_D_ROWS; j++) if (j <= ao + 2) D[(size_t)j * N + i] = col[j];
+  if (copy_out) copy_out[i] = col[0];
+  // predict (bdf_predict_kernel), order <= ao + 1
+  double yp = col[0], ps = 0.0;
+#pragma unroll
+  for (int j = 1; j < BDF_D_ROWS; j++) {
+    if (j <= order) { yp += col[j]; ps += col[j] * cf.gamma[j]; }
+  }
+  y[i] = yp;
+  psi[i] = ps / cf.alpha[order];
+  d[i] = 0.0;
+  scale[i] = atol + rtol * fabs(yp);
 }
 
 // D[0..order] <- (R U)^T D[0..order]   (step-size change by `factor`, matrix built on the host)
@@ -759,8 +806,12 @@ void launch_bdf_error(int N, int order, const double* D, const double* y, const 
   hipLaunchKernelGGL(bdf_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl, part,
                      host_ctrl, host_seq, seq);
 }
-void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d);
+void launch_bdf_accept_predict(int N, int ao, int order, double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
+                               double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_accept_predict_kernel, GRID1(N), 0, s, N, ao, order, D, cf, atol, rtol, y, psi, d, scale, ctrl, copy_out);
+}
+void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d, copy_out);
 }
 void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s) {
   hipLaunchKernelGGL(bdf_change_D_kernel, GRID1(N), 0, s, N, order, ru, D);

@@ -43,7 +43,10 @@ void launch_bdf_error(int N, int order, const double* D, const double* y, const 
                       unsigned long long seq, hipStream_t s);   // host_ctrl / host_seq: device-visible pinned host memory (or null)
 // `part`: 5 * bdf_reduce_blocks(N) doubles of partial sums shared by the two reductions above
 int bdf_reduce_blocks(int N);
-void launch_bdf_accept(int N, int order, double* D, const double* d, hipStream_t s);
+void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s);   // copy_out (optional): the new state
+// accept of the previous step (order `ao`) + predictor of the next one in one pass (the host defers the accept)
+void launch_bdf_accept_predict(int N, int ao, int order, double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
+                               double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s);
 void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s);
 void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, double h, double* D, hipStream_t s);
 void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s);
