@@ -529,6 +529,7 @@ void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipSt
   }
   if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, bad, s);
   q.c_fact = c;
+  q.crate = 1.0;
   q.valid = true;
 }
 

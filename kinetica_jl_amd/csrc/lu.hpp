@@ -51,6 +51,8 @@ struct SparseLU {
     DevBuf<double> jd;                      // diag(J) of the Jacobian behind this factorisation (drift test of the LU cache)
     const double* sinv = nullptr;           // where the inverse of the Schur block ended up (inside W or S2)
     double c_fact = 0.0;
+    double crate = 1.0;                     // contraction rate this factorisation has shown in the corrector (1 = unknown; CVODE's crate)
+    int64_t crate_step = 0, crate_restart = -1;   // accepted-step / restart counters when that rate was last MEASURED
     int64_t last_use = 0;
     int64_t jac_stamp = 0;                  // restart counter at the time the Jacobian behind this factorisation was evaluated
     int64_t step_stamp = 0;                 // accepted-step counter at that time

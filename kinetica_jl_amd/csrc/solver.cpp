@@ -110,6 +110,10 @@ struct Solver {
       size_t budget_mb = 32768;
       if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
       if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
+      if (const char* e = getenv("KIN_CARRY_RATE")) carry_rate = atoi(e) != 0;
+      if (const char* e = getenv("KIN_CRATE_AGE")) crate_max_age = atoll(e);
+      if (const char* e = getenv("KIN_CRATE_TOL")) crate_tol_factor = atof(e);
+      if (const char* e = getenv("KIN_CRATE_DYMAX")) crate_dy_max = atof(e);
       if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
       if (const char* e = getenv("KIN_LU_DRIFT")) lu_drift_max = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
@@ -337,6 +341,22 @@ struct Solver {
     }
   }
 
+  // CVODE's carried convergence rate (KIN_CARRY_RATE=0 switches it off): each factorisation remembers the contraction its
+  // corrector iterations have shown, and the first iteration of a step is judged with it (solver_kernels.hip)
+  bool carry_rate = true;
+  // The remembered rate is trusted for `crate_max_age` accepted steps after it was last measured and never across a
+  // restart (new rates, new Jacobian): CVODE resets crate at every linear-solver setup, i.e. at least every 20 steps,
+  // with a Jacobian at most 50 steps old. Without a bound a slot whose contraction has degraded is never found out -
+  // one-iteration steps measure nothing - and the unconverged iterates pile up in the difference history until the
+  // error test collapses the step size (seen on the first segment of the C4 ramp).
+  int64_t crate_max_age = 10;
+  double crate_tol_factor = 1.0;   // KIN_CRATE_TOL: the first-iteration test asks for this fraction of the corrector tolerance
+  // is the slot's remembered rate fresh enough for the first-iteration test? (it keeps being carried and updated either way)
+  bool crate_fresh(const SparseLU::Slot& q) const {
+    return carry_rate && q.crate < 1.0 && q.crate_restart == st.n_restarts && st.n_steps - q.crate_step <= crate_max_age;
+  }
+  double crate_dy_max = 1.0;       // KIN_CRATE_DYMAX: a first correction larger than this (in error-weight units) always gets a second iteration
+  int last_iters = 0, last_iter_slot = -1;
   double reuse_rate_max = 0.2;   // KIN_LU_RATE_MAX: slowest contraction accepted from a reused factorisation (0.1: 12 % slower on C3,
                                  // 0.5: 17 % slower on the C4 ramp - slow contractions leave iteration error in the error estimates)
   // KIN_LU_MAX_AGE: a slot is offered for that many restarts after its Jacobian was evaluated. Unlimited reuse is
@@ -371,7 +391,8 @@ struct Solver {
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
     const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
     launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd,
-                      (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, ctrl.p, red.p, s);
+                      (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, carry_rate ? q.crate : 1.0, crate_fresh(q) ? newton_tol * crate_tol_factor : -1.0, crate_dy_max,
+                      ctrl.p, red.p, s);
     st.n_rhs++; st.n_linsolve++;
   }
 
@@ -567,16 +588,25 @@ struct Solver {
         // a matrix made in this attempt for this c counts as fresh even when the Jacobian behind it is a few steps old
         slot_is_fresh = fresh || lu.slots[cur_slot].c_fact == c;
         predict();
-        newton_iteration(0, c);
-        newton_iteration(1, c);
+        // Blind depth: two iterations are enqueued ahead of the decision, one when this factorisation converged the previous
+        // step in its first iteration (the carried rate makes that the common case; the second launch chain would be
+        // six no-ops). Whatever is not decided when the host looks gets up to two more iterations per hand-over.
+        int it = 0;
+        const int blind = (last_iters == 1 && last_iter_slot == cur_slot && crate_fresh(lu.slots[cur_slot])) ? 1 : 2;
+        for (int b = 0; b < blind; b++) newton_iteration(it++, c);
         launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
         wait_ctrl(seq_no);
-        if (!hc->newton_done) {
-          newton_iteration(2, c);
-          newton_iteration(3, c);
+        while (!hc->newton_done && it < BDF_NEWTON_MAXITER) {
+          for (int b = 0; b < 2 && it < BDF_NEWTON_MAXITER; b++) newton_iteration(it++, c);
           launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
           wait_ctrl(seq_no);
         }
+        if (hc->n_iter > 1) {        // a rate was measured in this attempt
+          SparseLU::Slot& q = lu.slots[cur_slot];
+          q.crate = hc->crate; q.crate_step = st.n_steps; q.crate_restart = st.n_restarts;
+        }
+        last_iters = (hc->newton_done && hc->converged) ? hc->n_iter : 0;
+        last_iter_slot = cur_slot;
         converged = hc->newton_done && hc->converged && !hc->nonfinite;
         if (trace)
           fprintf(stderr, "[trace] t=%.6e h=%.3e order=%d c=%.3e slot=%d c_fact=%.3e fresh=%d jac_cur=%d -> done=%d conv=%d iters=%d dy=%.3e err=%.3e nonfinite=%d lu_bad=%d\n",

@@ -449,7 +449,8 @@ __device__ __forceinline__ double sum_partials(const double* part, int n) {
 __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
                                                          const double* __restrict__ W, const double* __restrict__ scale,
                                                          double* __restrict__ y, double* __restrict__ d, double upd,
-                                                         double rate_max, BdfCtrl* ctrl, double* __restrict__ part) {
+                                                         double rate_max, double crate0, double tol_first, double dy_first_max, BdfCtrl* ctrl,
+                                                         double* __restrict__ part) {
   __shared__ double sh[4];
   __shared__ int last;
   if (ctrl->newton_done) return;
@@ -488,6 +489,12 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     const bool nonfinite = !isfinite(tot);
     const bool have_rate = iter > 0;
     const double rate = have_rate ? dy_norm / old : 0.0;
+    // CVODE's carried convergence rate: every factorisation keeps the contraction it has shown (crate <- max(0.3 crate,
+    // rate) after each iteration with a rate; 1 = unknown, set by the host when the factorisation is made). It lets the
+    // FIRST iteration of a step be judged like the later ones instead of always being followed by a second one.
+    double crate = iter == 0 ? crate0 : ctrl->crate;
+    if (have_rate && !nonfinite) crate = fmax(0.3 * crate, rate);
+    ctrl->crate = crate;
     bool diverged = nonfinite;
     // rate_max < 1 (a reused factorisation): a contraction slower than that means the matrix no longer matches the
     // Jacobian well enough for the error of the iteration to be judged from two or three corrections
@@ -499,7 +506,8 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     ctrl->n_iter = iter + 1;
     ctrl->dy_norm = dy_norm;
     if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nonfinite; }
-    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) || (!have_rate && dy_norm < tol)) {
+    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) ||
+             (!have_rate && (dy_norm < tol || (crate0 < 1.0 && dy_norm <= dy_first_max && crate0 / (1.0 - crate0) * dy_norm < tol_first)))) {
       ctrl->newton_done = 1; ctrl->converged = 1;   // (first-iteration acceptance as in ode15s / CVODE)
     }
     else {
@@ -797,8 +805,9 @@ void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, do
 }
 int bdf_reduce_blocks(int N) { return (int)ceil_div(N, RED_ELEMS); }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, double upd, double rate_max, BdfCtrl* ctrl, double* part, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, rate_max, ctrl, part);
+                       double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max, BdfCtrl* ctrl,
+                       double* part, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, rate_max, crate0, tol_first, dy_first_max, ctrl, part);
 }
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
                       const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,

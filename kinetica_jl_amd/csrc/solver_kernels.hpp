@@ -21,6 +21,8 @@ struct RkVec { double v[7]; };   // per-stage weights of the explicit Dormand-Pr
 struct BdfCtrl {
   double dy_norm_old, dy_norm;
   double err_norm, err_m_norm, err_p_norm;
+  double crate;        // contraction rate carried by the factorisation in use (CVODE's crate): set from the host's per-slot copy
+                       // at iteration 0, updated by every later iteration, read back by the host with the step's result
   double scratch[3];
   int newton_done, converged, n_iter, nonfinite, any_negative;
   int ticket;   // arrival counter of the multi-workgroup reductions (back to 0 when a launch ends)
@@ -37,7 +39,9 @@ void launch_slot_drift(int N, int n_slots, const double* jv, const int32_t* j_di
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
                         double* d, double* scale, BdfCtrl* ctrl, hipStream_t s);   // also clears *ctrl
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, double upd, double rate_max, BdfCtrl* ctrl, double* part, hipStream_t s);   // dy = upd * x
+                       double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max, BdfCtrl* ctrl,
+                       double* part, hipStream_t s);   // dy = upd * x; crate0: carried rate; its first-iteration test needs the estimated
+                                                       // remaining error below tol_first (< 0: test off) and dy_norm <= dy_first_max
 void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
                       const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
                       unsigned long long seq, hipStream_t s);   // host_ctrl / host_seq: device-visible pinned host memory (or null)

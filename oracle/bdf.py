@@ -89,7 +89,12 @@ class OracleBDF:
         self.force_fresh_lu = False
         self.steps_since_jac = 0
         self.slot_is_fresh = True
-        self.slots = []          # dicts: c_fact, LU, last_use
+        self.slots = []          # dicts: c_fact, LU, last_use, crate, ...
+        self.cur_crate = 1.0
+        self.crate_fresh = False
+        self.nc_crate, self.nc_crate_step, self.nc_crate_restart = 1.0, 0, -1     # the single factorisation of the cache-less mode
+        self.crate_max_age = 10  # accepted steps a measured rate is trusted for (and never across a restart)
+        self.crate_dy_max = 1.0  # a first correction larger than this always gets a second iteration
         self.use_clock = 0
         self.c_fact = 0.0
         self.fun, self.jac, self.n = fun, jac, n
@@ -147,6 +152,8 @@ class OracleBDF:
                 sl = min(self.slots, key=lambda q: q["last_use"])
         sl["LU"] = self._factor(c)
         sl["c_fact"] = c
+        sl["crate"] = 1.0               # contraction rate this factorisation has shown (CVODE's crate; 1 = unknown)
+        sl["crate_step"], sl["crate_restart"] = 0, -1     # when that rate was last measured
         sl["jd"] = self.J.diagonal().copy()
         sl["jac_stamp"] = self.jac_stamp_now
         sl["step_stamp"] = self.stats["n_steps"] - self.steps_since_jac
@@ -175,7 +182,11 @@ class OracleBDF:
         while True:
             self.LU, self.c_fact = sl["LU"], sl["c_fact"]
             self.slot_is_fresh = fresh or sl["c_fact"] == c
+            self.cur_crate = sl["crate"]
+            self.crate_fresh = self._crate_fresh(sl["crate"], sl["crate_step"], sl["crate_restart"])
             converged, n_iter, y_new, d = self._newton(y_pred, c, psi, scale)
+            if n_iter > 1:                  # a rate was measured
+                sl["crate"], sl["crate_step"], sl["crate_restart"] = self.cur_crate, self.stats["n_steps"], self.stats["n_restarts"]
             if converged:
                 if not fresh and n_iter >= NEWTON_MAXITER:
                     self.slots = [q for q in self.slots if q is not sl]          # too stale to be offered again
@@ -190,6 +201,12 @@ class OracleBDF:
                 self.jac_stamp_now = self.stats["n_restarts"]
             self._factor_into(sl, c)
             fresh = True
+
+    def _crate_fresh(self, crate, step, restart):
+        """May the remembered rate decide a step after ONE iteration? Only when it was measured in this restart segment and
+        at most crate_max_age accepted steps ago (Solver::crate_fresh, solver.cpp)."""
+        return (not self.scipy_newton) and crate < 1.0 and restart == self.stats["n_restarts"] and \
+            self.stats["n_steps"] - step <= self.crate_max_age
 
     def _factor(self, c):
         self.stats["n_factor"] += 1
@@ -316,7 +333,12 @@ class OracleBDF:
                 if self.LU is None:
                     self.LU = self._factor(c)
                     self.c_fact = c
+                    self.nc_crate, self.nc_crate_step, self.nc_crate_restart = 1.0, 0, -1
+                self.cur_crate = self.nc_crate
+                self.crate_fresh = self._crate_fresh(self.nc_crate, self.nc_crate_step, self.nc_crate_restart)
                 converged, n_iter, y_new, d = self._newton(y_pred, c, psi, scale)
+                if n_iter > 1:
+                    self.nc_crate, self.nc_crate_step, self.nc_crate_restart = self.cur_crate, self.stats["n_steps"], self.stats["n_restarts"]
                 if converged:
                     break
                 self.stats["n_newton_fail"] += 1
@@ -379,6 +401,10 @@ class OracleBDF:
         # a factorisation made for another c (cache hit, or kept across an error-test rejection): update scaled by
         # 2 / (1 + c / c_fact)
         upd = 2.0 / (1.0 + c / self.c_fact) if (self.c_fact != c and not self.scipy_newton) else 1.0
+        # CVODE's carried convergence rate (cvNlsConvTest: crate <- max(CRDOWN crate, del / delp), CRDOWN = 0.3, reset to 1
+        # by every linear-solver setup): each factorisation keeps the contraction its iterations have shown, and the FIRST
+        # iteration of a step is judged with it, like the later ones are with the rate measured inside the step
+        crate0 = crate = self.cur_crate
         for k in range(NEWTON_MAXITER):
             f = self._f(y)
             dy = self._lusolve(self.LU, c * f - psi - d)
@@ -388,16 +414,21 @@ class OracleBDF:
                 break
             dy_norm = rms(dy / scale)
             rate = None if dy_norm_old is None else dy_norm / dy_norm_old
+            if rate is not None and np.isfinite(dy_norm):
+                crate = max(0.3 * crate, rate)
             rate_max = self.lu_rate_max if (self.lu_band > 0 and not self.cache_suspended and not self.slot_is_fresh) else 1.0
             if rate is not None and (rate >= rate_max or rate ** (NEWTON_MAXITER - k) / (1 - rate) * dy_norm > self.newton_tol):
                 break
             y += dy
             d += dy
             if dy_norm == 0 or (rate is not None and rate / (1 - rate) * dy_norm < self.newton_tol) or \
-                    (rate is None and not self.scipy_newton and dy_norm < self.newton_tol):
+                    (rate is None and not self.scipy_newton and
+                     (dy_norm < self.newton_tol or (self.crate_fresh and crate0 < 1.0 and dy_norm <= self.crate_dy_max and
+                                                    crate0 / (1.0 - crate0) * dy_norm < self.newton_tol))):
                 converged = True
                 break
             dy_norm_old = dy_norm
+        self.cur_crate = crate
         return converged, k + 1, y, d
 
     def select_order(self):

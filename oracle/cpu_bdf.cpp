@@ -420,7 +420,7 @@ struct Bdf {
   bool force_fresh_lu = false, slot_is_fresh = true;
   int64_t steps_since_jac = 0;
   int lu_cache = 0;
-  struct Slot { double c_fact = 0.0; int64_t last_use = 0, jac_stamp = 0; std::vector<double> Lx, Ux, Udiag, jd; };
+  struct Slot { double c_fact = 0.0, crate = 1.0; int64_t crate_step = 0, crate_restart = -1; int64_t last_use = 0, jac_stamp = 0; std::vector<double> Lx, Ux, Udiag, jd; };
   int64_t lu_max_age = 50, jac_stamp_now = 0;
   double lu_drift_max = 0.25;                   // drift guard: see Solver::restart (solver.cpp)   // restarts a slot stays on offer after its Jacobian was evaluated
   bool cache_suspended = false;                // a tolerance retry runs its chunk without the cache
@@ -490,7 +490,14 @@ struct Bdf {
   }
   double GAMMA[7], ALPHA[7], ERRC[7];
   std::vector<double> D, y, ypred, psi, d, scale, f, rhsv, dy, J, M, work, tmp;
-  double t = 0, h_abs = 0, c_fact = 0;
+  double t = 0, h_abs = 0, c_fact = 0, cur_crate = 1.0;
+  // carried convergence rate: validity of the first-iteration test (Solver::crate_fresh, solver.cpp) and the cache-less mode's copy
+  bool crate_is_fresh = false;
+  int64_t crate_max_age = 10, nc_crate_step = 0, nc_crate_restart = -1;
+  double crate_dy_max = 1.0;
+  bool crate_fresh(double crate, int64_t step, int64_t restart) const {
+    return crate < 1.0 && restart == st.n_restarts && st.n_steps - step <= crate_max_age;
+  }
   int order = 1, n_equal = 0;
   bool lu_valid = false, jac_current = false, have_pending = false;
   double pend[4] = {0, 0, 0, 0};
@@ -555,6 +562,7 @@ struct Bdf {
     st.n_factor++;
     if (getenv("CPUB_TRACE")) fprintf(stderr, "[factor] t=%.3e h=%.3e order=%d c=%.3e c_prev=%.3e steps=%lld\n", t, h_abs, order, c, c_fact, (long long)st.n_steps);
     c_fact = c;
+    cur_crate = 1.0; nc_crate_step = 0; nc_crate_restart = -1;
     st.t_factor += now_s() - t0;
     return ok;
   }
@@ -602,6 +610,10 @@ struct Bdf {
     // a factorisation made for another c is still used (lu_reuse): the update is scaled by 2 / (1 + c/c_fact), the
     // first-order correction CVODE applies for the changed gamma
     const double upd = (lu_reuse > 0.0 && c_fact != c) ? 2.0 / (1.0 + c / c_fact) : 1.0;
+    // CVODE's carried convergence rate (cvNlsConvTest: crate <- max(0.3 crate, del / delp), reset to 1 by every setup):
+    // every factorisation keeps the contraction its iterations have shown; the first iteration of a step is judged with it
+    const double crate0 = cur_crate;
+    double crate = cur_crate;
     for (kk = 0; kk < NEWTON_MAXITER; kk++) {
       fun(y.data(), f.data());
       for (int64_t i = 0; i < N; i++) rhsv[i] = c * f[i] - psi[i] - d[i];
@@ -614,15 +626,19 @@ struct Bdf {
       const double dy_norm = rms_scaled(dy.data(), scale.data());
       const bool have_rate = dy_norm_old >= 0.0;
       const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
+      if (have_rate && std::isfinite(dy_norm)) crate = std::max(0.3 * crate, rate);
       const double rate_max = (lu_cache > 0 && !cache_suspended && !slot_is_fresh) ? lu_rate_max : 1.0;
       if (have_rate && (rate >= rate_max || std::pow(rate, NEWTON_MAXITER - kk) / (1.0 - rate) * dy_norm > newton_tol)) break;
       for (int64_t i = 0; i < N; i++) { y[i] += dy[i]; d[i] += dy[i]; }
-      if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < newton_tol) || (!have_rate && dy_norm < newton_tol)) {
+      if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < newton_tol) ||
+          (!have_rate && (dy_norm < newton_tol || (crate_is_fresh && crate0 < 1.0 && dy_norm <= crate_dy_max &&
+                                                   crate0 / (1.0 - crate0) * dy_norm < newton_tol)))) {
         converged = true;
         break;
       }
       dy_norm_old = dy_norm;
     }
+    cur_crate = crate;
     n_iter = std::min(kk + 1, NEWTON_MAXITER);
     return converged;
   }
@@ -640,13 +656,16 @@ struct Bdf {
       const int64_t pb = lu.n_full;
       if (!factor(c)) return false;
       if (lu.n_full != pb && pb != 0) { keep_only_active(); i = 0; }
-      slots[i].c_fact = c; slots[i].jac_stamp = jac_stamp_now; slots[i].jd = jac_diag(); fresh = jac_current;
+      slots[i].c_fact = c; slots[i].crate = 1.0; slots[i].crate_step = 0; slots[i].crate_restart = -1; slots[i].jac_stamp = jac_stamp_now; slots[i].jd = jac_diag(); fresh = jac_current;
     }
     force_fresh_lu = false;
     slots[i].last_use = ++use_clock;
     c_fact = slots[i].c_fact;
     slot_is_fresh = fresh || c_fact == c;
+    cur_crate = slots[i].crate;
+    crate_is_fresh = crate_fresh(slots[i].crate, slots[i].crate_step, slots[i].crate_restart);
     bool converged = newton(c, n_iter);
+    if (n_iter > 1) { slots[i].crate = cur_crate; slots[i].crate_step = st.n_steps; slots[i].crate_restart = st.n_restarts; }
     if (converged) {
       if (!fresh && n_iter >= NEWTON_MAXITER) {   // too stale to be offered again
         if (active_slot >= 0) swap_arrays(slots[active_slot]);
@@ -664,7 +683,11 @@ struct Bdf {
     slots[i].c_fact = c; slots[i].last_use = ++use_clock; slots[i].jac_stamp = jac_stamp_now; slots[i].jd = jac_diag();
     c_fact = c;
     slot_is_fresh = true;
+    cur_crate = 1.0;
+    crate_is_fresh = false;
+    slots[i].crate = 1.0; slots[i].crate_step = 0; slots[i].crate_restart = -1;
     converged = newton(c, n_iter);
+    if (n_iter > 1) { slots[i].crate = cur_crate; slots[i].crate_step = st.n_steps; slots[i].crate_restart = st.n_restarts; }
     if (!converged) st.n_newton_fail++;
     return converged;
   }
@@ -708,7 +731,9 @@ struct Bdf {
           if (!factor(c)) { converged = false; break; }
           lu_valid = true; lu_stale = false;
         }
+        crate_is_fresh = crate_fresh(cur_crate, nc_crate_step, nc_crate_restart);
         converged = newton(c, n_iter);
+        if (n_iter > 1) { nc_crate_step = st.n_steps; nc_crate_restart = st.n_restarts; }
         if (converged) break;
         st.n_newton_fail++;
         if (lu_reuse > 0.0 && c_fact != c) {   // the stale factorisation is the first suspect: refactor for this c, same Jacobian

@@ -192,7 +192,9 @@ def test_vanishing_pivot_is_detected_and_answered():
         del os.environ["KIN_INJECT_BAD_PIVOT"]
     assert rc0 == 0 and st0["n_bad_pivot"] == 0
     assert status == capi.KIN_OK and rc == 0 and st["n_bad_pivot"] == 1
-    assert st["n_rejected"] >= 1 and st["n_jac"] >= st0["n_jac"] + 1
+    # (the refreshed Jacobian is counted, but the two runs take different step sequences from there on, so their totals
+    # are not comparable one to one)
+    assert st["n_rejected"] >= 1 and st["n_jac"] >= 2
     # logistic growth of A at constant A + B: closed form. The solution grows 337-fold over the span and local errors grow
     # with it (an unstable direction), hence the wider band than for the decaying test problems
     S_ = u0.sum()
