@@ -378,7 +378,9 @@ struct Solver {
   bool cache_suspended = false;  // a tolerance retry (adaptive_solve!) runs its chunk without the cache
   int64_t jac_stamp_now = 0;     // restart counter at the last Jacobian evaluation
   bool slot_is_fresh = false;
-  void newton_iteration(int it, double c) {
+  // `last`: the batch's last launch publishes the control block even when nothing is decided yet (seq = the number the
+  // host waits for; the launch that decides publishes it itself - there is no separate error-estimate launch)
+  void newton_iteration(int it, double c, unsigned long long seq, bool last) {
     const int* skip = &ctrl.p->newton_done;
     SparseLU::Slot& q = lu.slots[cur_slot];
     SegExtra ex;
@@ -391,8 +393,9 @@ struct Solver {
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
     const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
     launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd,
-                      (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, carry_rate ? q.crate : 1.0, crate_fresh(q) ? newton_tol * crate_tol_factor : -1.0, crate_dy_max,
-                      ctrl.p, red.p, s);
+                      (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, carry_rate ? q.crate : 1.0,
+                      crate_fresh(q) ? newton_tol * crate_tol_factor : -1.0, crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p,
+                      hc_dev, hseq_dev, seq, last, s);
     st.n_rhs++; st.n_linsolve++;
   }
 
@@ -593,12 +596,13 @@ struct Solver {
         // six no-ops). Whatever is not decided when the host looks gets up to two more iterations per hand-over.
         int it = 0;
         const int blind = (last_iters == 1 && last_iter_slot == cur_slot && crate_fresh(lu.slots[cur_slot])) ? 1 : 2;
-        for (int b = 0; b < blind; b++) newton_iteration(it++, c);
-        launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
+        ++seq_no;
+        for (int b = 0; b < blind; b++, it++) newton_iteration(it, c, seq_no, b == blind - 1);
         wait_ctrl(seq_no);
         while (!hc->newton_done && it < BDF_NEWTON_MAXITER) {
-          for (int b = 0; b < 2 && it < BDF_NEWTON_MAXITER; b++) newton_iteration(it++, c);
-          launch_bdf_error(N, order, D.p, y.p, d.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
+          const int more = std::min(2, BDF_NEWTON_MAXITER - it);
+          ++seq_no;
+          for (int b = 0; b < more; b++, it++) newton_iteration(it, c, seq_no, b == more - 1);
           wait_ctrl(seq_no);
         }
         if (hc->n_iter > 1) {        // a rate was measured in this attempt

@@ -443,27 +443,37 @@ __device__ __forceinline__ double sum_partials(const double* part, int n) {
   return t;
 }
 
-// One Newton update: y += dy, d += dy, ||dy||, convergence decision. The update is applied
-// unconditionally: when the decision is "diverged" the attempt is abandoned and y, d are rebuilt by the
-// next predictor, so the stale update is never read.
+// One Newton update: y += dy, d += dy, ||dy||, convergence decision - and, folded in, the step's error estimate: every
+// workgroup also reduces the error-test sums of the state THIS iteration produces, so the workgroup that takes the
+// decision has them at hand when the decision is "converged" and publishes the attempt's result to the host itself
+// (control block into coherent pinned host memory + sequence number the host spins on - no D2H copy, no stream
+// synchronisation, and no separate error-estimate launch behind the corrector: 12 us per step at C3 size). The later
+// launches of a blind-enqueued batch find newton_done set and return; `publish_always` marks the batch's last launch,
+// which publishes "not decided yet" when that is the state. The update is applied unconditionally: when the decision is
+// "diverged" the attempt is abandoned and y, d are rebuilt by the next predictor, so the stale update is never read.
 __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int maxit, double tol, const int32_t* __restrict__ xloc,
                                                          const double* __restrict__ W, const double* __restrict__ scale,
                                                          double* __restrict__ y, double* __restrict__ d, double upd,
-                                                         double rate_max, double crate0, double tol_first, double dy_first_max, BdfCtrl* ctrl,
-                                                         double* __restrict__ part) {
-  __shared__ double sh[4];
+                                                         double rate_max, double crate0, double tol_first, double dy_first_max,
+                                                         int order, const double* __restrict__ D, double atol, double rtol, BdfCoef cf,
+                                                         BdfCtrl* ctrl, double* __restrict__ part, BdfCtrl* host_ctrl,
+                                                         unsigned long long* host_seq, unsigned long long seq, int publish_always) {
+  __shared__ double sh[20];
   __shared__ int last;
   if (ctrl->newton_done) return;
   const int G = gridDim.x;
   // A non-finite update makes the sum of squares non-finite: one reduction carries both the norm and the flag.
-  double s = 0.0;
+  double s = 0.0, se = 0.0, sm = 0.0, sp = 0.0, neg = 0.0;
   const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
-  int32_t xl[4]; double dy[4], sc[4], yy[4], dd[4];
+  int32_t xl[4]; double dy[4], sc[4], yy[4], dd[4], dm[4], dp[4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
     const int i = i0 + 256 * x;
-    xl[x] = i < N ? xloc[i] : -1; sc[x] = i < N ? scale[i] : 1.0;
-    yy[x] = i < N ? y[i] : 0.0; dd[x] = i < N ? d[i] : 0.0;
+    const bool ok = i < N;
+    xl[x] = ok ? xloc[i] : -1; sc[x] = ok ? scale[i] : 1.0;
+    yy[x] = ok ? y[i] : 0.0; dd[x] = ok ? d[i] : 0.0;
+    dm[x] = (ok && order > 1) ? D[(size_t)order * N + i] : 0.0;
+    dp[x] = (ok && order < 5) ? D[(size_t)(order + 1) * N + i] : 0.0;
   }
 #pragma unroll
   for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
@@ -471,15 +481,37 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
   for (int x = 0; x < 4; x++) {
     const double q = dy[x] / sc[x];
     s += q * q;
+    yy[x] += dy[x]; dd[x] += dy[x];
+    if (i0 + 256 * x >= N) continue;
+    // error test of the state after this iteration (a non-finite state makes the sum non-finite)
+    if (yy[x] < 0.0) neg = 1.0;
+    const double sce = atol + rtol * fabs(yy[x]);
+    const double e = cf.error_const[order] * dd[x] / sce;
+    se += e * e + (isfinite(yy[x]) ? 0.0 : INFINITY);
+    if (order > 1) { const double em = cf.error_const[order - 1] * (dm[x] + dd[x]) / sce; sm += em * em; }
+    if (order < 5) { const double ep = cf.error_const[order + 1] * (dd[x] - dp[x]) / sce; sp += ep * ep; }
   }
-  const double ps = block_sum_256(s, sh);
-  if (threadIdx.x == 0) store_partial(part + blockIdx.x, ps);
+  // five sums, one pair of barriers
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_down(s, off, 64); se += __shfl_down(se, off, 64); sm += __shfl_down(sm, off, 64);
+    sp += __shfl_down(sp, off, 64); neg += __shfl_down(neg, off, 64);
+  }
+  {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[5 * w] = s; sh[5 * w + 1] = se; sh[5 * w + 2] = sm; sh[5 * w + 3] = sp; sh[5 * w + 4] = neg; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) store_partial(part + q * G + blockIdx.x, (sh[q] + sh[5 + q]) + (sh[10 + q] + sh[15 + q]));
+  }
   const bool is_last = last_block_arrives(ctrl, &last);
   // the state update is off the critical path of the decision: its stores go out while the ticket travels
 #pragma unroll
   for (int x = 0; x < 4; x++) {
     const int i = i0 + 256 * x;
-    if (i < N) { y[i] = yy[x] + dy[x]; d[i] = dd[x] + dy[x]; }
+    if (i < N) { y[i] = yy[x]; d[i] = dd[x]; }
   }
   if (!is_last) return;
   if (threadIdx.x == 0) {
@@ -505,85 +537,27 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     }
     ctrl->n_iter = iter + 1;
     ctrl->dy_norm = dy_norm;
-    if (diverged) { ctrl->newton_done = 1; ctrl->converged = 0; ctrl->nonfinite = nonfinite; }
+    bool done = true, converged = false;
+    if (diverged) { ctrl->nonfinite = nonfinite; }
     else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) ||
              (!have_rate && (dy_norm < tol || (crate0 < 1.0 && dy_norm <= dy_first_max && crate0 / (1.0 - crate0) * dy_norm < tol_first)))) {
-      ctrl->newton_done = 1; ctrl->converged = 1;   // (first-iteration acceptance as in ode15s / CVODE)
+      converged = true;                             // (first-iteration acceptance as in ode15s / CVODE)
     }
     else {
       ctrl->dy_norm_old = dy_norm;
-      if (iter == maxit - 1) { ctrl->newton_done = 1; ctrl->converged = 0; }
+      done = iter == maxit - 1;
     }
-  }
-}
-
-__global__ __launch_bounds__(256) void bdf_error_kernel(int N, int order, const double* __restrict__ D, const double* __restrict__ y,
-                                                        const double* __restrict__ d, double atol, double rtol, BdfCoef cf,
-                                                        BdfCtrl* ctrl, double* __restrict__ part, BdfCtrl* host_ctrl,
-                                                        unsigned long long* host_seq, unsigned long long seq) {
-  __shared__ double sh[16];
-  __shared__ int last;
-  // The attempt ends with this kernel: its last action publishes the control block straight into pinned host
-  // memory and bumps a sequence number the host spins on - no D2H copy, no stream synchronisation on the
-  // step's critical path (the host falls back to both if the number does not show up).
-  if (!ctrl->newton_done || !ctrl->converged) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && host_ctrl) {
-      *host_ctrl = *ctrl;
-      __threadfence_system();
-      *(volatile unsigned long long*)host_seq = seq;
+    if (converged) {
+      const double te = sum_partials(part + G, G);
+      ctrl->err_norm = sqrt(te / (double)N);
+      ctrl->err_m_norm = sqrt(sum_partials(part + 2 * G, G) / (double)N);
+      ctrl->err_p_norm = sqrt(sum_partials(part + 3 * G, G) / (double)N);
+      ctrl->any_negative = sum_partials(part + 4 * G, G) > 0.0;
+      if (!isfinite(te)) ctrl->nonfinite = 1;
     }
-    return;
-  }
-  const int G = gridDim.x;
-  double se = 0.0, sm = 0.0, sp = 0.0, neg = 0.0;
-  {
-    const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
-    double yi[4], di[4], dm[4], dp[4];
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-      const int i = i0 + 256 * x;
-      const bool ok = i < N;
-      yi[x] = ok ? y[i] : 0.0; di[x] = ok ? d[i] : 0.0;
-      dm[x] = (ok && order > 1) ? D[(size_t)order * N + i] : 0.0;
-      dp[x] = (ok && order < 5) ? D[(size_t)(order + 1) * N + i] : 0.0;
-    }
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-      if (i0 + 256 * x >= N) continue;
-      if (yi[x] < 0.0) neg = 1.0;
-      // a non-finite state makes its scale, hence the sum of squares, non-finite: no separate flag reduction
-      const double sc = atol + rtol * fabs(yi[x]);
-      const double e = cf.error_const[order] * di[x] / sc;
-      se += e * e + (isfinite(yi[x]) ? 0.0 : INFINITY);
-      if (order > 1) { const double em = cf.error_const[order - 1] * (dm[x] + di[x]) / sc; sm += em * em; }
-      if (order < 5) { const double ep = cf.error_const[order + 1] * (di[x] - dp[x]) / sc; sp += ep * ep; }
-    }
-  }
-  // four sums, one pair of barriers
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    se += __shfl_down(se, off, 64); sm += __shfl_down(sm, off, 64); sp += __shfl_down(sp, off, 64); neg += __shfl_down(neg, off, 64);
-  }
-  {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sh[4 * w] = se; sh[4 * w + 1] = sm; sh[4 * w + 2] = sp; sh[4 * w + 3] = neg; }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    store_partial(part + blockIdx.x, (sh[0] + sh[4]) + (sh[8] + sh[12]));
-    store_partial(part + G + blockIdx.x, (sh[1] + sh[5]) + (sh[9] + sh[13]));
-    store_partial(part + 2 * G + blockIdx.x, (sh[2] + sh[6]) + (sh[10] + sh[14]));
-    store_partial(part + 3 * G + blockIdx.x, (sh[3] + sh[7]) + (sh[11] + sh[15]));
-  }
-  if (!last_block_arrives(ctrl, &last)) return;
-  if (threadIdx.x == 0) {
-    const double te = sum_partials(part, G);
-    ctrl->err_norm = sqrt(te / (double)N);
-    ctrl->err_m_norm = sqrt(sum_partials(part + G, G) / (double)N);
-    ctrl->err_p_norm = sqrt(sum_partials(part + 2 * G, G) / (double)N);
-    ctrl->any_negative = sum_partials(part + 3 * G, G) > 0.0;
-    if (!isfinite(te)) ctrl->nonfinite = 1;
-    if (host_ctrl) {
+    ctrl->converged = converged ? 1 : 0;
+    ctrl->newton_done = done ? 1 : 0;
+    if ((done || publish_always) && host_ctrl) {
       *host_ctrl = *ctrl;
       __threadfence_system();
       *(volatile unsigned long long*)host_seq = seq;
@@ -725,7 +699,7 @@ __global__ __launch_bounds__(256) void rk_error_kernel(int N, RkVec e, const dou
     ctrl->err_norm = sqrt(sum_partials(part, G) / (double)N);
     ctrl->any_negative = sum_partials(part + G, G) > 0.0;
     ctrl->nonfinite = sum_partials(part + 2 * G, G) > 0.0 || !isfinite(ctrl->err_norm);
-    if (host_ctrl) {   // step-end hand-over through pinned host memory (see bdf_error_kernel)
+    if (host_ctrl) {   // step-end hand-over through pinned host memory (see bdf_newton_kernel)
       *host_ctrl = *ctrl;
       __threadfence_system();
       *(volatile unsigned long long*)host_seq = seq;
@@ -805,15 +779,11 @@ void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, do
 }
 int bdf_reduce_blocks(int N) { return (int)ceil_div(N, RED_ELEMS); }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max, BdfCtrl* ctrl,
-                       double* part, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, rate_max, crate0, tol_first, dy_first_max, ctrl, part);
-}
-void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
-                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
-                      unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_error_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, order, D, y, d, atol, rtol, cf, ctrl, part,
-                     host_ctrl, host_seq, seq);
+                       double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max,
+                       int order, const double* D, double atol, double rtol, const BdfCoef& cf, BdfCtrl* ctrl, double* part,
+                       BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s) {
+  hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, rate_max,
+                     crate0, tol_first, dy_first_max, order, D, atol, rtol, cf, ctrl, part, host_ctrl, host_seq, seq, publish_always ? 1 : 0);
 }
 void launch_bdf_accept_predict(int N, int ao, int order, double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
                                double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s) {

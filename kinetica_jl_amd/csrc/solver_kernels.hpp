@@ -38,14 +38,15 @@ void launch_slot_drift(int N, int n_slots, const double* jv, const int32_t* j_di
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
                         double* d, double* scale, BdfCtrl* ctrl, hipStream_t s);   // also clears *ctrl
+// One corrector iteration's update + decision + (folded in) the step's error estimate; the launch that decides publishes
+// the control block to host_ctrl / host_seq (device-visible pinned host memory, or null), the batch's last launch
+// (`publish_always`) also when nothing is decided yet. dy = upd * x; crate0: carried rate, whose first-iteration test needs
+// the estimated remaining error below tol_first (< 0: test off) and dy_norm <= dy_first_max.
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
-                       double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max, BdfCtrl* ctrl,
-                       double* part, hipStream_t s);   // dy = upd * x; crate0: carried rate; its first-iteration test needs the estimated
-                                                       // remaining error below tol_first (< 0: test off) and dy_norm <= dy_first_max
-void launch_bdf_error(int N, int order, const double* D, const double* y, const double* d, double atol, double rtol,
-                      const BdfCoef& cf, BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq,
-                      unsigned long long seq, hipStream_t s);   // host_ctrl / host_seq: device-visible pinned host memory (or null)
-// `part`: 5 * bdf_reduce_blocks(N) doubles of partial sums shared by the two reductions above
+                       double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max,
+                       int order, const double* D, double atol, double rtol, const BdfCoef& cf, BdfCtrl* ctrl, double* part,
+                       BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s);
+// `part`: 5 * bdf_reduce_blocks(N) doubles of partial sums
 int bdf_reduce_blocks(int N);
 void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s);   // copy_out (optional): the new state
 // accept of the previous step (order `ao`) + predictor of the next one in one pass (the host defers the accept)
