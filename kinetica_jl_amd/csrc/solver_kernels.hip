@@ -154,55 +154,119 @@ __device__ __forceinline__ double fast_recip(double x) {
   return r;
 }
 
-// 32 dependent elimination steps on a 32x32 block; 256 threads, thread = (row r, 4 consecutive columns) keeps ITS
-// four elements in registers for the whole inversion. Per step only the pivot row (8 threads) and the pivot
-// column (32 threads) go through LDS, double-buffered so that one barrier per step suffices. The inversion of
-// the next pivot block is the critical path of every gj_update_kernel launch (the tile updates take ~10 us,
-// the launch took 18 us with the earlier version that rewrote the whole block image in LDS every step).
-// The block is in A[0] on entry (A[1] provides the row / column buffers); the result goes to `pinv`.
-__device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB][GJ_NB + 1], double* __restrict__ pinv, int* bad) {
-  const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-  double a[4];
+// Inverse of the 32x32 pivot block (the critical path of every gj_update_kernel launch). Two levels: the block is split
+// into 16x16 quarters, inv([[A11, A12], [A21, A22]]) = [[B11, B12], [B21, B22]] with S = A22 - A21 A11^-1 A12,
+//   B22 = S^-1,  B12 = -(A11^-1 A12) B22,  B21 = -B22 (A21 A11^-1),  B11 = A11^-1 - B12 (A21 A11^-1).
+// The two 16x16 inversions are 16 dependent Gauss-Jordan steps each inside ONE wavefront (lane = row r, four consecutive
+// columns in registers; pivot row / column / pivot travel by lane shuffles, no workgroup barrier per step); the six
+// 16x16x16 products in between use all 256 threads (one output element each, operands in LDS). 32 dependent steps either
+// way, but a step costs a few shuffles instead of an LDS round trip plus a workgroup barrier (the one-level version,
+// thread = (row, 4 columns) of the whole block, took ~7 us of each 13 us block step).
+// The block is in A on entry (XS and, once read, A serve as scratch); the result goes to `pinv`.
+__device__ __forceinline__ bool gj_inv16_wave(double (&a)[4], int lane) {
+  const int r = lane >> 2, q = lane & 3;
+  bool vanished = false;
 #pragma unroll
-  for (int j = 0; j < 4; j++) a[j] = A[0][r][c0 + j];
-  double* rowbuf = &A[1][0][0];                 // [2][GJ_NB]
-  double* colbuf = rowbuf + 2 * GJ_NB;          // [2][GJ_NB]
-  bool vanished = false;                        // pivot guard: kept in a register, one store after the loop
-  for (int k = 0; k < GJ_NB; k++) {
-    double* rb = rowbuf + (k & 1) * GJ_NB;
-    double* cb = colbuf + (k & 1) * GJ_NB;
-    if (r == k) {
+  for (int k = 0; k < 16; k++) {
+    // my row's element of the pivot column (it sits in lane 4 r + k / 4, register k % 4), the pivot, the pivot row
+    const double own = a[k & 3];
+    const double aik = __shfl(own, 4 * r + (k >> 2), 64);
+    const double piv = __shfl(own, 4 * k + (k >> 2), 64);
+    double rk[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) rb[c0 + j] = a[j];
-    }
-    if (k >= c0 && k < c0 + 4) {
-      const int jj = k - c0;
-      cb[r] = jj == 0 ? a[0] : (jj == 1 ? a[1] : (jj == 2 ? a[2] : a[3]));
-    }
-    __syncthreads();
-    const double inv = fast_recip(rb[k]);
-    const double aik = cb[r];
+    for (int j = 0; j < 4; j++) rk[j] = __shfl(a[j], 4 * k + q, 64);
+    const double inv = fast_recip(piv);
     // vanished pivot: the multiplier of this row exceeds the growth bound, or the pivot is tiny / 0 / not finite
-    vanished |= (r != k) ? (aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) : !(fabs(rb[k]) >= PIVOT_MIN);
+    vanished |= (r != k) ? (aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) : !(fabs(piv) >= PIVOT_MIN);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const bool kc = (c0 + j == k);
-      const double rk = (kc ? 1.0 : rb[c0 + j]) * inv;
-      a[j] = (r == k) ? rk : (kc ? 0.0 : a[j]) - aik * rk;
+      const bool kc = (4 * q + j == k);
+      const double rkj = (kc ? 1.0 : rk[j]) * inv;
+      a[j] = (r == k) ? rkj : (kc ? 0.0 : a[j]) - aik * rkj;
     }
   }
+  return vanished;
+}
+
+constexpr int GJ_XS = 4 * (GJ_NB / 2) * (GJ_NB / 2 + 1);     // scratch doubles of gj_invert_block_lds
+__device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB + 1], double* __restrict__ XS, double* __restrict__ pinv, int* bad) {
+  constexpr int H = GJ_NB / 2, LDX = H + 1;
+  double* X0 = XS;                     // A11^-1
+  double* X1 = X0 + H * LDX;           // T = A21 A11^-1
+  double* X2 = X1 + H * LDX;           // U = A11^-1 A12
+  double* X3 = X2 + H * LDX;           // S, then B22
+  const int t = threadIdx.x, lane = t & 63;
+  const int i = t >> 4, j = t & 15;
+  bool vanished = false;
+  if (t < 64) {
+    const int r = lane >> 2, c0 = (lane & 3) * 4;
+    double a[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) pinv[r * GJ_NB + c0 + j] = a[j];
+    for (int x = 0; x < 4; x++) a[x] = A[r][c0 + x];
+    vanished |= gj_inv16_wave(a, lane);
+#pragma unroll
+    for (int x = 0; x < 4; x++) X0[r * LDX + c0 + x] = a[x];
+  }
+  __syncthreads();
+  {
+    double tt = 0.0, uu = 0.0;
+#pragma unroll
+    for (int k = 0; k < H; k++) {
+      tt += A[H + i][k] * X0[k * LDX + j];
+      uu += X0[i * LDX + k] * A[k][H + j];
+    }
+    X1[i * LDX + j] = tt;
+    X2[i * LDX + j] = uu;
+  }
+  __syncthreads();
+  {
+    double ss = A[H + i][H + j];
+#pragma unroll
+    for (int k = 0; k < H; k++) ss -= X1[i * LDX + k] * A[k][H + j];
+    X3[i * LDX + j] = ss;
+  }
+  __syncthreads();
+  if (t < 64) {
+    const int r = lane >> 2, c0 = (lane & 3) * 4;
+    double a[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) a[x] = X3[r * LDX + c0 + x];
+    vanished |= gj_inv16_wave(a, lane);
+#pragma unroll
+    for (int x = 0; x < 4; x++) X3[r * LDX + c0 + x] = a[x];
+  }
+  __syncthreads();
+  double* Y = &A[0][0];                // B12 (the input block is not needed any more)
+  {
+    double b21 = 0.0, b12 = 0.0;
+#pragma unroll
+    for (int k = 0; k < H; k++) {
+      b21 -= X3[i * LDX + k] * X1[k * LDX + j];
+      b12 -= X2[i * LDX + k] * X3[k * LDX + j];
+    }
+    Y[i * LDX + j] = b12;
+    pinv[(H + i) * GJ_NB + j] = b21;
+    pinv[i * GJ_NB + H + j] = b12;
+    pinv[(H + i) * GJ_NB + H + j] = X3[i * LDX + j];
+  }
+  __syncthreads();
+  {
+    double b11 = X0[i * LDX + j];
+#pragma unroll
+    for (int k = 0; k < H; k++) b11 -= Y[i * LDX + k] * X1[k * LDX + j];
+    pinv[i * GJ_NB + j] = b11;
+  }
   if (bad && vanished) *bad = 1;                // benign race: every writer stores the same value
 }
 
 __global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv, int* bad) {
-  __shared__ double A[2][GJ_NB][GJ_NB + 1];
+  __shared__ double A[GJ_NB][GJ_NB + 1];
+  __shared__ double XS[GJ_XS];
   const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
 #pragma unroll
-  for (int j = 0; j < 4; j++) A[0][r][c0 + j] = X[(size_t)(kb * GJ_NB + r) * ld + kb * GJ_NB + c0 + j];
+  for (int j = 0; j < 4; j++) A[r][c0 + j] = X[(size_t)(kb * GJ_NB + r) * ld + kb * GJ_NB + c0 + j];
   __syncthreads();
-  gj_invert_block_lds(A, pinv, bad);
+  gj_invert_block_lds(A, XS, pinv, bad);
 }
 
 // grid = (mpad/64, 1 + mpad/64): block row 0 (dispatched first) holds ONE active workgroup (blockIdx.x == 0) that
@@ -212,7 +276,8 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
                                                         int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next,
                                                         int* bad) {
   __shared__ double RP[GJ_NB][64 + 2];                 // row panel slice of this tile's columns
-  __shared__ double A[2][GJ_NB][GJ_NB + 1];            // look-ahead workgroup only
+  __shared__ double A[GJ_NB][GJ_NB + 1];               // look-ahead workgroup only
+  __shared__ double XS[GJ_XS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int kr0 = kb * GJ_NB, kr1 = kr0 + GJ_NB;
@@ -245,10 +310,10 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], RP[4 * ks + lk][16 * cb + li], acc, 0, 0, 0);
 #pragma unroll
-      for (int v = 0; v < 4; v++) A[0][16 * rb + 4 * v + lk][16 * cb + li] = xd[v] - acc[v];
+      for (int v = 0; v < 4; v++) A[16 * rb + 4 * v + lk][16 * cb + li] = xd[v] - acc[v];
     }
     __syncthreads();
-    gj_invert_block_lds(A, pinv_next, bad);
+    gj_invert_block_lds(A, XS, pinv_next, bad);
     return;
   }
   const int r0 = (blockIdx.y - 1) * 64 + 16 * w, c0 = blockIdx.x * 64;
