@@ -317,6 +317,16 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
     return;
   }
   const int r0 = (blockIdx.y - 1) * 64 + 16 * w, c0 = blockIdx.x * 64;
+  const bool pivot_rows = (r0 >= kr0 && r0 < kr1);
+  // every global operand of the tile is requested up front - the pivot-column panel `a` and the old tile values `xo` do
+  // not depend on the row panel, and behind the barrier they would be a second round of load latency
+  double a[8], xo[4][4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) a[ks] = X[(size_t)(r0 + li) * ld + kr0 + 4 * ks + lk];
+#pragma unroll
+  for (int blk = 0; blk < 4; blk++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) xo[blk][v] = X[(size_t)(r0 + 4 * v + lk) * ld + c0 + 16 * blk + li];
   // ---- row panel: wave w forms columns 16w..16w+15 (two 16-row blocks), RP = P * X[k rows, cols]
   {
     const int jc = c0 + 16 * w + li;
@@ -341,10 +351,6 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
   }
   __syncthreads();
   // ---- rank-32 update of this wave's 16 rows x 64 columns
-  const bool pivot_rows = (r0 >= kr0 && r0 < kr1);
-  double a[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ks++) a[ks] = X[(size_t)(r0 + li) * ld + kr0 + 4 * ks + lk];
 #pragma unroll
   for (int blk = 0; blk < 4; blk++) {
     gj_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
       const size_t off = (size_t)i * ld + j;
       if (pivot_rows) Y[off] = RP[i - kr0][16 * blk + li];
       else if (pivot_col) Y[off] = -acc[v];
-      else Y[off] = X[off] - acc[v];
+      else Y[off] = xo[blk][v] - acc[v];
     }
   }
 }
