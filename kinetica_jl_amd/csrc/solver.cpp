@@ -112,7 +112,6 @@ struct Solver {
       if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
       if (const char* e = getenv("KIN_CARRY_RATE")) carry_rate = atoi(e) != 0;
       if (const char* e = getenv("KIN_CRATE_AGE")) crate_max_age = atoll(e);
-      if (const char* e = getenv("KIN_CRATE_TOL")) crate_tol_factor = atof(e);
       if (const char* e = getenv("KIN_CRATE_DYMAX")) crate_dy_max = atof(e);
       if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
       if (const char* e = getenv("KIN_LU_DRIFT")) lu_drift_max = atof(e);
@@ -350,7 +349,6 @@ struct Solver {
   // one-iteration steps measure nothing - and the unconverged iterates pile up in the difference history until the
   // error test collapses the step size (seen on the first segment of the C4 ramp).
   int64_t crate_max_age = 10;
-  double crate_tol_factor = 1.0;   // KIN_CRATE_TOL: the first-iteration test asks for this fraction of the corrector tolerance
   // is the slot's remembered rate fresh enough for the first-iteration test? (it keeps being carried and updated either way)
   bool crate_fresh(const SparseLU::Slot& q) const {
     return carry_rate && q.crate < 1.0 && q.crate_restart == st.n_restarts && st.n_steps - q.crate_step <= crate_max_age;
@@ -394,7 +392,7 @@ struct Solver {
     const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
     launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd,
                       (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, carry_rate ? q.crate : 1.0,
-                      crate_fresh(q) ? newton_tol * crate_tol_factor : -1.0, crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p,
+                      crate_fresh(q) ? newton_tol : -1.0, crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p,
                       hc_dev, hseq_dev, seq, last, s);
     st.n_rhs++; st.n_linsolve++;
   }
