@@ -11,12 +11,13 @@
 //     round is one parallel gather pass with no intra-round dependencies);
 //   * whatever is left (hubs + the stubborn core) forms one dense Schur block that is inverted
 //     explicitly (blocked Gauss-Jordan), so its share of every solve is a single GEMV.
-// Factorisation = rounds x (scale L, gather Schur updates) + dense inverse; a solve =
-// (rounds-1) forward gathers + 1 dense-row gather + GEMV + rounds backward gathers: ~2*rounds+3
-// dependent kernels instead of hundreds of levels. All updates are pull-style gathers over
+// Factorisation = rounds x (scale L, gather Schur updates) + dense inverse (+ the explicit inverses
+// of the sparse triangular blocks and the products of the fused solve, see below); a solve = three
+// dependent kernels (gather | GEMV | gather), five without the fused products, 2*rounds+3 by plain
+// substitution - instead of hundreds of levels. All updates are pull-style gathers over
 // precomputed index lists (SegPlan), i.e. deterministic and atomic-free. Pivoting is static
-// (diagonal), like KLU's refactor path; a bad pivot shows up as a Newton failure and the step
-// is retried with a smaller h (M -> I as h -> 0).
+// (diagonal), like KLU's refactor path, and guarded: a vanishing pivot raises a device flag that
+// the integrator answers with a fresh Jacobian and a shorter step (M -> I as h -> 0).
 #pragma once
 #include <algorithm>
 #include <vector>

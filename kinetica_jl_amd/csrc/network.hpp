@@ -13,9 +13,9 @@ namespace kin {
 
 // Deterministic load-balanced gather-sum plan: out[dst(row)] = sum over the row's entries.
 // Short rows are packed 64 to a wavefront in a transposed (ELL) layout so that lane reads are
-// coalesced; long rows are cut into segments of <= SEG_LEN entries, one wavefront each; rows
-// with several segments are finished by a fix-up pass that adds the partial sums in a fixed
-// order (bitwise reproducible, no atomics).
+// coalesced; medium rows (<= SEG_LEN entries) take one wavefront each, longer rows one whole
+// workgroup each; every sum is formed in a fixed order (bitwise reproducible, no atomics, no
+// partial sums in memory).
 struct SegPlanHost {
   // Everything these plans drive is cache resident and latency bound, so the sizes minimise the
   // longest dependent chain per wavefront: ELL rows are walked 4 columns at a time with all loads

@@ -162,8 +162,8 @@ struct Solver {
     newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, 0.05);
   }
 
-  // step-end hand-over without a stream synchronisation: the error kernel publishes the control block into
-  // pinned host memory and bumps `*hseq`; the host spins on it (bounded), else falls back to sync_ctrl()
+  // step-end hand-over without a stream synchronisation: the corrector launch that decides the attempt publishes the
+  // control block into pinned host memory and bumps `*hseq`; the host spins on it (bounded), else falls back to sync_ctrl()
   unsigned long long* hseq = nullptr;
   BdfCtrl* hc_dev = nullptr;                // device-side address of hc
   unsigned long long* hseq_dev = nullptr;
