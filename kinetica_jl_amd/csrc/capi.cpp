@@ -31,7 +31,7 @@ void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, dou
     big_scratch.alloc((size_t)launch_sweep_big_grid(B) * (size_t)(host.N - host.big_H + host.n_pairs()));
     launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, (int32_t)host.big_tail_ptr.size() - 1,
                      big_rec8.p, big_rec.p, big_expl.p, (int32_t)host.big_expl.size(), sweep_k.p, big_spec.p, big_tptr.p, big_tent.p,
-                     big_scratch.p, d_u, d_k, k.p, d_du, s);
+                     big_scratch.p, d_u, d_k, k.p, d_du, host.big_tail_by_species, s);
   } else
     launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.pairs_block, sweep_rec.p, sweep_k.p,
                  host.pair_rec64.empty() ? nullptr : sweep_rec64.p, sweep_copy.p, (int)host.sweep_copy_species.size(),

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
                                                          const int32_t* __restrict__ tail_ptr, const uint2* __restrict__ tail_ent,
                                                          double* __restrict__ scratch, const double* __restrict__ u,
                                                          const double* __restrict__ k_b, const double* __restrict__ k_1,
-                                                         double* __restrict__ du) {
+                                                         double* __restrict__ du, int by_species) {
   extern __shared__ double lds[];
   const int HL = H + SWEEP_DUMMY;            // LDS entries per array: hubs + per-lane dummies
   double* du_s = lds;
@@ -749,8 +749,10 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
     const double* ub = u + (size_t)b * N;
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
     double* dub = du + (size_t)b * N;
-    // 1. permuting gather, PERM_ILP independent element chains per thread in flight
-    for (int l0 = tid; l0 < N; l0 += 1024 * PERM_ILP) {
+    // 1. permuting gather, PERM_ILP independent element chains per thread in flight. With tail operands addressed by
+    // species id (by_species) only the hubs are gathered: the record stream reads tail operands straight from u[b].
+    const double* tsrc = by_species ? ub : ut;
+    for (int l0 = tid; l0 < (by_species ? H : N); l0 += 1024 * PERM_ILP) {
       int sp[PERM_ILP];
       double v[PERM_ILP];
 #pragma unroll
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
       for (int x = 0; x < ILP; x++) {
         const uint32_t sl[4] = {w[x].x & 0xffffu, w[x].x >> 16, w[x].y & 0xffffu, w[x].y >> 16};
 #pragma unroll
-        for (int j = 0; j < 4; j++) uv[x][j] = (int)sl[j] < HL ? u_s[sl[j]] : ut[(int)sl[j] - HL];
+        for (int j = 0; j < 4; j++) uv[x][j] = (int)sl[j] < HL ? u_s[sl[j]] : tsrc[(int)sl[j] - HL];
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
@@ -817,8 +819,9 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
         const SweepRec q = rec[p];
         const double kf = ADJ ? kb[2 * (size_t)p] : kb[pair_k[p].x];
         const uint32_t a = q.ops & 0xffffu, c = q.ops >> 16;
-        double net = kf * ((int)a < H ? u_s[a] : ut[(int)a - H]);
-        if (c != 0xffffu) net *= ((int)c < H ? u_s[c] : ut[(int)c - H]);
+        // (16-byte records carry labels: tail operands by label, through the label -> species table when there is no `ut`)
+        double net = kf * ((int)a < H ? u_s[a] : (by_species ? ub[spec_of_label[a]] : ut[(int)a - H]));
+        if (c != 0xffffu) net *= ((int)c < H ? u_s[c] : (by_species ? ub[spec_of_label[c]] : ut[(int)c - H]));
         netbuf[p] = net;
         const uint32_t sl[4] = {q.s01 & 0xffffu, q.s01 >> 16, q.s23 & 0xffffu, q.s23 >> 16};
 #pragma unroll
@@ -880,24 +883,24 @@ template <bool ADJ>
 static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tail_tiles, const void* rec8, const void* rec,
                                const int32_t* expl, int n_expl, const void* pair_k, const int32_t* spec_of_label,
                                const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
-                               const double* k_1, double* du, hipStream_t s) {
+                               const double* k_1, double* du, int by_species, hipStream_t s) {
   // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
   KIN_HIP(hipFuncSetAttribute((const void*)sweep_big_kernel<ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((sweep_big_kernel<ADJ>), dim3(grid), dim3(1024), (size_t)2 * (H + SWEEP_DUMMY) * 8, s, N, R, P, B, H,
                      n_tail_tiles, (const uint2*)rec8, (const SweepRec*)rec, expl, n_expl, (const int2*)pair_k, spec_of_label,
-                     tail_ptr, (const uint2*)tail_ent, scratch, u, k_b, k_1, du);
+                     tail_ptr, (const uint2*)tail_ent, scratch, u, k_b, k_1, du, by_species);
 }
 
 // `scratch` holds launch_sweep_big_grid(B) rows of (N - H) + P doubles
 void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
                       const void* rec, const int32_t* expl, int32_t n_expl, const void* pair_k, const int32_t* spec_of_label,
                       const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
-                      const double* k_1, double* du, hipStream_t s) {
+                      const double* k_1, double* du, bool tail_by_species, hipStream_t s) {
   if (B == 0) return;
   const int grid = launch_sweep_big_grid(B);
   const bool adj = adjacent && ((((uintptr_t)(k_b ? k_b : k_1)) & 15) == 0);
-  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
-  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, s);
+  if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, tail_by_species ? 1 : 0, s);
+  else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, tail_by_species ? 1 : 0, s);
   KIN_HIP(hipGetLastError());
 }
 

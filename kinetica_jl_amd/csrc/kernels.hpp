@@ -63,6 +63,6 @@ int launch_sweep_big_grid(int64_t B);
 void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
                       const void* rec, const int32_t* expl, int32_t n_expl, const void* pair_k, const int32_t* spec_of_label,
                       const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
-                      const double* k_1, double* du, hipStream_t s);
+                      const double* k_1, double* du, bool tail_by_species, hipStream_t s);
 
 }  // namespace kin

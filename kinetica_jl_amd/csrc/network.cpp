@@ -310,6 +310,9 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
       for (int32_t sp = 0; sp < N; sp++) if (is_hub[sp]) { label[sp] = (int32_t)H.big_spec_of_label.size(); H.big_spec_of_label.push_back(sp); }
       for (int32_t sp = 0; sp < N; sp++) if (!is_hub[sp]) { label[sp] = (int32_t)H.big_spec_of_label.size(); H.big_spec_of_label.push_back(sp); }
       H.big_H = Hh;
+      // tail operands by species id when the 16-bit label space has room for it (N + H + 64 <= 65535: C5 does)
+      const bool by_species = (int64_t)N + Hh + 64 <= 65535;
+      H.big_tail_by_species = by_species;
       auto relabel = [&](uint32_t v) { return v == 0xffffu ? 0xffffu : (uint32_t)label[v]; };
       H.big_rec.resize((size_t)4 * P);
       const int32_t TT = 2 * Hh;                      // tail labels accumulated per pass (the whole LDS)
@@ -334,7 +337,7 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
               const int c = (int)(int8_t)(H.pair_rec[4 * p + 2] >> (8 * j));
               const int sd = c < 0 ? 0 : 1;
               for (int q = 0; q < (c < 0 ? -c : c) && cnt[sd] < 2; q++)
-                side[sd][cnt[sd]++] = (int32_t)sl[j] < Hh ? sl[j] : sl[j] + 64u;
+                side[sd][cnt[sd]++] = (int32_t)sl[j] < Hh ? sl[j] : (by_species ? (uint32_t)(Hh + 64 + H.big_spec_of_label[sl[j]]) : sl[j] + 64u);
             }
           } else {
             H.big_expl.push_back((int32_t)p);

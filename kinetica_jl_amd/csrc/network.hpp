@@ -83,6 +83,8 @@ struct NetworkHost {
   // carry labels. Hubs keep u and du in LDS; tail rates are gathered per tile of 2 * big_H labels from
   // `big_tail_ent` = (record, local label | coef << 24) pairs, sorted by record inside each tile.
   int32_t big_H = 0;
+  bool big_tail_by_species = false;   // stream records address tail operands by SPECIES id (label = big_H + 64 + species):
+                                      // operands come straight from the caller's u[b], no relabelled scratch copy of the tail
   std::vector<int32_t> big_spec_of_label;    // N
   std::vector<uint32_t> big_rec;             // 4 words per record, slots = labels (slow path of explicit-operand records)
   std::vector<uint32_t> big_rec8;            // 2 words per record: the stream format (kernels.hip: sweep_big_kernel)

@@ -363,7 +363,7 @@ def test_batched_sweep_size_boundaries(layout):
     and general kernels, odd N, the large-N kernel), few reactions, batch sizes below / above the CU count."""
     rng = np.random.default_rng({"adjacent": 1, "block": 2, "irregular": 3}[layout])
     for n in (2, 3, 63, 64, 65, 1023, 1024, 1025, 2559, 2560, 2561, 2562, 5119, 5120, 5121, 5122, 10111, 10112, 10175, 10176, 10177,
-              10178, 10239, 10240, 10241, 12001):
+              10178, 10239, 10240, 10241, 12001, 55471, 55472, 60001):     # > 55 471: tail operands by label again
         net = _random_net(rng, n, 150 if n >= 4 else 1, layout)
         h = capi.HipNetwork.from_flat(net)
         on = orc.OracleNetwork.from_flat(net)
