@@ -94,7 +94,7 @@ class OracleBDF:
         self.crate_fresh = False
         self.nc_crate, self.nc_crate_step, self.nc_crate_restart = 1.0, 0, -1     # the single factorisation of the cache-less mode
         self.crate_max_age = 10  # accepted steps a measured rate is trusted for (and never across a restart)
-        self.crate_dy_max = 1.0  # a first correction larger than this always gets a second iteration
+        self.crate_dy_max = 0.2  # a first correction larger than this always gets a second iteration (solver.cpp: crate_dy_max)
         self.use_clock = 0
         self.c_fact = 0.0
         self.fun, self.jac, self.n = fun, jac, n

@@ -494,7 +494,7 @@ struct Bdf {
   // carried convergence rate: validity of the first-iteration test (Solver::crate_fresh, solver.cpp) and the cache-less mode's copy
   bool crate_is_fresh = false;
   int64_t crate_max_age = 10, nc_crate_step = 0, nc_crate_restart = -1;
-  double crate_dy_max = 1.0;
+  double crate_dy_max = 0.2;
   bool crate_fresh(double crate, int64_t step, int64_t restart) const {
     return crate < 1.0 && restart == st.n_restarts && st.n_steps - step <= crate_max_age;
   }
