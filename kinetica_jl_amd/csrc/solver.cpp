@@ -157,11 +157,12 @@ struct Solver {
 
   void set_tols(double a, double r) {
     atol = a; rtol = r;
-    // corrector tolerance of ode15s / CVODE: a fixed fraction of the error weight (0.05), not RADAU5's sqrt(rtol); see
-    // oracle/bdf.py (set_tols) for the rationale. KIN_NEWTON_TOL overrides the fraction (experiments: 0.02 takes 13 % fewer
-    // steps on one 0.3 s window of the C4 ramp - less iteration noise in the order selection - but the full ramp is 3 %
-    // slower, 166 against 161 s, and C3 4 %)
-    static const double frac = getenv("KIN_NEWTON_TOL") ? atof(getenv("KIN_NEWTON_TOL")) : 0.05;
+    // corrector tolerance in the style of ode15s / CVODE: a fixed fraction of the error weight, not RADAU5's sqrt(rtol); see
+    // oracle/bdf.py (set_tols). ode15s uses 0.05; here 0.03 (KIN_NEWTON_TOL), together with reuse_rate_max = 0.15: with
+    // 0.05 / 0.2 two of the 140 solves of tools/robustness_sweep.py collapsed their step size (DtLessThanMin at every retry
+    // tolerance; the CPU mirror of the algorithm did the same) - iterates converged no further than asked leave enough
+    // noise in the difference history for that. Measured: C3 0.434 -> 0.452 s, full C4 ramp 161 -> 163 s, sweep 140 / 140.
+    static const double frac = getenv("KIN_NEWTON_TOL") ? atof(getenv("KIN_NEWTON_TOL")) : 0.03;
     newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, frac);
   }
 
@@ -362,8 +363,8 @@ struct Solver {
   // corrections of 0.66 units on a stale rate, poisoned its difference history and ended in DtLessThanMin at every tolerance.)
   double crate_dy_max = 0.2;
   int last_iters = 0, last_iter_slot = -1;
-  double reuse_rate_max = 0.2;   // KIN_LU_RATE_MAX: slowest contraction accepted from a reused factorisation (0.1: 12 % slower on C3,
-                                 // 0.5: 17 % slower on the C4 ramp - slow contractions leave iteration error in the error estimates)
+  double reuse_rate_max = 0.15;  // KIN_LU_RATE_MAX: slowest contraction accepted from a reused factorisation (0.1: C3 11 % slower, in
+                                 // refreshes that were not needed; 0.2: not robust, see set_tols; 0.5: 17 % slower on the C4 ramp)
   // KIN_LU_MAX_AGE: a slot is offered for that many restarts after its Jacobian was evaluated. Unlimited reuse is
   // UNSAFE: a direction that was stiff when the slot was made (c J ~ 1e6) and is not any more (its species consumed) is
   // damped to nothing by the old matrix - the corrections vanish, the corrector "converges" at once, and both the

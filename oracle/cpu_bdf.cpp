@@ -416,7 +416,7 @@ struct Bdf {
   // (4 per decade) and reused - across step-size changes AND across restarts - while |c / c_fact - 1| <= lu_reuse,
   // with the update scaled by 2 / (1 + c / c_fact); a slot is refreshed (new Jacobian, new factorisation) only when a
   // corrector that used it fails. lu_cache = number of slots (0: off).
-  double lu_rate_max = 0.2;   // slowest contraction accepted from a reused factorisation
+  double lu_rate_max = 0.15;  // slowest contraction accepted from a reused factorisation
   bool force_fresh_lu = false, slot_is_fresh = true;
   int64_t steps_since_jac = 0;
   int lu_cache = 0;
@@ -517,7 +517,7 @@ struct Bdf {
     lu.analyze((int32_t)N, net.jcp, net.jri);
   }
   double* Drow(int j) { return D.data() + (size_t)j * N; }
-  void set_tols(double a, double r) { atol = a; rtol = r; newton_tol = std::max(10.0 * EPS / r, 0.05); }
+  void set_tols(double a, double r) { atol = a; rtol = r; newton_tol = std::max(10.0 * EPS / r, 0.03); }   // oracle/bdf.py set_tols
   void fun(const double* u, double* out) { const double t0 = now_s(); net.rhs(k, u, out); st.n_rhs++; st.t_rhs += now_s() - t0; }
   void eval_jac(const double* u) { const double t0 = now_s(); net.jac(k, u, J.data()); st.n_jac++; lu_valid = false; steps_since_jac = 0; jac_stamp_now = st.n_restarts; st.t_jac += now_s() - t0; }
   double rms_scaled(const double* v, const double* sc) const {

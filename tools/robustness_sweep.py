@@ -13,13 +13,14 @@ from kinetica_jl_amd import capi  # noqa: E402
 from kinetica_jl_amd.synth import synthetic_crn  # noqa: E402
 
 bad = 0
-for (n, r) in ((1000, 5000), (3000, 15000), (10000, 50000)):
-    for seed in (12345, 1, 2, 3):
+WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"      # more seeds and temperatures on the two smaller sizes
+for (n, r) in (((1000, 5000), (3000, 15000)) if WIDE else ((1000, 5000), (3000, 15000), (10000, 50000))):
+    for seed in ((12345, 1, 2, 3, 4, 5, 6, 7, 8, 9) if WIDE else (12345, 1, 2, 3)):
         net, Ea, A = synthetic_crn(n, r, seed=seed)
         h = capi.HipNetwork.from_flat(net)
         h.set_arrhenius(Ea, A, k_max=1e12)
         u0 = np.zeros(n); u0[0] = 1.0
-        for T in (800.0, 1000.0, 1400.0):
+        for T in ((600.0, 800.0, 1000.0, 1200.0, 1400.0, 1800.0) if WIDE else (800.0, 1000.0, 1400.0)):
             h.rates_at(T)
             p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=1,
                                ban_negatives=0, solve_chunkstep=1e-3, maxiters=100000, save_interval=1e-3, dtmin=1e-30)
