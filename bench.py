@@ -70,10 +70,34 @@ def self_launch(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    sys.stdout.write(out.decode())
+    # a rank that dies (e.g. fewer GPUs than ranks) leaves the others waiting at the rendezvous: watch the children and,
+    # when one exits with an error, end the rest (these exact child processes) instead of hanging until an outer timeout
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        states = [p.poll() for p in procs]
+        failed = [c for c in states if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            print(f"bench.py: a rank exited with status {rc}; the other ranks were stopped", file=sys.stderr)
+            break
+        if all(c == 0 for c in states):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    rc = max(p.wait() for p in procs)
     raise SystemExit(rc)
 
 
