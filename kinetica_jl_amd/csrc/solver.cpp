@@ -1057,7 +1057,12 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
       S.st.n_retries++;
       S.invalidate_lu_keep_counters();
       S.cache_suspended = true;
-      KIN_HIP(hipMemcpyAsync(S.y.p, chunk_start.p, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+      // The retried chunk starts from its start state with NEGATIVE entries set to zero. A chunk can inherit concentrations
+      // of -1e-9 (tolerance-sized, 10 x abstol is common) from its predecessor, and mass-action kinetics is unstable under
+      // them - a bimolecular term flips its sign - up to a finite-time blow-up of the exact solution from that state: every
+      // retry then dies at the same local time whatever its tolerances (3k species, 1 500 K: five attempts, all at
+      // t = 7.0e-4). The first attempt of a chunk is untouched (reference semantics); only the rescue path clips.
+      launch_clip_negative(N, chunk_start.p, S.y.p, s);
       h->n_saved = saved_at_chunk_start;
       h->sol_t.resize(times_at_chunk_start);
     }

@@ -779,6 +779,12 @@ __global__ __launch_bounds__(256) void rk_error_kernel(int N, RkVec e, const dou
 }
 
 // out = a + s*b
+// out[i] = max(a[i], 0): the start state of a RETRIED chunk (see solve_entry)
+__global__ __launch_bounds__(256) void clip_negative_kernel(int N, const double* __restrict__ a, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) { const double v = a[i]; out[i] = v < 0.0 ? 0.0 : v; }
+}
+
 __global__ __launch_bounds__(256) void axpy_out_kernel(int N, const double* __restrict__ a, double s, const double* __restrict__ b, double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < N) out[i] = a[i] + s * b[i];
@@ -862,6 +868,9 @@ void launch_bdf_accept_predict(int N, int ao, int order, double* D, const BdfCoe
 }
 void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s) {
   hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d, copy_out);
+}
+void launch_clip_negative(int N, const double* a, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(clip_negative_kernel, GRID1(N), 0, s, N, a, out);
 }
 void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s) {
   hipLaunchKernelGGL(bdf_change_D_kernel, GRID1(N), 0, s, N, order, ru, D);

@@ -60,6 +60,7 @@ void launch_rk_error(int N, const RkVec& e, const double* y, const double* y_new
                      BdfCtrl* ctrl, double* part, BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq,
                      hipStream_t s);
 void launch_axpy_out(int N, const double* a, double sc, const double* b, double* out, hipStream_t s);
+void launch_clip_negative(int N, const double* a, double* out, hipStream_t s);   // out = max(a, 0)
 void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s);
 void launch_rowdot(int N, int64_t M, const double* U, const double* w, double* out, hipStream_t s);
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s);

@@ -667,7 +667,7 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
             if hasattr(bdf, "cache_suspended"):
                 bdf.invalidate_lu()
                 bdf.cache_suspended = True
-            y = y_start.copy()
+            y = np.maximum(y_start, 0.0)      # the rescue path clips inherited negative concentrations (solver.cpp, solve_entry)
             del out_t[n_out_start:]; del out_u[n_out_start:]
         if retcode != RET_SUCCESS:
             break

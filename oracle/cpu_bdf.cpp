@@ -966,6 +966,7 @@ int solve(Handle& H, const CpuParams& p, const double* u0, const double* k0, con
       B.st.n_retries++;
       B.clear_cache(); B.lu_valid = false; B.cache_suspended = true;
       y = y_start;
+      for (double& v : y) if (v < 0.0) v = 0.0;      // the rescue path clips inherited negative concentrations (solver.cpp, solve_entry)
       H.sol_t.resize(n_out_start);
       H.sol_u.resize(n_out_start * (size_t)N);
     }
