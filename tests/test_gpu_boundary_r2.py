@@ -257,3 +257,24 @@ def test_solves_that_collapsed_under_looser_corrector_settings(seed, T):
     m = u @ net.mass.astype(float)
     np.testing.assert_allclose(m, m[0], rtol=5e-7, atol=0)
     h.close()
+
+
+@pytest.mark.parametrize("seed,T", [(14, 900.0), (14, 1500.0), (17, 1100.0)])
+def test_retry_rescues_a_chunk_that_inherited_negative_concentrations(seed, T):
+    """Loose tolerances (1e-8 / 1e-6) let a chunk end with concentrations of -1e-9; mass-action kinetics is unstable under
+    them and the next chunk can start on a solution with a finite-time blow-up: these three solves failed at EVERY retry
+    tolerance, each retry at the same local time. The rescue path now restarts the chunk with the negative entries of
+    its start state set to zero (solver.cpp, solve_entry): they end with Success (after one to three retries on the
+    build this was written for - the count itself is not asserted, the excursions are chaotic)."""
+    net, Ea, A = synthetic_crn(1000, 5000, seed=seed)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    h.rates_at(T)
+    u0 = np.zeros(1000); u0[0] = 1.0
+    p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=1e-8, reltol=1e-6, adaptive_tols=1, update_tols=0, solve_chunks=1,
+                       ban_negatives=0, solve_chunkstep=1e-3, maxiters=100000, save_interval=1e-3, dtmin=1e-30)
+    t, u, rc, st, status = h.solve(p, u0)
+    assert status == capi.KIN_OK and rc == 0 and len(t) == 11
+    m = u @ net.mass.astype(float)
+    np.testing.assert_allclose(m, m[0], rtol=1e-5, atol=0)      # clipping -1e-9 entries moves the invariant by ~1e-9 each
+    h.close()
