@@ -17,13 +17,14 @@ BAN = int(os.environ.get("BAN_NEG", "0"))      # ODESimulationParams.ban_negativ
 WIDE = len(sys.argv) > 1 and sys.argv[1] in ("wide", "wide2")      # more seeds and temperatures on the two smaller sizes
 WIDE2 = len(sys.argv) > 1 and sys.argv[1] == "wide2"               # other seeds, in-between temperatures, looser / tighter tolerances
 TOLS = ((1e-10, 1e-8), (1e-8, 1e-6), (1e-12, 1e-10)) if WIDE2 else ((1e-10, 1e-8),)
-for (n, r) in (((1000, 5000), (3000, 15000)) if WIDE else ((1000, 5000), (3000, 15000), (10000, 50000))):
-    for seed in ((11, 12, 13, 14, 15, 16, 17, 18) if WIDE2 else (12345, 1, 2, 3, 4, 5, 6, 7, 8, 9) if WIDE else (12345, 1, 2, 3)):
+BIG = len(sys.argv) > 1 and sys.argv[1] == "big"                   # 10k species only, eight other seeds, five temperatures
+for (n, r) in (((10000, 50000),) if BIG else ((1000, 5000), (3000, 15000)) if WIDE else ((1000, 5000), (3000, 15000), (10000, 50000))):
+    for seed in ((21, 22, 23, 24, 25, 26, 27, 28) if BIG else (11, 12, 13, 14, 15, 16, 17, 18) if WIDE2 else (12345, 1, 2, 3, 4, 5, 6, 7, 8, 9) if WIDE else (12345, 1, 2, 3)):
         net, Ea, A = synthetic_crn(n, r, seed=seed)
         h = capi.HipNetwork.from_flat(net)
         h.set_arrhenius(Ea, A, k_max=1e12)
         u0 = np.zeros(n); u0[0] = 1.0
-        for T, (ATOL, RTOL) in [(T, tl) for T in ((900.0, 1100.0, 1300.0, 1500.0) if WIDE2 else (600.0, 800.0, 1000.0, 1200.0, 1400.0, 1800.0) if WIDE else (800.0, 1000.0, 1400.0)) for tl in TOLS]:
+        for T, (ATOL, RTOL) in [(T, tl) for T in ((700.0, 900.0, 1100.0, 1300.0, 1500.0) if BIG else (900.0, 1100.0, 1300.0, 1500.0) if WIDE2 else (600.0, 800.0, 1000.0, 1200.0, 1400.0, 1800.0) if WIDE else (800.0, 1000.0, 1400.0)) for tl in TOLS]:
             h.rates_at(T)
             p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=ATOL, reltol=RTOL, adaptive_tols=1, update_tols=0, solve_chunks=1,
                                ban_negatives=BAN, solve_chunkstep=1e-3, maxiters=100000, save_interval=1e-3, dtmin=1e-30)
