@@ -44,6 +44,13 @@ summary = {
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     "bench_line_under_profiler": bench,
 }
+timed = glob.glob(os.path.join(out, "stats_timed", "**", "*kernel_stats.csv"), recursive=True)
+if timed:      # warm-up + timed launches only (no sustained leg): the figure to hold against roofline.achieved
+    trow = [r for r in csv.DictReader(open(timed[0])) if "kin::sweep_" in r["Name"]][0]
+    tline = [l for l in open(os.path.join(out, "bench_stats_timed.log")) if l.startswith("{")][-1]
+    summary["timed_launches_only"] = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --solve-chunks 0 --no-cpu --no-pmc --sustain-seconds 0",
+                                      "calls": int(trow["Calls"]), "avg_ns_rocprof": float(trow["AverageNs"]),
+                                      "avg_launch_ms_bench_events": json.loads(tline)["roofline"]["avg_launch_ms"]}
 summary["traffic_over_algorithmic"] = summary["hbm_bytes_per_launch_corrected"] / summary["algorithmic_bytes_per_launch"]
 json.dump(summary, open(os.path.join(dst, f"{tag}_sweep_pmc.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "bench_line_under_profiler"}, indent=1))
