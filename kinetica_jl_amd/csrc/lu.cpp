@@ -1,10 +1,13 @@
 #include "lu.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <map>
 #include <numeric>
+#include <thread>
 
 namespace kin {
 
@@ -45,6 +48,14 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
                        const LUOptions& opt, hipStream_t s) {
   n = n_;
   nnzJ = (int64_t)j_col.size();
+  const bool dbg_time = getenv("KIN_LU_DEBUG") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_time) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[lu] analyze: %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   // ---- symmetric adjacency of J + J^T without self loops
   std::vector<std::vector<int32_t>> adj(n);
   for (int32_t i = 0; i < n; i++)
@@ -118,6 +129,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   iperm.assign(n, -1);
   for (int32_t q = 0; q < n; q++) iperm[perm[q]] = q;
 
+  lap("elimination rounds");
   // ---- sparse structure in new indices
   ent_ptr.assign(ns + 1, 0);
   std::vector<int32_t> nbr;
@@ -225,45 +237,80 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       n_mono_ent = (int32_t)m_dst.size();
     }
   }
+  lap("monomials of Z and V");
   // ---- fused solve (symbolic): LZ = L21 * L11^-1 and NVU = -(U11^-1 * U12), so that a solve is three dependent
   // launches: [y1 = Z b1 ; y2 = b2 - LZ b1] | x2 = S^-1 y2 | x1 = V y1 + NVU x2
   struct Prod { int32_t a, b; };
-  std::vector<std::map<int32_t, std::pair<int32_t, std::vector<Prod>>>> lz_rows, nvu_rows;   // per row: col -> (direct pos | -1, products)
+  // rows of LZ / NVU as flat CSR: per entry its column, the position of its direct term (LZ: L21[j,p], else -1) and its
+  // products [pptr[e], pptr[e + 1]). Built row by row from a small sorted scratch list (no per-row maps: the symbolic
+  // products are 1.7 M terms at 10k species, 13 M at 50k, and the analysis is part of every first solve of a network).
+  struct FusedRows {
+    std::vector<int64_t> row_ptr{0}, pptr{0};
+    std::vector<int32_t> col, direct;
+    std::vector<Prod> prod;
+    int64_t n_entries() const { return (int64_t)col.size(); }
+  };
+  struct Item { int32_t col, a, b; };      // b < 0: direct term at position a
+  auto flush_row = [](std::vector<Item>& tmp, FusedRows& F) {
+    std::sort(tmp.begin(), tmp.end(), [](const Item& x, const Item& y) { return x.col != y.col ? x.col < y.col : x.b < y.b; });
+    for (size_t q = 0; q < tmp.size();) {
+      const int32_t c = tmp[q].col;
+      int32_t dir = -1;
+      for (; q < tmp.size() && tmp[q].col == c; q++) {
+        if (tmp[q].b < 0) dir = tmp[q].a; else F.prod.push_back({tmp[q].a, tmp[q].b});
+      }
+      F.col.push_back(c); F.direct.push_back(dir); F.pptr.push_back((int64_t)F.prod.size());
+    }
+    F.row_ptr.push_back(F.n_entries());
+    tmp.clear();
+  };
+  FusedRows LZ, NVU;
   fused_tri = explicit_tri && m > 0 && !(getenv("KIN_LU_FUSED") && atoi(getenv("KIN_LU_FUSED")) == 0);
   if (fused_tri) {
     const int64_t prod_limit = 16000000;
-    int64_t nprod = 0;
-    lz_rows.resize(m); nvu_rows.resize(ns);
-    for (int32_t k = 0; k < ns && fused_tri; k++)
-      for (int32_t e = ent_ptr[k]; e < ent_ptr[k + 1]; e++) {
-        if (nbr[e] < ns) continue;
-        auto& row = lz_rows[nbr[e] - ns];
-        auto it = row.find(k);
-        if (it == row.end()) row[k] = {(int32_t)(off_L + e), {}}; else it->second.first = (int32_t)(off_L + e);
-        for (auto& ce : z_cols[k]) {                 // Z'[k, ce.first], ce.first < k
-          auto jt = row.find(ce.first);
-          if (jt == row.end()) jt = row.emplace(ce.first, std::make_pair((int32_t)-1, std::vector<Prod>{})).first;
-          jt->second.second.push_back({(int32_t)(off_L + e), (int32_t)(off_Z + ce.second)});
-          if (++nprod > prod_limit) { fused_tri = false; break; }
+    // L21 entries bucketed by dense row
+    std::vector<int64_t> dptr(m + 1, 0);
+    for (int32_t e = 0; e < (int32_t)nbr.size(); e++) if (nbr[e] >= ns) dptr[nbr[e] - ns + 1]++;
+    for (int32_t j = 0; j < m; j++) dptr[j + 1] += dptr[j];
+    std::vector<int32_t> dk(dptr[m]), de(dptr[m]);
+    {
+      std::vector<int64_t> fill(dptr.begin(), dptr.end() - 1);
+      for (int32_t k = 0; k < ns; k++)
+        for (int32_t e = ent_ptr[k]; e < ent_ptr[k + 1]; e++)
+          if (nbr[e] >= ns) { const int64_t q = fill[nbr[e] - ns]++; dk[q] = k; de[q] = e; }
+    }
+    bool lz_ok = true, nvu_ok = true;
+    auto build_lz = [&] {
+      std::vector<Item> tmp;
+      for (int32_t j = 0; j < m && lz_ok; j++) {
+        for (int64_t q = dptr[j]; q < dptr[j + 1]; q++) {
+          const int32_t k = dk[q], le = (int32_t)(off_L + de[q]);
+          tmp.push_back({k, le, -1});
+          for (auto& ce : z_cols[k]) tmp.push_back({ce.first, le, (int32_t)(off_Z + ce.second)});     // Z'[k, ce.first], ce.first < k
         }
-        if (!fused_tri) break;
+        flush_row(tmp, LZ);
+        if ((int64_t)LZ.prod.size() > prod_limit) lz_ok = false;
       }
-    for (int32_t i = 0; i < ns && fused_tri; i++)
-      for (auto& je : v_cols[i]) {                   // V[i, je.first], je.first >= i
-        const int32_t j = je.first;
-        for (int32_t e = ent_ptr[j]; e < ent_ptr[j + 1]; e++) {
-          if (nbr[e] < ns) continue;
-          auto& ent = nvu_rows[i][nbr[e] - ns];
-          ent.first = -1;
-          ent.second.push_back({(int32_t)(off_V + je.second), (int32_t)(off_U + e)});
-          if (++nprod > prod_limit) { fused_tri = false; break; }
+    };
+    auto build_nvu = [&] {
+      std::vector<Item> tmp;
+      for (int32_t i = 0; i < ns && nvu_ok; i++) {
+        for (auto& je : v_cols[i]) {                   // V[i, je.first], je.first >= i
+          const int32_t j = je.first;
+          for (int32_t e = ent_ptr[j]; e < ent_ptr[j + 1]; e++)
+            if (nbr[e] >= ns) tmp.push_back({nbr[e] - ns, (int32_t)(off_V + je.second), (int32_t)(off_U + e)});
         }
-        if (!fused_tri) break;
+        flush_row(tmp, NVU);
+        if ((int64_t)NVU.prod.size() > prod_limit) nvu_ok = false;
       }
+    };
+    std::thread th(build_lz);
+    build_nvu();
+    th.join();
+    const int64_t nprod = (int64_t)LZ.prod.size() + (int64_t)NVU.prod.size();
+    if (!lz_ok || !nvu_ok || nprod > prod_limit) fused_tri = false;
     if (fused_tri) {
-      nnzLZ = 0; nnzNVU = 0;
-      for (auto& r : lz_rows) nnzLZ += (int64_t)r.size();
-      for (auto& r : nvu_rows) nnzNVU += (int64_t)r.size();
+      nnzLZ = LZ.n_entries(); nnzNVU = NVU.n_entries();
       // LZ / NVU entries get IDs in a virtual range first; their storage is assigned below, in the order in which
       // the solve reads them (value-ordered plans)
       off_LZ = (int64_t)1 << 30;
@@ -275,16 +322,16 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     }
   }
   if (getenv("KIN_LU_DEBUG") && fused_tri) {
-    auto hist = [](const char* name, const std::vector<std::map<int32_t, std::pair<int32_t, std::vector<Prod>>>>& rows) {
+    auto hist = [](const char* name, const FusedRows& F) {
       long long h[6] = {0, 0, 0, 0, 0, 0}, mx = 0;
-      for (auto& r : rows) {
-        const long long l = (long long)r.size();
+      for (size_t r = 0; r + 1 < F.row_ptr.size(); r++) {
+        const long long l = (long long)(F.row_ptr[r + 1] - F.row_ptr[r]);
         mx = std::max(mx, l);
         h[l <= 8 ? 0 : l <= 64 ? 1 : l <= 256 ? 2 : l <= 1024 ? 3 : l <= 4096 ? 4 : 5]++;
       }
       fprintf(stderr, "[lu] %s row lengths: <=8:%lld <=64:%lld <=256:%lld <=1024:%lld <=4096:%lld more:%lld max:%lld\n", name, h[0], h[1], h[2], h[3], h[4], h[5], mx);
     };
-    hist("LZ", lz_rows); hist("NVU", nvu_rows);
+    hist("LZ", LZ); hist("NVU", NVU);
   }
   if (getenv("KIN_LU_DEBUG"))
     fprintf(stderr, "[lu] n=%d ns=%d m=%d rounds=%d nnzU=%lld nnzZ=%lld nnzV=%lld monomials=%lld explicit=%d fused=%d nnzLZ=%lld nnzNVU=%lld products=%lld\n",
@@ -297,6 +344,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     return off_L + find_entry(ent_ptr, nbr, c, j);              // L column c
   };
 
+  lap("LZ / NVU symbolic products");
   // ---- J scatter map
   {
     std::vector<int32_t> jm(nnzJ);
@@ -321,16 +369,29 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   schur.clear(); fwd.clear(); bwd.clear();
   schur.resize(nrounds); fwd.resize(nrounds); bwd.resize(nrounds);
   schur_macs = 0;
-  std::vector<Triple> tr;
-  for (int r = 0; r < nrounds; r++) {
-    tr.clear();
-    for (int32_t p = round_ptr[r]; p < round_ptr[r + 1]; p++)
-      for (int32_t ej = ent_ptr[p]; ej < ent_ptr[p + 1]; ej++)
-        for (int32_t ec = ent_ptr[p]; ec < ent_ptr[p + 1]; ec++)
-          tr.push_back({pos_of(nbr[ej], nbr[ec]), (int32_t)(off_L + ej), (int32_t)(off_U + ec)});
-    schur_macs += (int64_t)tr.size();
-    schur[r].upload(plan_from_triples(tr, false, 0, 0), s);
+  {
+    // one host thread per round: the triple lists (1 M entries at 10k species) are sorted and laid out independently
+    std::vector<SegPlanHost> hp(nrounds);
+    std::vector<int64_t> macs(nrounds, 0);
+    std::vector<std::exception_ptr> errs(nrounds);
+    std::vector<std::thread> th;
+    for (int r = 0; r < nrounds; r++)
+      th.emplace_back([&, r] {
+        try {
+          std::vector<Triple> tr;
+          for (int32_t p = round_ptr[r]; p < round_ptr[r + 1]; p++)
+            for (int32_t ej = ent_ptr[p]; ej < ent_ptr[p + 1]; ej++)
+              for (int32_t ec = ent_ptr[p]; ec < ent_ptr[p + 1]; ec++)
+                tr.push_back({pos_of(nbr[ej], nbr[ec]), (int32_t)(off_L + ej), (int32_t)(off_U + ec)});
+          macs[r] = (int64_t)tr.size();
+          hp[r] = plan_from_triples(tr, false, 0, 0);
+        } catch (...) { errs[r] = std::current_exception(); }
+      });
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (e) std::rethrow_exception(e);
+    for (int r = 0; r < nrounds; r++) { schur_macs += macs[r]; schur[r].upload(hp[r], s); }
   }
+  lap("scatter map + Schur plans");
   // ---- forward substitution: y_q -= sum_{p < q, q in nb(p)} L[q][p] * y_p, grouped by the round of q
   {
     std::vector<std::vector<Triple>> per_round(nrounds + 1);
@@ -387,31 +448,30 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     // (monomial kernel for Z and V, the LZ / NVU product launches) writes to the relocated positions.
     std::vector<int32_t> idA, idC, slotA, slotC;
     SegPlanHost PA, PC;
-    {   // stage A: y1_i = b_i - sum_p Z'[i,p] b_p (sparse rows) ; y2_j = b2_j - sum_p LZ[j,p] b_p (dense rows, in place)
+    auto build_A = [&] {   // stage A: y1_i = b_i - sum_p Z'[i,p] b_p (sparse rows) ; y2_j = b2_j - sum_p LZ[j,p] b_p (dense rows, in place)
       std::vector<int32_t> ptr{0}, dst, aux, b;
       for (int32_t i = 0; i < ns; i++) {
         for (auto& ce : z_cols[i]) { idA.push_back((int32_t)(off_Z + ce.second)); b.push_back((int32_t)(off_y + ce.first)); }
         ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y1 + i)); aux.push_back((int32_t)(off_y + i));
       }
-      int64_t idx = 0;
       for (int32_t j = 0; j < m; j++) {
-        for (auto& ce : lz_rows[j]) { idA.push_back((int32_t)(off_LZ + idx++)); b.push_back((int32_t)(off_y + ce.first)); }
+        for (int64_t en = LZ.row_ptr[j]; en < LZ.row_ptr[j + 1]; en++) { idA.push_back((int32_t)(off_LZ + en)); b.push_back((int32_t)(off_y + LZ.col[en])); }
         ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y + ns + j)); aux.push_back((int32_t)(off_y + ns + j));
       }
       b.push_back(0);
       PA = build_seg_plan((int64_t)ns + m, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, aux.data(), &slotA);
-    }
-    {   // stage C: x1_i = sum_j V[i,j] y1_j + sum_c NVU[i,c] x2_c
+    };
+    auto build_C = [&] {   // stage C: x1_i = sum_j V[i,j] y1_j + sum_c NVU[i,c] x2_c
       std::vector<int32_t> ptr{0}, dst, b;
-      int64_t idx = 0;
       for (int32_t i = 0; i < ns; i++) {
         for (auto& ce : v_cols[i]) { idC.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_y1 + ce.first)); }
-        for (auto& ce : nvu_rows[i]) { idC.push_back((int32_t)(off_NVU + idx++)); b.push_back((int32_t)(off_x + ce.first)); }
+        for (int64_t en = NVU.row_ptr[i]; en < NVU.row_ptr[i + 1]; en++) { idC.push_back((int32_t)(off_NVU + en)); b.push_back((int32_t)(off_x + NVU.col[en])); }
         ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y + i));
       }
       b.push_back(0);
       PC = build_seg_plan(ns, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, nullptr, &slotC);
-    }
+    };
+    { std::thread tA(build_A); build_C(); tA.join(); }
     off_VA = w_end;
     off_VC = align(off_VA + PA.ell_total + PA.long_total);
     w_end = align(off_VC + PC.ell_total + PC.long_total + 8);
@@ -439,33 +499,32 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     };
     for (int32_t& d : m_dst) d = R(d);
     // numeric products of a factorisation: LZ[j,p] = L21[j,p] - sum_k L21[j,k] Z'[k,p] ; NVU[i,c] = - sum_j V[i,j] U12[j,c]
-    {
+    SegPlanHost Plz, Pnvu;
+    auto build_lzp = [&] {
       std::vector<int32_t> ptr{0}, dst, aux, a, b;
-      int64_t idx = 0;
-      for (int32_t j = 0; j < m; j++)
-        for (auto& ce : lz_rows[j]) {
-          for (const Prod& pr : ce.second.second) { a.push_back(pr.a); b.push_back(R(pr.b)); }
-          ptr.push_back((int32_t)a.size());
-          dst.push_back(R((int32_t)(off_LZ + idx)));
-          aux.push_back(ce.second.first >= 0 ? ce.second.first : (int32_t)off_zero);
-          idx++;
-        }
+      a.reserve(LZ.prod.size() + 1); b.reserve(LZ.prod.size() + 1);
+      for (int64_t en = 0; en < LZ.n_entries(); en++) {
+        for (int64_t q = LZ.pptr[en]; q < LZ.pptr[en + 1]; q++) { a.push_back(LZ.prod[q].a); b.push_back(R(LZ.prod[q].b)); }
+        ptr.push_back((int32_t)a.size());
+        dst.push_back(R((int32_t)(off_LZ + en)));
+        aux.push_back(LZ.direct[en] >= 0 ? LZ.direct[en] : (int32_t)off_zero);
+      }
       a.push_back(0); b.push_back(0);
-      lz_build.upload(build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
-    }
-    {
+      Plz = build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data());
+    };
+    auto build_nvup = [&] {
       std::vector<int32_t> ptr{0}, dst, a, b;
-      int64_t idx = 0;
-      for (int32_t i = 0; i < ns; i++)
-        for (auto& ce : nvu_rows[i]) {
-          for (const Prod& pr : ce.second.second) { a.push_back(R(pr.a)); b.push_back(pr.b); }
-          ptr.push_back((int32_t)a.size());
-          dst.push_back(R((int32_t)(off_NVU + idx)));
-          idx++;
-        }
+      a.reserve(NVU.prod.size() + 1); b.reserve(NVU.prod.size() + 1);
+      for (int64_t en = 0; en < NVU.n_entries(); en++) {
+        for (int64_t q = NVU.pptr[en]; q < NVU.pptr[en + 1]; q++) { a.push_back(R(NVU.prod[q].a)); b.push_back(NVU.prod[q].b); }
+        ptr.push_back((int32_t)a.size());
+        dst.push_back(R((int32_t)(off_NVU + en)));
+      }
       a.push_back(0); b.push_back(0);
-      nvu_build.upload(build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
-    }
+      Pnvu = build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false);
+    };
+    { std::thread tL(build_lzp); build_nvup(); tL.join(); }
+    lz_build.upload(Plz, s); nvu_build.upload(Pnvu, s);
     KIN_HIP(hipStreamSynchronize(s));
   }
   if (explicit_tri) {
@@ -475,6 +534,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   }
   w_size = w_end;
   if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
+  lap("substitution + fused plans");
   // ---- backward substitution: x_p = (y_p - sum_c U[p][c] x_c) / diag_p
   for (int r = 0; r < nrounds; r++) {
     int32_t p0 = round_ptr[r], p1 = round_ptr[r + 1];
@@ -497,6 +557,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   slots.clear();
   ensure_slots(1, s);
   KIN_HIP(hipStreamSynchronize(s));
+  lap("backward plans + first slot");
 }
 
 void SparseLU::ensure_slots(int nslots, hipStream_t s) {
