@@ -104,9 +104,27 @@ def self_launch(args):
 # ---------------------------------------------------------------------------------------------------------------
 # HBM traffic of the sweep kernel from the PMC counters, measured by child processes of this run
 # ---------------------------------------------------------------------------------------------------------------
+def under_profiler():
+    """True when this process was itself started under rocprofv3 / rocprof (its tool library is preloaded and has
+    initialised the GPU): starting another profiler from here would exec through processes that hold the GPU."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ)
+
+
+def clean_child_env():
+    """Environment of the profiler children: nothing of an outer profiler (LD_PRELOAD, ROCP* / ROCPROF*) is handed down."""
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_"))}
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
 def measure_traffic(args):
     """(bytes per launch, note). FETCH_SIZE and WRITE_SIZE in separate passes; units are KiB; FETCH_SIZE counts half of a
     wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section) - doubled here."""
+    if under_profiler():
+        return None, "not measured: this process already runs under a profiler (no nested rocprofv3)"
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -119,7 +137,7 @@ def measure_traffic(args):
                    "--pmc-child", "--species", str(args.species), "--reactions", str(args.reactions), "--batch", str(args.batch),
                    "--steps", "4", "--warmup", "1"]
             try:
-                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                p = subprocess.run(cmd, cwd="/tmp", env=clean_child_env(), stdout=subprocess.PIPE,
                                    stderr=subprocess.STDOUT, timeout=300)
             except (subprocess.TimeoutExpired, OSError) as e:
                 return None, f"rocprofv3 --pmc {ctr}: {type(e).__name__}"
@@ -147,7 +165,7 @@ def main():
 
     import torch  # device memory, streams, torch.distributed: plumbing only (importing it makes no GPU call)
 
-    traffic, traffic_note = None, "not measured (--no-pmc, a child of the profiler, or N > 1)"
+    traffic, traffic_note = None, "not measured (--no-pmc, the counter-collecting child itself, or N > 1)"
     if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_child:
         traffic, traffic_note = measure_traffic(args)      # child processes; this process has not touched the GPU yet
 

@@ -96,6 +96,49 @@ int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k,
  * call only enqueues (no allocation, no synchronisation: graph-capturable). */
 int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const double* d_k, double* d_du, void* stream);
 
+/* ---- A2 in the library's own data layout ("library order"): the bandwidth path of the batched sweep --------------
+ * The reference evaluates its RHS one state at a time inside the integrator; the batched sweep (ensembles, flux
+ * analysis over sol.u) has no layout to inherit, so the library defines one in which ONE pass over a state's rate
+ * constants needs random access to on-chip memory only (kinetica_jl_amd/csrc/tiled.hpp):
+ *   species   [ hubs | window 0 | window 1 | ... ]   (the caller's order when the state fits on-chip memory, N <= 10 000)
+ *   reactions every reaction next to its exact reverse, grouped by window: a k row has k_len = 2 x records doubles,
+ *             reaction r at slot_of_reaction[r], 0.0 in the reverse slot of a reaction without one.
+ * KIN_ERR_UNSUPPORTED (from every call of this block) when the network has no such layout: more than two product
+ * molecules in a reaction, or rarely referenced species that do not fall apart into window-sized groups. */
+/* k_len; species_of_lib[N] (library position -> species id, + index_base); slot_of_reaction[R] (+ index_base);
+ * species_identity = 1 when the library species order is the caller's; info[6] = hubs, windows, records, on-chip
+ * entries, split-accumulator entries, workgroup size. Any pointer may be NULL. */
+int kin_lib_layout(kin_network* h, int index_base, int64_t* k_len, int64_t* species_of_lib, int64_t* slot_of_reaction,
+                   int32_t* species_identity, int64_t* info);
+/* The same layout computed on the host alone (no device, no handle): what the library-order tables contain, for tools
+ * and for tests that replay the sweep's arithmetic on the CPU. `hubs` = 0 lets the library choose. info[8] = hubs,
+ * windows, records, on-chip entries, split-accumulator entries, workgroup size, first window entry, iteration rows;
+ * rec[records] = packed 64-bit records (four 14-bit on-chip labels with fixed roles + 3 flag bits at bit 56),
+ * rowtab[2 x rows], seg_q[windows + 1], win_off / win_cnt[windows], copy_src[copies]. Call once with NULL arrays for
+ * the sizes. */
+int kin_lib_layout_host(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr, const int64_t* reac_idx,
+                        const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
+                        int index_base, int hubs, int64_t* info, int64_t* species_of_lib, int64_t* slot_of_reaction,
+                        uint64_t* rec, int32_t* rowtab, int32_t* seg_q, int32_t* win_off, int32_t* win_cnt, int32_t* copy_src);
+/* Layout conversions on device buffers (each a coalesced write with a gather on the source side; enqueue only):
+ * states u[b][N] caller order <-> library order, rate constants k[b][R] -> k_lib[b][k_len]. */
+int kin_states_to_lib_dev(kin_network* h, int64_t B, const double* d_in, double* d_out, void* stream);
+int kin_states_from_lib_dev(kin_network* h, int64_t B, const double* d_in, double* d_out, void* stream);
+int kin_rates_to_lib_dev(kin_network* h, int64_t B, const double* d_k, double* d_k_lib, void* stream);
+/* calculate_discrete_rates (solve_utils.jl:91-109) written directly in library order: d_out[s][k_len] (device). */
+int kin_rate_table_lib_dev(kin_network* h, const double* T, int64_t n_stops, double* d_out);
+/* The sweep: du_lib[b] = f(u_lib[b]; k) for b < B, device buffers in library order. Exactly one of d_k_lib
+ * (k_lib[b][k_len], 16-byte aligned) and d_T (B temperatures) is non-NULL; with d_T the rate constants are formed
+ * inside the sweep from the Arrhenius parameters - no k stream at all (SURVEY 8(d) M1'; the reference's continuous
+ * path inlines k(T(t)) into every species ODE the same way, methods.jl:389-419 with calculator.jl:223-226).
+ * HBM traffic per state: k_lib row (or nothing) + u row in, du row out. Enqueue only. */
+int kin_rhs_tiled_dev(kin_network* h, int64_t B, const double* d_u_lib, const double* d_k_lib, const double* d_T,
+                      double* d_du_lib, void* stream);
+/* The temperature form on states in the CALLER's species order: u[b][N], T[b], du[b][N] (device). When the library
+ * species order differs (species_identity == 0) the call converts the layout on the way in and out (16 N bytes per
+ * state each way, workspace grown on demand). */
+int kin_rhs_batched_T_dev(kin_network* h, int64_t B, const double* d_u, const double* d_T, double* d_du, void* stream);
+
 /* ---- A3: analytic sparse Jacobian ---------------------------------------------------- */
 /* Replaces ODEProblem(...; jac=true, sparse=true) (methods.jl:157-158): pattern (CSR,
  * sorted columns, diagonal always present) and values for the current rates. The reference

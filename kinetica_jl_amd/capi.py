@@ -27,6 +27,8 @@ SYMBOLS = [
     "kin_integrator_state",
     "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version", "kin_solution_dot", "kin_rate_table_rows",
     "kin_solution_max_dev", "kin_rate_table_dev", "kin_rhs_block_dev",
+    "kin_lib_layout", "kin_lib_layout_host", "kin_states_to_lib_dev", "kin_states_from_lib_dev", "kin_rates_to_lib_dev", "kin_rate_table_lib_dev",
+    "kin_rhs_tiled_dev", "kin_rhs_batched_T_dev",
 ]
 
 
@@ -98,6 +100,13 @@ def lib():
         L.kin_solution_copy.argtypes = [c_void_p, PD, PD]
         L.kin_solution_max.argtypes = [c_void_p, PD]
         L.kin_newton_solve.argtypes = [c_void_p, c_double, PD, PD, PD]
+        L.kin_lib_layout.argtypes = [c_void_p, c_int, P64, P64, P64, POINTER(c_int32), P64]
+        L.kin_states_to_lib_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+        L.kin_states_from_lib_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+        L.kin_rates_to_lib_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+        L.kin_rate_table_lib_dev.argtypes = [c_void_p, PD, c_int64, c_void_p]
+        L.kin_rhs_tiled_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.kin_rhs_batched_T_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         L.kin_device_count.argtypes = [POINTER(c_int)]
         L.kin_set_device.argtypes = [c_int]
         _lib = L
@@ -120,6 +129,31 @@ def device_count():
     n = c_int(0)
     lib().kin_device_count(ctypes.byref(n))
     return n.value
+
+
+def lib_layout_host(net, hubs=0):
+    """The tiled sweep's library order of a FlatNetwork, computed on the host (no device): dict of the layout tables."""
+    L = lib()
+    arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (net.reac_ptr, net.reac_idx, net.reac_sto, net.prod_ptr,
+                                                              net.prod_idx, net.prod_sto)]
+    P32, PU64 = POINTER(c_int32), POINTER(ctypes.c_uint64)
+    L.kin_lib_layout_host.argtypes = [c_int64, c_int64] + [POINTER(c_int64)] * 6 + [c_int, c_int, POINTER(c_int64), POINTER(c_int64),
+                                                                                  POINTER(c_int64), PU64, P32, P32, P32, P32, P32]
+    info = np.zeros(8, np.int64)
+    head = [int(net.n_species), int(net.n_reactions)] + [_p64(a) for a in arrs] + [0, int(hubs), _p64(info)]
+    st = L.kin_lib_layout_host(*head, None, None, None, None, None, None, None, None)
+    if st != KIN_OK:
+        raise KineticaHipError(st, "network has no tiled layout")
+    h, T, P, E, n_copy, BS, wbase, Q = [int(x) for x in info]
+    sp = np.empty(net.n_species, np.int64); slot = np.empty(net.n_reactions, np.int64)
+    rec = np.empty(max(P, 1), np.uint64); rowtab = np.empty(max(2 * Q, 1), np.int32); seg_q = np.empty(T + 1, np.int32)
+    woff = np.empty(T, np.int32); wcnt = np.empty(T, np.int32); copy_src = np.empty(max(n_copy, 1), np.int32)
+    i32 = lambda a: a.ctypes.data_as(P32)
+    st = L.kin_lib_layout_host(*head, _p64(sp), _p64(slot), rec.ctypes.data_as(PU64), i32(rowtab), i32(seg_q), i32(woff), i32(wcnt),
+                               i32(copy_src))
+    assert st == KIN_OK
+    return dict(h=h, T=T, P=P, E=E, n_copy=n_copy, BS=BS, wbase=wbase, Q=Q, species_of_lib=sp, slot_of_reaction=slot,
+                rec=rec[:P], rowtab=rowtab[:2 * Q].reshape(Q, 2), seg_q=seg_q, win_off=woff, win_cnt=wcnt, copy_src=copy_src[:n_copy])
 
 
 def arrhenius_eval(Ea, A, T, k_max=None, t_mult=1.0):
@@ -218,6 +252,41 @@ class HipNetwork:
         """Device pointers (ints), state-major u[b][N], k[b][R] or 0, du[b][N]; only enqueues."""
         self._chk(lib().kin_rhs_batched_dev(self._h, int(B), c_void_p(d_u), c_void_p(d_k) if d_k else None,
                                             c_void_p(d_du), c_void_p(stream) if stream else None))
+
+    # --- library order (tiled sweep) --------------------------------------------------------
+    def lib_layout(self):
+        """dict(k_len, species_of_lib[N], slot_of_reaction[R], identity, hubs, windows, records, entries, copies, block)."""
+        k_len, ident = c_int64(0), c_int32(0)
+        sp = np.empty(self.n, np.int64)
+        slot = np.empty(self.nr, np.int64)
+        info = np.zeros(6, np.int64)
+        self._chk(lib().kin_lib_layout(self._h, 0, ctypes.byref(k_len), _p64(sp), _p64(slot), ctypes.byref(ident), _p64(info)))
+        return dict(k_len=k_len.value, species_of_lib=sp, slot_of_reaction=slot, identity=bool(ident.value), hubs=int(info[0]),
+                    windows=int(info[1]), records=int(info[2]), entries=int(info[3]), copies=int(info[4]), block=int(info[5]))
+
+    def states_to_lib_dev(self, B, d_in, d_out, stream=0):
+        self._chk(lib().kin_states_to_lib_dev(self._h, int(B), c_void_p(d_in), c_void_p(d_out), c_void_p(stream) if stream else None))
+
+    def states_from_lib_dev(self, B, d_in, d_out, stream=0):
+        self._chk(lib().kin_states_from_lib_dev(self._h, int(B), c_void_p(d_in), c_void_p(d_out), c_void_p(stream) if stream else None))
+
+    def rates_to_lib_dev(self, B, d_k, d_k_lib, stream=0):
+        self._chk(lib().kin_rates_to_lib_dev(self._h, int(B), c_void_p(d_k), c_void_p(d_k_lib), c_void_p(stream) if stream else None))
+
+    def rate_table_lib_dev(self, T_stops, d_out):
+        """Rate table for T_stops in library order straight into a device buffer [len(T_stops)][k_len]."""
+        T_stops = _f64(T_stops)
+        self._chk(lib().kin_rate_table_lib_dev(self._h, _pd(T_stops), len(T_stops), c_void_p(d_out)))
+
+    def rhs_tiled_dev(self, B, d_u_lib, d_du_lib, d_k_lib=0, d_T=0, stream=0):
+        """Batched RHS in library order; exactly one of d_k_lib / d_T (device pointers as ints); only enqueues."""
+        self._chk(lib().kin_rhs_tiled_dev(self._h, int(B), c_void_p(d_u_lib), c_void_p(d_k_lib) if d_k_lib else None,
+                                          c_void_p(d_T) if d_T else None, c_void_p(d_du_lib), c_void_p(stream) if stream else None))
+
+    def rhs_batched_T_dev(self, B, d_u, d_T, d_du, stream=0):
+        """Batched RHS on caller-order states with rate constants formed in the sweep from T[b]; only enqueues."""
+        self._chk(lib().kin_rhs_batched_T_dev(self._h, int(B), c_void_p(d_u), c_void_p(d_T), c_void_p(d_du),
+                                              c_void_p(stream) if stream else None))
 
     def jac_pattern(self, index_base=0):
         nnz = c_int64(0)

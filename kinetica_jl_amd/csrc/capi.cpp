@@ -28,12 +28,12 @@ void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, dou
       launch_segsum(rhs_plan.view(), SEG_COEF_SET, rate.p, d_du + b * host.N, SegExtra{}, s);
     }
   } else if (host.big_H > 0) {
-    big_scratch.alloc((size_t)launch_sweep_big_grid(B) * (size_t)(host.N - host.big_H + host.n_pairs()));
-    launch_sweep_big(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, (int32_t)host.big_tail_ptr.size() - 1,
+    big_scratch.alloc((size_t)std::min<int64_t>(B, n_cu) * (size_t)(host.N - host.big_H + host.n_pairs()));
+    launch_sweep_big(n_cu, host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.big_H, (int32_t)host.big_tail_ptr.size() - 1,
                      big_rec8.p, big_rec.p, big_expl.p, (int32_t)host.big_expl.size(), sweep_k.p, big_spec.p, big_tptr.p, big_tent.p,
                      big_scratch.p, d_u, d_k, k.p, d_du, host.big_tail_by_species, s);
   } else
-    launch_sweep(host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.pairs_block, sweep_rec.p, sweep_k.p,
+    launch_sweep(n_cu, host.N, host.R, host.n_pairs(), B, host.pairs_adjacent, host.pairs_block, sweep_rec.p, sweep_k.p,
                  host.pair_rec64.empty() ? nullptr : sweep_rec64.p, sweep_copy.p, (int)host.sweep_copy_species.size(),
                  host.gen_rec8.empty() ? nullptr : gen_rec8.p, gen_expl.p, (int)host.gen_expl.size(), d_u, d_k, k.p, d_du, s);
 }
@@ -43,7 +43,9 @@ void kin_network::jac_dev(const double* d_u, double* d_vals) {
   launch_segsum(jac_plan.view(), SEG_COEF_SET, dr.p, d_vals, SegExtra{}, stream);
 }
 
-#define KIN_TRY(h) try {
+// every entry point runs on the handle's own device (the one current at kin_network_create), whatever the calling
+// thread's current device is: K handles on K host threads can share one GPU or sit on different ones
+#define KIN_TRY(h) try { if (h) KIN_HIP(hipSetDevice((h)->device));
 #define KIN_CATCH(h)                                                        \
   }                                                                         \
   catch (const KinError& e) {                                               \
@@ -90,6 +92,8 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
       throw KinError(ERR_DEVICE, "no HIP device available (libkinetica_hip has no CPU fallback)");
     h = new kin_network();
     h->host = std::move(H);
+    KIN_HIP(hipGetDevice(&h->device));
+    KIN_HIP(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     KIN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const NetworkHost& N = h->host;
     hipStream_t s = h->stream;
@@ -164,6 +168,7 @@ int kin_set_arrhenius(kin_network* h, const double* Ea, const double* A, double 
   h->k_max = h->has_kmax ? k_max : 1.0;
   h->t_mult = t_mult;
   h->has_arrhenius = true;
+  h->t_par_valid = false;
   KIN_CATCH(h)
 }
 

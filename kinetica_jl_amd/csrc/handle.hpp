@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "network.hpp"
+#include "tiled.hpp"
 
 namespace kin { struct Solver; struct IntegratorState; }
 
@@ -40,6 +41,17 @@ struct kin_network {
 
   // batched sweep workspace
   kin::DevBuf<double> b_u, b_k, b_du;
+
+  // tiled sweep in library order (tiled.hpp, tiled_api.cpp): built at the first call that needs it
+  kin::TiledHost tiled;
+  bool tiled_tried = false;
+  kin::DevBuf<uint32_t> t_rec;
+  kin::DevBuf<int32_t> t_rowtab, t_segq, t_woff, t_wcnt, t_copy, t_kf, t_kr, t_rxn_of_slot, t_spec_of_lib, t_lib_of_spec;
+  kin::DevBuf<double> t_par, t_T, t_u, t_du;   // Arrhenius parameters per record (4 doubles), temperatures, layout scratch
+  bool t_par_valid = false;
+
+  // the device this handle lives on (the one current at kin_network_create) and its compute units
+  int device = 0, n_cu = 0;
 
   // solver + stored solution (solver.cpp)
   std::unique_ptr<kin::Solver> solver;

@@ -4,6 +4,8 @@
 // wave-uniform (scalar) index loads, fixed summation order and enough waves in flight.
 #include "kernels.hpp"
 
+#include "exp_tab.hpp"
+
 #include <algorithm>
 
 namespace kin {
@@ -242,47 +244,7 @@ __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __r
   k[i] = arrhenius_one(Ea[i], A[i], 8.314462618 * T, has_kmax, k_max, t_mult);
 }
 
-// Table variant without IEEE divisions (the table kernel is FP64-VALU bound: with two full divisions and the library exp
-// per element it ran at 2.0 ms for 14001 x 50000, against a 1.0 ms pure-store floor). Ea/RT is a multiply by the row's
-// reciprocal plus one FMA residual correction; the cap 1/(1/k_max + 1/k_r) is evaluated in exactly that form,
-// 1/k_r = exp(+Ea/RT) / (A N_A t_mult), with v_rcp_f64 and two Newton steps - an overflowing exp gives k = 0, the limit
-// of the reference formula. Deviation from the two-division form: <= (2 |Ea/RT| + 8) * 2^-53 relative (one ulp in the
-// argument of exp is amplified by |Ea/RT|), the bound the parity test applies element by element.
-// Table-driven exp for the rate table (round 2): exp(x) = 2^m * T[j] * e^r with n = rint(x * 512/ln 2) = 512 m + j,
-// r = x - n ln2/512 (two-part constant, n * hi exact: hi has 31 significant bits, |n| < 2^21 after the clamp),
-// |r| <= ln2/1024 = 6.8e-4, e^r - 1 = r (1 + r (1/2 + r (1/6 + r/24))) (remainder r^5/120 < 1.3e-18 relative),
-// T[j] = 2^(j/512) correctly rounded (exp2_tab.inc), kept in LDS. 11 FP64 operations instead of the 19 of exp_lean
-// (degree-13 polynomial): the table kernel is FP64-VALU bound under sustained load. <= 1 ulp.
-__device__ const double kExp2Tab[512] = {
-#include "exp2_tab.inc"
-};
-
-__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ tab_s) {
-  const double n = rint(x * 0x1.71547652b82fep+9);
-  double r = fma(n, -0x1.62e42fec00000p-10, x);
-  r = fma(n, -0x1.d1cf79abc9e3bp-41, r);
-  const int ni = (int)n;
-  const double T = tab_s[ni & 511];
-  double p = fma(r, 1.0 / 24.0, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  return ldexp(fma(T, p * r, T), ni >> 9);
-}
-
-// c = A N_A t_mult, inv_c = 1 / c
-__device__ __forceinline__ double arrhenius_fast(double Ea, double c, double inv_c, double RT, double inv_RT, int has_kmax,
-                                                 double inv_kmax, const double* __restrict__ tab_s) {
-  double q = Ea * inv_RT;
-  q = fma(fma(-q, RT, Ea), inv_RT, q);
-  q = fmin(q, 800.0);                                     // e^800 overflows anyway; keeps n inside the table arithmetic
-  if (!has_kmax) return c * exp_tab(-q, tab_s);
-  const double x = fma(inv_c, exp_tab(q, tab_s), inv_kmax);     // 1/k_max + 1/k_r
-  double y = __builtin_amdgcn_rcp(x);
-  y = fma(fma(-x, y, 1.0), y, y);
-  y = fma(fma(-x, y, 1.0), y, y);
-  return x < 1e300 ? y : 0.0;
-}
-
+// (table-driven exp and the division-free Arrhenius of the table kernels: exp_tab.hpp)
 // table[s][r]; one thread produces two consecutive reactions (16-byte stores), grid.y walks
 // time stops so that each workgroup keeps its (Ea, A N_A t_mult) pairs in registers across
 // TABLE_ROWS_PER_BLOCK rows; the rows' R T and 1 / (R T) are computed once per workgroup.
@@ -873,12 +835,6 @@ __global__ __launch_bounds__(1024) void sweep_big_kernel(int N, int R, int P, in
   }
 }
 
-int launch_sweep_big_grid(int64_t B) {
-  static int n_cu = 0;
-  if (!n_cu) { int dev = 0; hipDeviceProp_t pr; KIN_HIP(hipGetDevice(&dev)); KIN_HIP(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount; }
-  return (int)std::min<int64_t>(B, n_cu);
-}
-
 template <bool ADJ>
 static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int n_tail_tiles, const void* rec8, const void* rec,
                                const int32_t* expl, int n_expl, const void* pair_k, const int32_t* spec_of_label,
@@ -891,13 +847,13 @@ static void launch_sweep_big_t(int grid, int N, int R, int P, int B, int H, int 
                      tail_ptr, (const uint2*)tail_ent, scratch, u, k_b, k_1, du, by_species);
 }
 
-// `scratch` holds launch_sweep_big_grid(B) rows of (N - H) + P doubles
-void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
+// `scratch` holds min(B, n_cu) rows of (N - H) + P doubles; n_cu = compute units of the handle's device
+void launch_sweep_big(int n_cu, int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
                       const void* rec, const int32_t* expl, int32_t n_expl, const void* pair_k, const int32_t* spec_of_label,
                       const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
                       const double* k_1, double* du, bool tail_by_species, hipStream_t s) {
   if (B == 0) return;
-  const int grid = launch_sweep_big_grid(B);
+  const int grid = (int)std::min<int64_t>(B, n_cu);
   const bool adj = adjacent && ((((uintptr_t)(k_b ? k_b : k_1)) & 15) == 0);
   if (adj) launch_sweep_big_t<true>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, tail_by_species ? 1 : 0, s);
   else launch_sweep_big_t<false>(grid, (int)N, (int)R, (int)P, (int)B, H, n_tail_tiles, rec8, rec, expl, n_expl, pair_k, spec_of_label, tail_ptr, tail_ent, scratch, u, k_b, k_1, du, tail_by_species ? 1 : 0, s);
@@ -913,17 +869,10 @@ static void launch_sweep_t(int grid, size_t smem, int N, int R, int P, int B, in
                      (const SweepRec*)rec, (const int2*)pair_k, u, k_b, k_1, du);
 }
 
-void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
+void launch_sweep(int n_cu, int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
                   const void* rec64, const int32_t* copy_species, int n_copy, const void* gen_rec8, const int32_t* gen_expl,
                   int n_gen_expl, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s) {
   if (B == 0) return;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0; hipDeviceProp_t pr;
-    KIN_HIP(hipGetDevice(&dev));
-    KIN_HIP(hipGetDeviceProperties(&pr, dev));
-    n_cu = pr.multiProcessorCount;
-  }
   const size_t lds_max = 160 * 1024;
   const int grid = (int)std::min<int64_t>(B, n_cu);
   // the double2 fast path also needs 16-byte aligned rows of k: R even (checked by the host) and an aligned base

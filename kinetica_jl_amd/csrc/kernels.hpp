@@ -53,14 +53,14 @@ void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const doubl
 
 // batched sweep over B states, state-major layouts (see kin_rhs_batched_dev); rec = packed 16-byte records
 // `adjacent`: pair p = reactions (2p, 2p+1); `block`: pair p = reactions (p, P+p) (forwards first, reverses behind)
-void launch_sweep(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
+// n_cu: compute units of the device the handle lives on (per handle, not cached per process)
+void launch_sweep(int n_cu, int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, bool block, const void* rec, const void* pair_k,
                   const void* rec64, const int32_t* copy_species, int n_copy, const void* gen_rec8, const int32_t* gen_expl,
                   int n_gen_expl, const double* u, const double* k_b, const double* k_1, double* du, hipStream_t s);
 
 // large-N sweep (state too large for LDS): hubs in LDS, tail via a per-workgroup scratch row and tail-entry lists;
-// `scratch` holds launch_sweep_big_grid(B) rows of (N - H) + P doubles
-int launch_sweep_big_grid(int64_t B);
-void launch_sweep_big(int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
+// `scratch` holds min(B, n_cu) rows of (N - H) + P doubles
+void launch_sweep_big(int n_cu, int64_t N, int64_t R, int64_t P, int64_t B, bool adjacent, int32_t H, int32_t n_tail_tiles, const void* rec8,
                       const void* rec, const int32_t* expl, int32_t n_expl, const void* pair_k, const int32_t* spec_of_label,
                       const int32_t* tail_ptr, const void* tail_ent, double* scratch, const double* u, const double* k_b,
                       const double* k_1, double* du, bool tail_by_species, hipStream_t s);

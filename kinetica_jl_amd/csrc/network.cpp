@@ -85,6 +85,7 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
   NetworkHost H;
   H.N = N; H.R = R;
   H.x0.assign(R, -1); H.x1.assign(R, -1);
+  H.y0.assign(R, -1); H.y1.assign(R, -1);
   H.slot_sp.assign(4 * R, -1); H.slot_co.assign(R, 0);
 
   struct Ent { int32_t rxn; float coef; };
@@ -112,12 +113,19 @@ NetworkHost compile_network(int64_t N, int64_t R, const int64_t* reac_ptr, const
       net[(int32_t)s] -= (int)st;
     }
     if (nops == 0) fail(ERR_UNSUPPORTED, "reaction " + std::to_string(r) + " has no reactants");
+    int nprod = 0;
     for (int64_t p = b0; p < b1; p++) {
       int64_t s = prod_idx[p] - index_base, st = prod_sto[p];
       if (s < 0 || s >= N) fail(ERR_INVALID_ARG, "product species index out of range in reaction " + std::to_string(r));
       if (st < 1 || st > 100) fail(ERR_INVALID_ARG, "product stoichiometry out of range");
       net[(int32_t)s] += (int)st;
+      // product instances, expanded by stoichiometry (fixed-role records of the tiled sweep, tiled.cpp)
+      for (int64_t q = 0; q < st; q++, nprod++) {
+        if (nprod == 0) H.y0[r] = (int32_t)s;
+        else if (nprod == 1) H.y1[r] = (int32_t)s;
+      }
     }
+    if (nprod > 2) H.products_le2 = false;
     H.x0[r] = ops[0];
     H.x1[r] = nops == 2 ? ops[1] : -1;
     // update slots

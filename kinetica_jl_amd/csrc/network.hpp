@@ -63,6 +63,10 @@ struct NetworkHost {
   int64_t N = 0, R = 0;
   // per reaction: rate operands, rate = k * u[x0] * (x1 >= 0 ? u[x1] : 1)   (2A: x0 == x1)
   std::vector<int32_t> x0, x1;
+  // per reaction: product instances expanded by stoichiometry (2C is listed as C, C); -1 = none. products_le2: every
+  // reaction has at most two of them (the reference's max_molecularity = 2 holds for both sides, network.jl:275-279)
+  std::vector<int32_t> y0, y1;
+  bool products_le2 = true;
   // per reaction: up to 4 update slots (distinct species with non-zero net stoichiometry)
   std::vector<int32_t> slot_sp;   // 4*R, species id or -1
   std::vector<int32_t> slot_co;   // R, four signed bytes packed

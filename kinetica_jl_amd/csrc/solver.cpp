@@ -850,6 +850,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   hipStream_t s = h->stream;
   S.st = kin_stats{};
   S.invalidate_lu();   // the LU cache lives within one solve: identical calls give identical results
+  S.accept_pending = false; S.accept_copy = nullptr;   // nothing of an earlier call (its solution buffer may be gone)
   S.explicit_mode = explicit_solver;
   S.sync_wait_s = 0.0;
   std::fill(S.iter_hist, S.iter_hist + 8, 0);
@@ -1031,7 +1032,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
             }
             S.select_order();
           }
-          if (failed) break;
+          // a failed attempt leaves the accept of its last good step (and the copy of that state into the solution
+          // buffer, whose time is already recorded) pending: it must not outlive the buffers it points into
+          if (failed) { S.flush_accept(); break; }
           // state at the segment end = D[0]
           KIN_HIP(hipMemcpyAsync(S.y.p, S.state_ptr(), N * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
@@ -1067,6 +1070,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
       h->sol_t.resize(times_at_chunk_start);
     }
   }
+  S.flush_accept();
   KIN_HIP(hipStreamSynchronize(s));
   S.pre_attempt = nullptr;   // the lambda captures locals of this call
   S.st.final_abstol = abstol;
@@ -1150,6 +1154,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
   hipStream_t s = h->stream;
   S.st = kin_stats{};
   S.invalidate_lu();
+  S.accept_pending = false; S.accept_copy = nullptr;
   S.explicit_mode = false;
   S.ban_negatives = p.ban_negatives != 0;
   S.dtmin = resolve_dtmin(p);
@@ -1207,9 +1212,9 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
     }
     const double seg_len = I.seg_end - I.t_seg;
     StepStatus ss = S.step(seg_len);
-    if (S.iters_left < 0) { I.retcode = KIN_RETCODE_MAXITERS; break; }
-    if (ss == STEP_DT_MIN) { I.retcode = KIN_RETCODE_DTLESSTHANMIN; break; }
-    if (ss == STEP_UNSTABLE) { I.retcode = KIN_RETCODE_UNSTABLE; break; }
+    if (S.iters_left < 0) { I.retcode = KIN_RETCODE_MAXITERS; S.flush_accept(); break; }
+    if (ss == STEP_DT_MIN) { I.retcode = KIN_RETCODE_DTLESSTHANMIN; S.flush_accept(); break; }
+    if (ss == STEP_UNSTABLE) { I.retcode = KIN_RETCODE_UNSTABLE; S.flush_accept(); break; }
     S.select_order();
     taken++;
     if (S.t >= seg_len) {   // segment finished: state = D[0]; switch the rates at a tstop

@@ -1,0 +1,60 @@
+// "Library order" of a network for the tiled batched sweep (tiled_kernels.hip): a species order and a reaction order
+// chosen by the library so that ONE pass over a state's rate constants needs random access to LDS only.
+//
+//   species   [ hubs | window 0 | window 1 | ... ]   hubs = the h most referenced species, resident in LDS (u and du)
+//                                                      for the whole state; a window = a set of tail species whose u / du
+//                                                      share the rest of the LDS while "their" records are processed
+//   records   [ segment 0 | segment 1 | ... ]         record = a reaction and (if the network has it) its exact reverse;
+//                                                      segment s holds the records whose tail species all lie in window s
+//
+// Such a partition exists whenever the graph "tail species that occur in the same record" falls apart into components
+// smaller than a window: tail species are exactly the rarely referenced ones, so for sparse CRNs it does (the synthetic
+// Zipf CRN at 50k species: largest component 282 species with 5 000 hubs, 17 with 10 000). A network whose tail does
+// not decompose is reported as not tileable and keeps the hub / net-rate-scratch kernel (kernels.hip: sweep_big_kernel).
+// A state that fits LDS entirely (N <= 10 000) is the special case h = N, one segment, species order = the caller's.
+//
+// Rate constants in library order: k_lib[2 p] / k_lib[2 p + 1] = forward / reverse rate constant of record p (0 where a
+// reaction has no reverse). The rate-table kernel writes this layout directly; Arrhenius parameters are stored in it too
+// for the sweep that forms its rate constants itself from the states' temperatures (SURVEY 8(d) M1').
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "network.hpp"
+
+namespace kin {
+
+constexpr int TILED_DUMMY = 64;        // per-lane dummy LDS entries (u = 1, du discarded) for unused record fields
+constexpr int TILED_COPIES = 7;        // extra accumulator entries per split hub (copy 0 = the species' own entry)
+constexpr int TILED_BATCH = 4;         // record rows a thread processes together (all LDS reads, then all atomics)
+constexpr int TILED_GROUP = 2 * TILED_BATCH;   // rows per segment are padded (in iteration space only) to this
+constexpr int TILED_EXP_TAB = 128;             // entries of the exp table the temperature form keeps in LDS (exp_tab.hpp)
+constexpr int TILED_LDS_ENTRIES = 10176;       // entries per LDS array (u, du): (2 x 10176 + 128) x 8 B = 160 kB exactly
+
+struct TiledHost {
+  bool ok = false;
+  std::string why;                 // why the network is not tileable
+  int32_t N = 0, R = 0, P = 0;     // species, reactions, records
+  int32_t BS = 1024;               // workgroup size the layout was built for (a record row = BS records)
+  int32_t h = 0;                   // hubs = library species [0, h), LDS entries [0, h)
+  int32_t n_copy = 0;              // split-accumulator entries, LDS entries [h + 64, h + 64 + n_copy)
+  int32_t wbase = 0;               // first LDS entry of the window region
+  int32_t E = 0;                   // LDS entries per array
+  int32_t T = 1;                   // segments (windows); T == 1 && win_cnt[0] == 0: no windows at all
+  bool identity = true;            // library species order == caller's
+  std::vector<int32_t> species_of_lib, lib_of_species;   // N each
+  std::vector<int32_t> win_off, win_cnt;                 // T each: window s = library species [win_off, win_off + win_cnt)
+  std::vector<int32_t> copy_src;   // n_copy: library index (= LDS entry) of the species behind each copy entry
+  std::vector<uint32_t> rec;       // 2 words per record: four 14-bit LDS labels with fixed roles + flags in bits 56.. (tiled_kernels.hip)
+  std::vector<int32_t> kf, kr;     // P each: reaction ids of a record's forward / reverse reaction (kr = -1: none)
+  std::vector<int32_t> slot_of_reaction;   // R: position of reaction r's rate constant in a k_lib row
+  std::vector<int32_t> rowtab;     // 2 per iteration row: first record of the row (-1: padding row), records in it
+  std::vector<int32_t> seg_q;      // T + 1: iteration rows [seg_q[s], seg_q[s + 1]) belong to segment s (multiples of TILED_GROUP)
+  int64_t k_len() const { return 2 * (int64_t)P; }
+};
+
+// `bs`: workgroup size (256 / 512 / 1024). `h_force` > 0 fixes the hub count (tests).
+TiledHost build_tiled(const NetworkHost& H, int bs, int h_force = 0);
+
+}  // namespace kin

@@ -1,0 +1,308 @@
+// Tiled batched RHS sweep (gfx950): B states in the library order of tiled.hpp, ONE pass over each state's rate
+// constants, every random access in LDS, every global access a coalesced stream:
+//   per state:   hubs' u            HBM -> LDS   (coalesced, prefetched during the previous state's last segment)
+//   per segment: window's u         HBM -> LDS   (coalesced, prefetched during the previous segment)
+//                records + k        streamed once, two batches of 4 record rows in flight per thread
+//                window's du        LDS -> HBM   (coalesced)
+//   per state:   hubs' du           LDS -> HBM
+// HBM traffic = the algorithmic one (k[b] + u[b] in, du[b] out; records and tables are shared by all states and stay
+// in L2 / Infinity Cache). A record is four 14-bit LDS labels with fixed roles (fields 0, 1 = reactant instances of the
+// forward reaction, fields 2, 3 = its product instances; net = kf u0 u1 - kr u2 u3, du[0,1] -= net, du[2,3] += net)
+// plus three flag bits that are equal for the 64 records a wavefront processes together: bit 56 = some record of the
+// group has a second reactant, bit 57 = ... a second product, bit 58 = nothing to do. A group without second reactants
+// skips that field's LDS read and ds_add_f64 altogether (3.1 instead of 4 fields per record on the synthetic CRNs).
+//
+// TMODE: no k stream at all - the rate constants are formed inside the sweep from the state's temperature and the
+// records' Arrhenius parameters (SURVEY 8(d) M1'; the reference's continuous-rate path inlines k(T(t)) into every
+// species ODE the same way, src/solving/methods.jl:389-419, calculator.jl:223-226).
+#include "tiled_kernels.hpp"
+
+#include "exp_tab.hpp"
+
+namespace kin {
+
+namespace {
+
+constexpr int UN = 10;   // doubles per thread of the staged-in set (hubs + window 0, or one window): E <= 10176 < 10 * 1024
+
+// rows per batch: 4 with a k stream (two batches = 8 rows of 16-byte loads in flight per thread cover the HBM latency);
+// 2 when the rate constants are computed (the parameters come from L2 and take twice the registers)
+template <bool TMODE> struct Batch;
+template <> struct Batch<false> { static constexpr int NB = 4; double2 k[NB]; uint2 w[NB]; };
+template <> struct Batch<true> { static constexpr int NB = 2; double4 p[NB]; uint2 w[NB]; };
+
+struct Labels { uint32_t l0, l1, l2, l3; };
+__device__ __forceinline__ Labels decode(uint2 w) {
+  return Labels{w.x & 0x3fffu, (w.x >> 14) & 0x3fffu, (w.x >> 28) | ((w.y & 0x3ffu) << 4), (w.y >> 10) & 0x3fffu};
+}
+
+}  // namespace
+
+template <int BS, bool TMODE>
+__global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, const double* __restrict__ u,
+                                                         const double* __restrict__ k_lib, const double* __restrict__ Tb,
+                                                         double* __restrict__ du) {
+  extern __shared__ double lds[];
+  double* du_s = lds;
+  double* u_s = lds + v.E;
+  const double* tab_s = lds + 2 * v.E;
+  const int tid = threadIdx.x;
+  const int N = v.N, h = v.h, wbase = v.wbase, T = v.T, Q = v.Q;
+  const size_t KL = 2 * (size_t)v.P;
+
+  for (int i = tid; i < v.E; i += BS) du_s[i] = 0.0;
+  if (tid < TILED_DUMMY) u_s[h + tid] = 1.0;
+  if (TMODE) for (int i = tid; i < TILED_EXP_TAB; i += BS) lds[2 * v.E + i] = kExp2Tab[i * (512 / TILED_EXP_TAB)];
+  const int csrc = tid < v.n_copy ? v.copy_src[tid] : -1;
+  // padding record of this lane: every field on the lane's dummy entry, "nothing to do" set
+  const uint64_t dl = (uint64_t)(h + (tid & 63));
+  const uint64_t ew = dl | (dl << 14) | (dl << 28) | (dl << 42) | (4ull << 56);
+  const uint2 EMPTY = {(uint32_t)ew, (uint32_t)(ew >> 32)};
+
+  // ---- the staged-in set of the next phase travels HBM -> registers while the current phase computes
+  double un[UN];
+  // hubs + window 0 of state bb (one concatenated range of h + win_cnt[0] entries)
+  auto load_state_head = [&](int bb) {
+    const double* ub = u + (size_t)bb * N;
+    const int c0 = v.win_cnt[0], o0 = v.win_off[0];
+#pragma unroll
+    for (int x = 0; x < UN; x++) {
+      const int e = tid + x * BS;
+      un[x] = (bb < B && e < h + c0) ? ub[e < h ? e : o0 + (e - h)] : 0.0;
+    }
+  };
+  auto store_state_head = [&]() {
+    const int c0 = v.win_cnt[0];
+#pragma unroll
+    for (int x = 0; x < UN; x++) {
+      const int e = tid + x * BS;
+      if (e < h + c0) u_s[e < h ? e : wbase + (e - h)] = un[x];
+    }
+  };
+  auto load_window = [&](int bb, int s) {
+    const double* ub = u + (size_t)bb * N + v.win_off[s];
+    const int c = v.win_cnt[s];
+#pragma unroll
+    for (int x = 0; x < UN; x++) {
+      const int e = tid + x * BS;
+      un[x] = e < c ? ub[e] : 0.0;
+    }
+  };
+  auto store_window = [&](int s) {
+    const int c = v.win_cnt[s];
+#pragma unroll
+    for (int x = 0; x < UN; x++) {
+      const int e = tid + x * BS;
+      if (e < c) u_s[wbase + e] = un[x];
+    }
+  };
+
+  // ---- record / rate-constant queue: batches of TILED_BATCH rows, two batches in flight
+  int qb = blockIdx.x, qpos = 0;   // state and iteration row of the next batch to request
+  constexpr int NB = Batch<TMODE>::NB;
+  static_assert(TILED_GROUP % (2 * NB) == 0, "segments are padded to whole pairs of batches");
+  auto load_batch = [&](Batch<TMODE>& G) {
+    const bool live = qb < B && Q > 0;
+    const double* kb = TMODE ? nullptr : k_lib + (size_t)(live ? qb : 0) * KL;
+#pragma unroll
+    for (int x = 0; x < NB; x++) {
+      const int2 rt = live ? v.rowtab[qpos + x] : make_int2(-1, 0);
+      const bool ok = rt.x >= 0 && tid < rt.y;
+      const int p = rt.x + tid;
+      G.w[x] = ok ? v.rec[p] : EMPTY;
+      if constexpr (TMODE) G.p[x] = ok ? v.par[p] : make_double4(0.0, 0.0, 0.0, 0.0);
+      else G.k[x] = ok ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+    }
+    qpos += NB;
+    if (qpos >= Q) { qpos = 0; qb += gridDim.x; }
+  };
+
+  double RT = 1.0, inv_RT = 1.0;
+  auto consume = [&](const Batch<TMODE>& G) {
+    uint32_t fl[NB];
+    double uf[NB], ur[NB];
+#pragma unroll
+    for (int x = 0; x < NB; x++) {
+      fl[x] = __builtin_amdgcn_readfirstlane(G.w[x].y >> 24);
+      if (fl[x] & 4u) continue;
+      const Labels L = decode(G.w[x]);
+      uf[x] = u_s[L.l0];
+      if (fl[x] & 1u) uf[x] *= u_s[L.l1];
+      ur[x] = u_s[L.l2];
+      if (fl[x] & 2u) ur[x] *= u_s[L.l3];
+    }
+#pragma unroll
+    for (int x = 0; x < NB; x++) {
+      if (fl[x] & 4u) continue;
+      double kf, kr;
+      if constexpr (TMODE) {
+        kf = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].x, G.p[x].y, G.p[x].y, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
+        kr = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].z, G.p[x].w, G.p[x].w, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
+      } else {
+        kf = G.k[x].x; kr = G.k[x].y;
+      }
+      const double net = kf * uf[x] - kr * ur[x];
+      const Labels L = decode(G.w[x]);
+      __hip_atomic_fetch_add(du_s + L.l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (fl[x] & 1u) __hip_atomic_fetch_add(du_s + L.l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(du_s + L.l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (fl[x] & 2u) __hip_atomic_fetch_add(du_s + L.l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+
+  int b = blockIdx.x;
+  load_state_head(b);
+  double ucn = (csrc >= 0 && b < B) ? u[(size_t)b * N + csrc] : 0.0;
+  double Tn = (TMODE && b < B) ? Tb[b] : 1.0;
+  Batch<TMODE> G0, G1;
+  load_batch(G0);
+  load_batch(G1);
+
+  for (; b < B; b += gridDim.x) {
+    double* dub = du + (size_t)b * N;
+    const int bn = b + gridDim.x;
+    if (TMODE) { RT = 8.314462618 * Tn; inv_RT = 1.0 / RT; }
+    store_state_head();
+    if (csrc >= 0) u_s[h + TILED_DUMMY + tid] = ucn;
+    __syncthreads();
+    ucn = (csrc >= 0 && bn < B) ? u[(size_t)bn * N + csrc] : 0.0;
+    if (TMODE) Tn = bn < B ? Tb[bn] : 1.0;
+    for (int s = 0; s < T; s++) {
+      const bool last = s == T - 1;
+      if (last) load_state_head(bn); else load_window(b, s + 1);
+      for (int q = v.seg_q[s]; q < v.seg_q[s + 1]; q += 2 * NB) {
+        consume(G0);
+        load_batch(G0);
+        consume(G1);
+        load_batch(G1);
+      }
+      __syncthreads();
+      if (last && v.n_copy > 0) {   // fold the split accumulators back into their species
+        if (csrc >= 0) {
+          const double a = du_s[h + TILED_DUMMY + tid];
+          du_s[h + TILED_DUMMY + tid] = 0.0;
+          __hip_atomic_fetch_add(du_s + csrc, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+      }
+      // window s out (and re-zeroed); on the state's last segment the hubs too
+      {
+        const int c = v.win_cnt[s], o = v.win_off[s];
+        for (int i = tid; i < c; i += BS) { dub[o + i] = du_s[wbase + i]; du_s[wbase + i] = 0.0; }
+        if (last) for (int i = tid; i < h; i += BS) { dub[i] = du_s[i]; du_s[i] = 0.0; }
+      }
+      if (!last) {
+        store_window(s + 1);   // u_s of the window region is dead since the barrier above
+        __syncthreads();
+      }
+      // (after the last segment the next state's head is stored at the top of the loop, before its barrier)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// layout helpers: every kernel below is a coalesced write of the destination with a gather on the source side
+// ------------------------------------------------------------------------------------------------------------------
+// dst[b][j] = src[b][map[j]]  (map[j] < 0: 0.0)
+__global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n_dst, int64_t n_src, int B, const int32_t* __restrict__ map,
+                                                          const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_dst) return;
+  const int32_t m = map[j];
+  for (int b = blockIdx.y; b < B; b += gridDim.y) dst[(size_t)b * n_dst + j] = m >= 0 ? src[(size_t)b * n_src + m] : 0.0;
+}
+
+// par[p] = (Ea_f, X_f, Ea_r, X_r), X = 1 / (A N_A t_mult) when the calculator caps its rate constants (the sweep and the
+// table kernel evaluate 1 / (1/k_max + X e^q)), else A N_A t_mult. A missing reverse: a constant that makes k = 0.
+__global__ __launch_bounds__(256) void tiled_params_kernel(int P, const int32_t* __restrict__ kf, const int32_t* __restrict__ kr,
+                                                           const double* __restrict__ Ea, const double* __restrict__ A, int has_kmax,
+                                                           double t_mult, double4* __restrict__ par) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int f = kf[p], r = kr[p];
+  const double cf = A[f] * 6.02214076e23 * t_mult;
+  const double none = has_kmax ? __builtin_inf() : 0.0;
+  double4 o;
+  o.x = Ea[f]; o.y = has_kmax ? 1.0 / cf : cf;
+  o.z = r >= 0 ? Ea[r] : 0.0;
+  o.w = r >= 0 ? (has_kmax ? 1.0 / (A[r] * 6.02214076e23 * t_mult) : A[r] * 6.02214076e23 * t_mult) : none;
+  par[p] = o;
+}
+
+// rate table in library order: table[s][2 p], table[s][2 p + 1] = forward / reverse rate constant of record p at T[s]
+__global__ __launch_bounds__(256) void rate_table_lib_kernel(int P, int n_stops, const double4* __restrict__ par, int has_kmax,
+                                                             double inv_kmax, const double* __restrict__ T, double* __restrict__ table) {
+  constexpr int ROWS = 32;
+  __shared__ double rt_s[ROWS], irt_s[ROWS];
+  __shared__ double tab_s[512];
+  tab_s[threadIdx.x] = kExp2Tab[threadIdx.x];
+  tab_s[threadIdx.x + 256] = kExp2Tab[threadIdx.x + 256];
+  const int s0 = blockIdx.y * ROWS, s1 = min(n_stops, s0 + ROWS);
+  if ((int)threadIdx.x < s1 - s0) {
+    const double RT = 8.314462618 * T[s0 + threadIdx.x];
+    rt_s[threadIdx.x] = RT;
+    irt_s[threadIdx.x] = 1.0 / RT;
+  }
+  __syncthreads();
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const double4 q = par[p];
+  for (int s = s0; s < s1; s++) {
+    const double RT = rt_s[s - s0], inv_RT = irt_s[s - s0];
+    const double kf = arrhenius_fast(q.x, q.y, q.y, RT, inv_RT, has_kmax, inv_kmax, tab_s);
+    const double kr = arrhenius_fast(q.z, q.w, q.w, RT, inv_RT, has_kmax, inv_kmax, tab_s);
+    *reinterpret_cast<double2*>(table + ((size_t)s * P + p) * 2) = make_double2(kf, kr);
+  }
+}
+
+void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* map, const double* src, double* dst, hipStream_t s) {
+  if (n_dst == 0 || B == 0) return;
+  dim3 grid((unsigned)ceil_div(n_dst, 256), (unsigned)std::min<int64_t>(B, 1024));
+  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, s, n_dst, n_src, (int)B, map, src, dst);
+  KIN_HIP(hipGetLastError());
+}
+
+void launch_tiled_params(int P, const int32_t* kf, const int32_t* kr, const double* Ea, const double* A, int has_kmax,
+                         double t_mult, void* par, hipStream_t s) {
+  if (P == 0) return;
+  hipLaunchKernelGGL(tiled_params_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, s, P, kf, kr, Ea, A, has_kmax, t_mult,
+                     (double4*)par);
+  KIN_HIP(hipGetLastError());
+}
+
+void launch_rate_table_lib(int P, int64_t n_stops, const void* par, int has_kmax, double k_max, const double* T, double* table,
+                           hipStream_t s) {
+  if (P == 0 || n_stops == 0) return;
+  dim3 grid((unsigned)ceil_div(P, 256), (unsigned)ceil_div(n_stops, 32));
+  hipLaunchKernelGGL(rate_table_lib_kernel, grid, dim3(256), 0, s, P, (int)n_stops, (const double4*)par, has_kmax, 1.0 / k_max, T, table);
+  KIN_HIP(hipGetLastError());
+}
+
+template <int BS, bool TMODE>
+static void launch_tiled_t(const TiledView& v, int grid, size_t smem, int B, const double* u, const double* k_lib, const double* Tb,
+                           double* du, hipStream_t s) {
+  // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
+  KIN_HIP(hipFuncSetAttribute((const void*)tiled_sweep_kernel<BS, TMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((tiled_sweep_kernel<BS, TMODE>), dim3(grid), dim3(BS), smem, s, v, B, u, k_lib, Tb, du);
+}
+
+void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const double* u, const double* k_lib, const double* Tb,
+                        double* du, hipStream_t s) {
+  if (B == 0) return;
+  const bool tmode = k_lib == nullptr;
+  const size_t smem = ((size_t)2 * v.E + (tmode ? TILED_EXP_TAB : 0)) * 8;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / bs, (160 * 1024) / smem));
+  const int grid = (int)std::min<int64_t>(B, (int64_t)n_cu * per_cu);
+#define KIN_TILED_GO(BSZ)                                                                      \
+  do {                                                                                         \
+    if (tmode) launch_tiled_t<BSZ, true>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);          \
+    else launch_tiled_t<BSZ, false>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);               \
+  } while (0)
+  if (bs == 256) KIN_TILED_GO(256);
+  else if (bs == 512) KIN_TILED_GO(512);
+  else KIN_TILED_GO(1024);
+#undef KIN_TILED_GO
+  KIN_HIP(hipGetLastError());
+}
+
+}  // namespace kin

@@ -1,0 +1,32 @@
+// Device view and launchers of the tiled batched sweep (tiled_kernels.hip; layout: tiled.hpp).
+#pragma once
+#include "common.hpp"
+#include "tiled.hpp"
+
+namespace kin {
+
+struct TiledView {   // passed to the kernel by value
+  int N, P, h, n_copy, wbase, E, T, Q;   // Q = iteration rows per state
+  const uint2* rec;
+  const int2* rowtab;
+  const int32_t* seg_q;
+  const int32_t* win_off;
+  const int32_t* win_cnt;
+  const int32_t* copy_src;
+  const double4* par;      // Arrhenius parameters per record (TMODE and the library-order rate table)
+  int has_kmax;
+  double inv_kmax;
+};
+
+// Exactly one of k_lib (B x 2P rate constants in library order) and Tb (B temperatures, device) is non-null.
+// u, du: B x N in library species order. n_cu: compute units of the device the stream belongs to.
+void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const double* u, const double* k_lib, const double* Tb,
+                        double* du, hipStream_t s);
+// dst[b][j] = map[j] >= 0 ? src[b][map[j]] : 0 for b < B (rows of n_dst / n_src doubles): the layout conversions
+void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* map, const double* src, double* dst, hipStream_t s);
+void launch_tiled_params(int P, const int32_t* kf, const int32_t* kr, const double* Ea, const double* A, int has_kmax,
+                         double t_mult, void* par, hipStream_t s);
+void launch_rate_table_lib(int P, int64_t n_stops, const void* par, int has_kmax, double k_max, const double* T, double* table,
+                           hipStream_t s);
+
+}  // namespace kin

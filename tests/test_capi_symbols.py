@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "kinetica_hip.h")
 def _declared():
     text = open(os.path.join(ROOT, "include", "kinetica_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(kin_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(kin_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

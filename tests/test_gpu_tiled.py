@@ -1,0 +1,215 @@
+"""GPU parity of the tiled batched sweep (library order, kinetica_jl_amd/csrc/tiled_kernels.hip) through the C ABI:
+the k-stream form against the oracle's RHS, the temperature form (rate constants formed inside the sweep) against
+the oracle's RHS with the oracle's Arrhenius rate constants, the library-order rate table against the plain one."""
+import numpy as np
+import pytest
+import torch
+
+from kinetica_jl_amd import capi
+from kinetica_jl_amd.synth import from_lists, synthetic_crn
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+R_GAS = 8.314462618
+
+
+def _dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def _states(B, n, seed):
+    return 10.0 ** np.random.default_rng(seed).uniform(-12, 0, (B, n))
+
+
+def _tiled_k(h, U, K):
+    """du[b] through kin_rates_to_lib_dev / kin_states_to_lib_dev / kin_rhs_tiled_dev / kin_states_from_lib_dev."""
+    B, N = U.shape
+    lay = h.lib_layout()
+    d_u, d_k = _dev(U), _dev(K)
+    d_ul, d_kl = torch.empty_like(d_u), torch.empty((B, lay["k_len"]), dtype=torch.float64, device="cuda")
+    d_dul, d_du = torch.full_like(d_u, float("nan")), torch.full_like(d_u, float("nan"))
+    h.states_to_lib_dev(B, d_u.data_ptr(), d_ul.data_ptr())
+    h.rates_to_lib_dev(B, d_k.data_ptr(), d_kl.data_ptr())
+    h.rhs_tiled_dev(B, d_ul.data_ptr(), d_dul.data_ptr(), d_k_lib=d_kl.data_ptr())
+    h.states_from_lib_dev(B, d_dul.data_ptr(), d_du.data_ptr())
+    torch.cuda.synchronize()
+    # the conversions are permutations: checked against the layout the library reports
+    assert np.array_equal(d_ul.cpu().numpy(), U[:, lay["species_of_lib"]])
+    kl = np.zeros((B, lay["k_len"])); kl[:, lay["slot_of_reaction"]] = K
+    assert np.array_equal(d_kl.cpu().numpy(), kl)
+    return d_du.cpu().numpy(), lay
+
+
+def _check_against_oracle(net, du, U, K, rows, tol=TOL):
+    on = orc.OracleNetwork.from_flat(net)
+    worst = 0.0
+    for b in rows:
+        k = K[b] if K.ndim == 2 else K
+        ref, scale = on.rhs(k, U[b]), on.abs_rhs(k, U[b])
+        err = np.abs(du[b] - ref) / np.maximum(scale, 1e-300)
+        worst = max(worst, err.max())
+    assert worst <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("n,r,B", [(300, 1500, 7), (1000, 5000, 33), (3000, 15000, 9), (6000, 30000, 5)],
+                         ids=["300", "C2_1k", "3k_bs512", "6k_bs1024"])
+def test_k_stream_form_matches_oracle(n, r, B):
+    net, Ea, A = synthetic_crn(n, r)
+    h = capi.HipNetwork.from_flat(net)
+    U = _states(B, n, 1)
+    K = 10.0 ** np.random.default_rng(2).uniform(-3, 3, (B, r))
+    du, lay = _tiled_k(h, U, K)
+    assert lay["identity"] and lay["windows"] == 1
+    _check_against_oracle(net, du, U, K, range(B))
+    h.close()
+
+
+def test_windows_on_a_small_network(monkeypatch):
+    monkeypatch.setenv("KIN_TILED_ENTRIES", "1400")     # read when the handle builds its layout
+    net, Ea, A = synthetic_crn(3000, 15000)
+    h = capi.HipNetwork.from_flat(net)
+    B = 300                                            # more states than workgroups: the state loop and its prefetches
+    U = _states(B, 3000, 3)
+    K = 10.0 ** np.random.default_rng(4).uniform(-3, 3, (B, 15000))
+    du, lay = _tiled_k(h, U, K)
+    assert lay["windows"] > 1 and not lay["identity"]
+    _check_against_oracle(net, du, U, K, [0, 1, 17, 255, 256, 299])
+    # temperature form on the same layout, caller-order entry point (converts on the way in and out)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    T = np.linspace(500.0, 1200.0, B)
+    d_u, d_T = _dev(U), _dev(T)
+    d_du = torch.full_like(d_u, float("nan"))
+    h.rhs_batched_T_dev(B, d_u.data_ptr(), d_T.data_ptr(), d_du.data_ptr())
+    torch.cuda.synchronize()
+    duT = d_du.cpu().numpy()
+    on = orc.OracleNetwork.from_flat(net)
+    for b in (0, 150, 299):
+        k = orc.arrhenius(Ea, A, T[b], k_max=1e12)
+        bound = (2 * (Ea.max() / (R_GAS * T[b])) + 16) * 2.0 ** -53
+        assert np.all(np.abs(duT[b] - on.rhs(k, U[b])) <= (bound + TOL) * on.abs_rhs(k, U[b]) + 1e-300)
+    h.close()
+
+
+def test_special_stoichiometries_and_unpaired_reactions():
+    reacs = [[(0, 2)], [(1, 1), (2, 1)], [(3, 1)], [(4, 2)], [(0, 1), (5, 1)], [(1, 1), (5, 1)], [(2, 1)], [(2, 1)], [(2, 1)], [(5, 2)]]
+    prods = [[(1, 1), (2, 1)], [(0, 2)], [(4, 2)], [(3, 1)], [(1, 1), (5, 1)], [(0, 1), (5, 1)], [(3, 1), (4, 1)], [(0, 1)], [(0, 1)], [(5, 1), (1, 1)]]
+    net = from_lists(6, reacs, prods)
+    h = capi.HipNetwork.from_flat(net)
+    U = _states(5, 6, 5)
+    K = 10.0 ** np.random.default_rng(6).uniform(-2, 2, (5, 10))
+    du, lay = _tiled_k(h, U, K)
+    assert lay["records"] == 7
+    _check_against_oracle(net, du, U, K, range(5))
+    h.close()
+
+
+@pytest.mark.parametrize("k_max", [1e12, None], ids=["kmax", "nokmax"])
+def test_temperature_form_and_library_order_table(k_max):
+    """C2-size network: du from T[b] (no k anywhere) against the oracle; the library-order rate table against the plain
+    table kernel (same arithmetic: equal bit for bit) and against the oracle within the table kernel's stated bound."""
+    n, r, B = 1000, 5000, 40
+    net, Ea, A = synthetic_crn(n, r)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=k_max)
+    U = _states(B, n, 7)
+    T = np.linspace(500.0, 1500.0, B)
+    lay = h.lib_layout()
+    d_u, d_T = _dev(U), _dev(T)
+    d_du = torch.full_like(d_u, float("nan"))
+    h.rhs_batched_T_dev(B, d_u.data_ptr(), d_T.data_ptr(), d_du.data_ptr())
+    torch.cuda.synchronize()
+    du = d_du.cpu().numpy()
+    on = orc.OracleNetwork.from_flat(net)
+    for b in range(0, B, 3):
+        k = orc.arrhenius(Ea, A, T[b], k_max=k_max)
+        bound = (2 * (Ea.max() / (R_GAS * T[b])) + 16) * 2.0 ** -53
+        assert np.all(np.abs(du[b] - on.rhs(k, U[b])) <= (bound + TOL) * on.abs_rhs(k, U[b]) + 1e-300)
+    # table in library order
+    d_tl = torch.full((B, lay["k_len"]), float("nan"), dtype=torch.float64, device="cuda")
+    d_t = torch.empty((B, r), dtype=torch.float64, device="cuda")
+    h.rate_table_lib_dev(T, d_tl.data_ptr())
+    h.rate_table_dev(T, d_t.data_ptr())
+    tl, t = d_tl.cpu().numpy(), d_t.cpu().numpy()
+    for b in (0, B // 2, B - 1):
+        ko = orc.arrhenius(Ea, A, T[b], k_max=k_max)
+        bound = (2 * np.abs(Ea / (R_GAS * T[b])) + 8) * 2.0 ** -53
+        assert np.all(np.abs(tl[b][lay["slot_of_reaction"]] - ko) <= bound * ko)
+    assert np.array_equal(tl[:, lay["slot_of_reaction"]], t)
+    # the k-stream form fed with that table reproduces the temperature form's arithmetic up to the exp table size
+    d_du2 = torch.full_like(d_u, float("nan"))
+    h.rhs_tiled_dev(B, d_u.data_ptr(), d_du2.data_ptr(), d_k_lib=d_tl.data_ptr())
+    torch.cuda.synchronize()
+    du2 = d_du2.cpu().numpy()
+    scale = np.stack([on.abs_rhs(orc.arrhenius(Ea, A, T[b], k_max=k_max), U[b]) for b in range(B)])
+    assert np.all(np.abs(du2 - du) <= 4e-14 * scale + 1e-300)
+    h.close()
+
+
+def test_argument_errors():
+    net, Ea, A = synthetic_crn(300, 1500)
+    h = capi.HipNetwork.from_flat(net)
+    d = torch.zeros((2, 300), dtype=torch.float64, device="cuda")
+    with pytest.raises(capi.KineticaHipError):       # neither k nor T
+        h.rhs_tiled_dev(2, d.data_ptr(), d.data_ptr())
+    with pytest.raises(capi.KineticaHipError) as e:  # T form without Arrhenius parameters
+        h.rhs_tiled_dev(2, d.data_ptr(), d.data_ptr(), d_T=d.data_ptr())
+    assert e.value.code == capi.KIN_ERR_STATE
+    # a reaction with three product molecules has no fixed-role record: the layout is refused, the plain sweep still works
+    net3 = from_lists(3, [[(0, 1)], [(1, 1)]], [[(1, 3)], [(2, 1)]])
+    h3 = capi.HipNetwork.from_flat(net3)
+    with pytest.raises(capi.KineticaHipError) as e:
+        h3.lib_layout()
+    assert e.value.code == capi.KIN_ERR_UNSUPPORTED
+    assert h3.rhs_batched(np.ones((1, 3)), np.ones((1, 2))).shape == (1, 3)
+    h.close(); h3.close()
+
+
+def test_full_size_c3_elementwise_and_c5_tiled_sweep():
+    """BASELINE sizes. C3 (10k / 50k): B = 300 states (> CU count) with per-state k, element-wise against the oracle on
+    sampled states. C5 (50k / 250k, 9 windows): sampled states against the oracle, linearity in k, mass conservation,
+    run-to-run reproducibility of the sampled rows, and the temperature form on the same states."""
+    for (n, r, B) in ((10000, 50000, 300), (50000, 250000, 264)):
+        net, Ea, A = synthetic_crn(n, r)
+        h = capi.HipNetwork.from_flat(net)
+        h.set_arrhenius(Ea, A, k_max=1e12)
+        lay = h.lib_layout()
+        U = _states(B, n, 11)
+        T = np.linspace(500.0, 1200.0, B)
+        d_ul = _dev(U[:, lay["species_of_lib"]])
+        d_kl = torch.empty((B, lay["k_len"]), dtype=torch.float64, device="cuda")
+        h.rate_table_lib_dev(T, d_kl.data_ptr())
+        d_dul = torch.full_like(d_ul, float("nan"))
+        h.rhs_tiled_dev(B, d_ul.data_ptr(), d_dul.data_ptr(), d_k_lib=d_kl.data_ptr())
+        torch.cuda.synchronize()
+        dul = d_dul.cpu().numpy()
+        assert np.all(np.isfinite(dul))
+        du = np.empty_like(dul); du[:, lay["species_of_lib"]] = dul
+        kl = d_kl.cpu().numpy()
+        on = orc.OracleNetwork.from_flat(net)
+        sample = [0, 1, 63, 128, 255, 256, 257, B - 1]
+        for b in sample:
+            k = kl[b][lay["slot_of_reaction"]]
+            err = np.abs(du[b] - on.rhs(k, U[b])) / np.maximum(on.abs_rhs(k, U[b]), 1e-300)
+            assert err.max() <= TOL, (n, b, err.max())
+            # mass conservation (the synthetic CRN conserves sum m_i u_i)
+            assert abs(du[b] @ net.mass) <= 1e-12 * (on.abs_rhs(k, U[b]) @ net.mass)
+        # linearity in k: doubling k doubles du exactly (power of two)
+        d_k2 = d_kl * 2.0
+        d_du2 = torch.empty_like(d_dul)
+        h.rhs_tiled_dev(B, d_ul.data_ptr(), d_du2.data_ptr(), d_k_lib=d_k2.data_ptr())
+        # temperature form on the same states
+        d_T = _dev(T)
+        d_duT = torch.full_like(d_ul, float("nan"))
+        h.rhs_tiled_dev(B, d_ul.data_ptr(), d_duT.data_ptr(), d_T=d_T.data_ptr())
+        torch.cuda.synchronize()
+        du2 = d_du2.cpu().numpy()
+        ok = np.abs(du2 - 2.0 * dul) <= 1e-13 * np.abs(2.0 * dul) + 1e-300   # the atomics' order may differ run to run
+        assert ok.all()
+        duT = np.empty_like(dul); duT[:, lay["species_of_lib"]] = d_duT.cpu().numpy()
+        for b in (0, 128, B - 1):
+            k = orc.arrhenius(Ea, A, T[b], k_max=1e12)
+            bound = (2 * (Ea.max() / (R_GAS * T[b])) + 16) * 2.0 ** -53
+            assert np.all(np.abs(duT[b] - on.rhs(k, U[b])) <= (bound + TOL) * on.abs_rhs(k, U[b]) + 1e-300), (n, b)
+        h.close()

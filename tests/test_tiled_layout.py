@@ -1,0 +1,72 @@
+"""CPU tests of the tiled sweep's library order (kinetica_jl_amd/csrc/tiled.cpp): the tables are replayed on the host
+(tests/tiled_replay.py follows the kernel's arithmetic) and compared with the oracle's RHS - no GPU involved."""
+import os
+
+import numpy as np
+import pytest
+
+from kinetica_jl_amd import capi
+from kinetica_jl_amd.synth import from_lists, synthetic_crn
+from oracle import oracle as orc
+from tests.tiled_replay import k_to_lib, replay
+
+
+def _check(net, seed=0, hubs=0):
+    L = capi.lib_layout_host(net, hubs)
+    N, R = net.n_species, net.n_reactions
+    rng = np.random.default_rng(seed)
+    u = 10.0 ** rng.uniform(-6, 0, N)
+    k = 10.0 ** rng.uniform(-2, 2, R)
+    # layout invariants
+    sp = L["species_of_lib"]
+    assert sorted(sp) == list(range(N))
+    slots = L["slot_of_reaction"]
+    assert len(set(slots)) == R and slots.min() >= 0 and slots.max() < 2 * L["P"]
+    assert L["win_cnt"].sum() + L["h"] == N
+    assert all(q % 8 == 0 for q in L["seg_q"])
+    du_lib = replay(L, u[sp], k_to_lib(L, k))
+    du = np.empty(N)
+    du[sp] = du_lib
+    on = orc.OracleNetwork.from_flat(net)
+    ref, scale = on.rhs(k, u), on.abs_rhs(k, u)
+    assert np.all(np.abs(du - ref) <= 1e-13 * np.maximum(scale, 1e-300))
+    return L
+
+
+def test_small_network_keeps_the_callers_species_order():
+    net, _, _ = synthetic_crn(300, 1500)
+    L = _check(net)
+    assert L["T"] == 1 and L["h"] == 300 and np.array_equal(L["species_of_lib"], np.arange(300))
+    assert L["P"] == 750          # every reaction paired with its reverse
+
+
+def test_special_stoichiometries_and_unpaired_reactions():
+    # 2A -> B + C, A -> 2B, a collider on both sides (A + M -> B + M), its reverse, a reaction without reverse,
+    # two identical reactions, a reaction whose products repeat a reactant (2M -> M + B)
+    reacs = [[(0, 2)], [(1, 1), (2, 1)], [(3, 1)], [(4, 2)], [(0, 1), (5, 1)], [(1, 1), (5, 1)], [(2, 1)], [(2, 1)], [(2, 1)], [(5, 2)]]
+    prods = [[(1, 1), (2, 1)], [(0, 2)], [(4, 2)], [(3, 1)], [(1, 1), (5, 1)], [(0, 1), (5, 1)], [(3, 1), (4, 1)], [(0, 1)], [(0, 1)], [(5, 1), (1, 1)]]
+    net = from_lists(6, reacs, prods)
+    L = _check(net, seed=3)
+    assert L["P"] == 7            # three pairs, four single reactions
+
+
+def test_windows_on_a_small_network(monkeypatch):
+    monkeypatch.setenv("KIN_TILED_ENTRIES", "1400")
+    net, _, _ = synthetic_crn(3000, 15000)
+    L = _check(net, seed=1)
+    assert L["T"] > 1 and L["h"] < 3000 and L["E"] <= 1400
+    # every record of a segment touches no other window: implied by the replay (foreign entries are NaN there)
+
+
+def test_low_k_cutoff_leftovers_stay_tileable():
+    net, _, _ = synthetic_crn(1000, 5000)
+    keep = np.sort(np.random.default_rng(5).choice(5000, 3500, replace=False))
+    _check(net.subset(keep), seed=2)
+
+
+def test_c5_size_layout():
+    net, _, _ = synthetic_crn(50000, 250000)
+    L = _check(net, seed=4)
+    assert L["BS"] == 1024 and L["T"] <= 12 and L["P"] == 125000
+    # every window fits next to the hubs
+    assert L["wbase"] + L["win_cnt"].max() <= L["E"] <= 10176
