@@ -231,7 +231,9 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
     }
     for (int32_t i = 0; i < n; i++) { L.rec.push_back((uint32_t)words[i]); L.rec.push_back((uint32_t)(words[i] >> 32)); }
     const int32_t rows = (int32_t)ceil_div(n, bs);
-    const int32_t rows_pad = (int32_t)ceil_div(rows, TILED_GROUP) * TILED_GROUP;
+    // (at least one group of iteration rows, also for a window without records: the kernel's producer relies on it)
+    const int32_t rows_pad = std::max<int32_t>(1, (int32_t)ceil_div(rows, TILED_GROUP)) * TILED_GROUP;
+    L.seginfo.push_back(base); L.seginfo.push_back(n); L.seginfo.push_back(rows_pad); L.seginfo.push_back(0);
     for (int32_t i = 0; i < rows_pad; i++) {
       L.rowtab.push_back(i < rows ? base + i * bs : -1);
       L.rowtab.push_back(i < rows ? std::min(bs, n - i * bs) : 0);

@@ -51,6 +51,7 @@ struct TiledHost {
   std::vector<int32_t> slot_of_reaction;   // R: position of reaction r's rate constant in a k_lib row
   std::vector<int32_t> rowtab;     // 2 per iteration row: first record of the row (-1: padding row), records in it
   std::vector<int32_t> seg_q;      // T + 1: iteration rows [seg_q[s], seg_q[s + 1]) belong to segment s (multiples of TILED_GROUP)
+  std::vector<int32_t> seginfo;    // 4 per segment: first record, records, iteration rows (>= TILED_GROUP), 0 - what the kernel reads
   int64_t k_len() const { return 2 * (int64_t)P; }
 };
 

@@ -23,7 +23,6 @@ namespace kin {
 
 namespace {
 
-constexpr int UN = 10;   // doubles per thread of the staged-in set (hubs + window 0, or one window): E <= 10176 < 10 * 1024
 
 // rows per batch: 4 with a k stream (two batches = 8 rows of 16-byte loads in flight per thread cover the HBM latency);
 // 2 when the rate constants are computed (the parameters come from L2 and take twice the registers)
@@ -38,7 +37,9 @@ __device__ __forceinline__ Labels decode(uint2 w) {
 
 }  // namespace
 
-template <int BS, bool TMODE>
+// UN = doubles per thread of the staged-in set (the hubs, or one window) that travel HBM -> registers ahead of their
+// use: 5 when hubs and windows have at most 5 BS entries each (the windowed layouts), else 10 (a state that fits LDS whole)
+template <int BS, bool TMODE, int UN>
 __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, const double* __restrict__ u,
                                                          const double* __restrict__ k_lib, const double* __restrict__ Tb,
                                                          double* __restrict__ du) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   double* u_s = lds + v.E;
   const double* tab_s = lds + 2 * v.E;
   const int tid = threadIdx.x;
-  const int N = v.N, h = v.h, wbase = v.wbase, T = v.T, Q = v.Q;
+  const int N = v.N, h = v.h, wbase = v.wbase, T = v.T;
   const size_t KL = 2 * (size_t)v.P;
 
   for (int i = tid; i < v.E; i += BS) du_s[i] = 0.0;
@@ -61,22 +62,20 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
 
   // ---- the staged-in set of the next phase travels HBM -> registers while the current phase computes
   double un[UN];
-  // hubs + window 0 of state bb (one concatenated range of h + win_cnt[0] entries)
-  auto load_state_head = [&](int bb) {
+  // the hubs of state bb
+  auto load_hubs = [&](int bb) {
     const double* ub = u + (size_t)bb * N;
-    const int c0 = v.win_cnt[0], o0 = v.win_off[0];
 #pragma unroll
     for (int x = 0; x < UN; x++) {
       const int e = tid + x * BS;
-      un[x] = (bb < B && e < h + c0) ? ub[e < h ? e : o0 + (e - h)] : 0.0;
+      un[x] = (bb < B && e < h) ? ub[e] : 0.0;
     }
   };
-  auto store_state_head = [&]() {
-    const int c0 = v.win_cnt[0];
+  auto store_hubs = [&]() {
 #pragma unroll
     for (int x = 0; x < UN; x++) {
       const int e = tid + x * BS;
-      if (e < h + c0) u_s[e < h ? e : wbase + (e - h)] = un[x];
+      if (e < h) u_s[e] = un[x];
     }
   };
   auto load_window = [&](int bb, int s) {
@@ -97,61 +96,73 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
     }
   };
 
-  // ---- record / rate-constant queue: batches of TILED_BATCH rows, two batches in flight
-  int qb = blockIdx.x, qpos = 0;   // state and iteration row of the next batch to request
+  // ---- record / rate-constant queue: two batches of NB record rows in flight per thread. The producer runs 2 NB
+  // iteration rows ahead of the consumer, across segment and state boundaries. Its segment descriptors live in SGPRs:
+  // `pa` = the segment it is in, `pn` = the one after; `pn` is re-read (scalar loads, which drain the LDS queue) only at
+  // the consumer's segment starts, right behind a barrier. Every segment has >= TILED_GROUP >= 2 NB iteration rows and
+  // the producer changes segment lazily (at the first request beyond the end), so it does so at most once in between.
   constexpr int NB = Batch<TMODE>::NB;
   static_assert(TILED_GROUP % (2 * NB) == 0, "segments are padded to whole pairs of batches");
+  int pb = blockIdx.x, ps = 0, pi = 0;   // state, segment, iteration row inside the segment of the next request
+  int4 pa = v.seginfo[0], pn = v.seginfo[T > 1 ? 1 : 0];   // x = first record, y = records, z = iteration rows
   auto load_batch = [&](Batch<TMODE>& G) {
-    const bool live = qb < B && Q > 0;
-    const double* kb = TMODE ? nullptr : k_lib + (size_t)(live ? qb : 0) * KL;
+    if (pi >= pa.z) {
+      pi = 0; pa = pn;
+      if (++ps == T) { ps = 0; pb += gridDim.x; }
+    }
+    const bool live = pb < B;
+    const double* kb = TMODE ? nullptr : k_lib + (size_t)(live ? pb : 0) * KL;
 #pragma unroll
     for (int x = 0; x < NB; x++) {
-      const int2 rt = live ? v.rowtab[qpos + x] : make_int2(-1, 0);
-      const bool ok = rt.x >= 0 && tid < rt.y;
-      const int p = rt.x + tid;
+      const int off = (pi + x) * BS + tid;
+      const bool ok = live && off < pa.y;
+      const int p = pa.x + off;
       G.w[x] = ok ? v.rec[p] : EMPTY;
       if constexpr (TMODE) G.p[x] = ok ? v.par[p] : make_double4(0.0, 0.0, 0.0, 0.0);
       else G.k[x] = ok ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
     }
-    qpos += NB;
-    if (qpos >= Q) { qpos = 0; qb += gridDim.x; }
+    pi += NB;
   };
 
   double RT = 1.0, inv_RT = 1.0;
+  // rows of a batch are processed two at a time: all eight LDS reads of the pair in flight together, then its atomics
   auto consume = [&](const Batch<TMODE>& G) {
-    uint32_t fl[NB];
-    double uf[NB], ur[NB];
 #pragma unroll
-    for (int x = 0; x < NB; x++) {
-      fl[x] = __builtin_amdgcn_readfirstlane(G.w[x].y >> 24);
-      if (fl[x] & 4u) continue;
-      const Labels L = decode(G.w[x]);
-      uf[x] = u_s[L.l0];
-      if (fl[x] & 1u) uf[x] *= u_s[L.l1];
-      ur[x] = u_s[L.l2];
-      if (fl[x] & 2u) ur[x] *= u_s[L.l3];
-    }
+    for (int x0 = 0; x0 < NB; x0 += 2) {
+      uint32_t fl[2];
+      double uf[2], ur[2];
 #pragma unroll
-    for (int x = 0; x < NB; x++) {
-      if (fl[x] & 4u) continue;
-      double kf, kr;
-      if constexpr (TMODE) {
-        kf = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].x, G.p[x].y, G.p[x].y, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
-        kr = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].z, G.p[x].w, G.p[x].w, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
-      } else {
-        kf = G.k[x].x; kr = G.k[x].y;
+      for (int y = 0; y < 2; y++) {
+        // all four fields are read whatever the flags say (an unused field sits on the lane's dummy entry, u = 1): no
+        // branch between the LDS reads
+        fl[y] = __builtin_amdgcn_readfirstlane(G.w[x0 + y].y >> 24);
+        const Labels L = decode(G.w[x0 + y]);
+        uf[y] = u_s[L.l0] * u_s[L.l1];
+        ur[y] = u_s[L.l2] * u_s[L.l3];
       }
-      const double net = kf * uf[x] - kr * ur[x];
-      const Labels L = decode(G.w[x]);
-      __hip_atomic_fetch_add(du_s + L.l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (fl[x] & 1u) __hip_atomic_fetch_add(du_s + L.l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(du_s + L.l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (fl[x] & 2u) __hip_atomic_fetch_add(du_s + L.l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int y = 0; y < 2; y++) {
+        const int x = x0 + y;
+        if (fl[y] & 4u) continue;
+        double kf, kr;
+        if constexpr (TMODE) {
+          kf = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].x, G.p[x].y, G.p[x].y, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
+          kr = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].z, G.p[x].w, G.p[x].w, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
+        } else {
+          kf = G.k[x].x; kr = G.k[x].y;
+        }
+        const double net = kf * uf[y] - kr * ur[y];
+        const Labels L = decode(G.w[x]);
+        __hip_atomic_fetch_add(du_s + L.l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (fl[y] & 1u) __hip_atomic_fetch_add(du_s + L.l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(du_s + L.l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (fl[y] & 2u) __hip_atomic_fetch_add(du_s + L.l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   };
 
   int b = blockIdx.x;
-  load_state_head(b);
+  load_hubs(b);
   double ucn = (csrc >= 0 && b < B) ? u[(size_t)b * N + csrc] : 0.0;
   double Tn = (TMODE && b < B) ? Tb[b] : 1.0;
   Batch<TMODE> G0, G1;
@@ -162,15 +173,20 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
     double* dub = du + (size_t)b * N;
     const int bn = b + gridDim.x;
     if (TMODE) { RT = 8.314462618 * Tn; inv_RT = 1.0 / RT; }
-    store_state_head();
+    store_hubs();
     if (csrc >= 0) u_s[h + TILED_DUMMY + tid] = ucn;
+    // the state's first window is not prefetched (the registers carry the hubs across the state boundary): one exposed
+    // global -> LDS copy per state
+    if (v.win_cnt_max > 0) { load_window(b, 0); store_window(0); }
     __syncthreads();
     ucn = (csrc >= 0 && bn < B) ? u[(size_t)bn * N + csrc] : 0.0;
     if (TMODE) Tn = bn < B ? Tb[bn] : 1.0;
     for (int s = 0; s < T; s++) {
       const bool last = s == T - 1;
-      if (last) load_state_head(bn); else load_window(b, s + 1);
-      for (int q = v.seg_q[s]; q < v.seg_q[s + 1]; q += 2 * NB) {
+      if (last) load_hubs(bn); else load_window(b, s + 1);
+      pn = v.seginfo[ps + 1 == T ? 0 : ps + 1];
+      const int rows = v.seginfo[s].z;
+      for (int q = 0; q < rows; q += 2 * NB) {
         consume(G0);
         load_batch(G0);
         consume(G1);
@@ -278,12 +294,12 @@ void launch_rate_table_lib(int P, int64_t n_stops, const void* par, int has_kmax
   KIN_HIP(hipGetLastError());
 }
 
-template <int BS, bool TMODE>
+template <int BS, bool TMODE, int UN>
 static void launch_tiled_t(const TiledView& v, int grid, size_t smem, int B, const double* u, const double* k_lib, const double* Tb,
                            double* du, hipStream_t s) {
   // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
-  KIN_HIP(hipFuncSetAttribute((const void*)tiled_sweep_kernel<BS, TMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL((tiled_sweep_kernel<BS, TMODE>), dim3(grid), dim3(BS), smem, s, v, B, u, k_lib, Tb, du);
+  KIN_HIP(hipFuncSetAttribute((const void*)tiled_sweep_kernel<BS, TMODE, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((tiled_sweep_kernel<BS, TMODE, UN>), dim3(grid), dim3(BS), smem, s, v, B, u, k_lib, Tb, du);
 }
 
 void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const double* u, const double* k_lib, const double* Tb,
@@ -293,10 +309,13 @@ void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const d
   const size_t smem = ((size_t)2 * v.E + (tmode ? TILED_EXP_TAB : 0)) * 8;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / bs, (160 * 1024) / smem));
   const int grid = (int)std::min<int64_t>(B, (int64_t)n_cu * per_cu);
+  const bool un5 = std::max(v.h, v.win_cnt_max) <= 5 * bs;
 #define KIN_TILED_GO(BSZ)                                                                      \
   do {                                                                                         \
-    if (tmode) launch_tiled_t<BSZ, true>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);          \
-    else launch_tiled_t<BSZ, false>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);               \
+    if (tmode) { if (un5) launch_tiled_t<BSZ, true, 5>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);      \
+                 else launch_tiled_t<BSZ, true, 10>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }       \
+    else { if (un5) launch_tiled_t<BSZ, false, 5>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);           \
+           else launch_tiled_t<BSZ, false, 10>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }            \
   } while (0)
   if (bs == 256) KIN_TILED_GO(256);
   else if (bs == 512) KIN_TILED_GO(512);

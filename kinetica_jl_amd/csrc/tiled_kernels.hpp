@@ -6,10 +6,9 @@
 namespace kin {
 
 struct TiledView {   // passed to the kernel by value
-  int N, P, h, n_copy, wbase, E, T, Q;   // Q = iteration rows per state
+  int N, P, h, n_copy, wbase, E, T, win_cnt_max;
   const uint2* rec;
-  const int2* rowtab;
-  const int32_t* seg_q;
+  const int4* seginfo;     // per segment: first record, records, iteration rows (>= TILED_GROUP, a multiple of it), 0
   const int32_t* win_off;
   const int32_t* win_cnt;
   const int32_t* copy_src;
