@@ -157,6 +157,7 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   } else {
     std::fill(seg_of_rec.begin(), seg_of_rec.end(), 0);
   }
+  if (T > TILED_MAX_SEG) { L.why = "too many windows"; return L; }
   L.h = h; L.T = T;
   L.wbase = h + TILED_DUMMY + L.n_copy;
   L.wbase += L.wbase & 1;

@@ -29,6 +29,7 @@ constexpr int TILED_DUMMY = 64;        // per-lane dummy LDS entries (u = 1, du 
 constexpr int TILED_COPIES = 7;        // extra accumulator entries per split hub (copy 0 = the species' own entry)
 constexpr int TILED_BATCH = 4;         // record rows a thread processes together (all LDS reads, then all atomics)
 constexpr int TILED_GROUP = 2 * TILED_BATCH;   // rows per segment are padded (in iteration space only) to this
+constexpr int TILED_MAX_SEG = 48;              // segments a layout may have (their descriptors travel in the kernel arguments)
 constexpr int TILED_EXP_TAB = 128;             // entries of the exp table the temperature form keeps in LDS (exp_tab.hpp)
 constexpr int TILED_LDS_ENTRIES = 10176;       // entries per LDS array (u, du): (2 x 10176 + 128) x 8 B = 160 kB exactly
 

@@ -26,8 +26,8 @@ void ensure_tiled(kin_network* h) {
       hipStream_t s = h->stream;
       std::vector<int32_t> rxn_of_slot((size_t)L.k_len(), -1);
       for (int32_t r = 0; r < L.R; r++) if (L.slot_of_reaction[r] >= 0) rxn_of_slot[L.slot_of_reaction[r]] = r;
-      h->t_rec.upload(L.rec, s); h->t_seginfo.upload(L.seginfo, s);
-      h->t_woff.upload(L.win_off, s); h->t_wcnt.upload(L.win_cnt, s); h->t_copy.upload(L.copy_src, s);
+      h->t_rec.upload(L.rec, s);
+      h->t_copy.upload(L.copy_src, s);
       h->t_kf.upload(L.kf, s); h->t_kr.upload(L.kr, s); h->t_rxn_of_slot.upload(rxn_of_slot, s);
       h->t_spec_of_lib.upload(L.species_of_lib, s); h->t_lib_of_spec.upload(L.lib_of_species, s);
       KIN_HIP(hipStreamSynchronize(s));
@@ -51,8 +51,12 @@ TiledView view_of(kin_network* h) {
   v.N = L.N; v.P = L.P; v.h = L.h; v.n_copy = L.n_copy; v.wbase = L.wbase; v.E = L.E; v.T = L.T;
   v.win_cnt_max = 0;
   for (int32_t c : L.win_cnt) v.win_cnt_max = std::max(v.win_cnt_max, c);
-  v.rec = (const uint2*)h->t_rec.p; v.seginfo = (const int4*)h->t_seginfo.p;
-  v.win_off = h->t_woff.p; v.win_cnt = h->t_wcnt.p; v.copy_src = h->t_copy.p;
+  v.rec = (const uint2*)h->t_rec.p;
+  for (int32_t t = 0; t < L.T; t++) {
+    v.seginfo[t] = make_int4(L.seginfo[4 * t], L.seginfo[4 * t + 1], L.seginfo[4 * t + 2], 0);
+    v.win_off[t] = L.win_off[t]; v.win_cnt[t] = L.win_cnt[t];
+  }
+  v.copy_src = h->t_copy.p;
   v.par = (const double4*)h->t_par.p;
   v.has_kmax = h->has_kmax ? 1 : 0;
   v.inv_kmax = h->has_kmax ? 1.0 / h->k_max : 0.0;

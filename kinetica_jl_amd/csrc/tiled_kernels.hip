@@ -54,22 +54,23 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   for (int i = tid; i < v.E; i += BS) du_s[i] = 0.0;
   if (tid < TILED_DUMMY) u_s[h + tid] = 1.0;
   if (TMODE) for (int i = tid; i < TILED_EXP_TAB; i += BS) lds[2 * v.E + i] = kExp2Tab[i * (512 / TILED_EXP_TAB)];
-  const int csrc = tid < v.n_copy ? v.copy_src[tid] : -1;
+  const int csrc = tid < v.n_copy ? v.copy_src[min(tid, max(v.n_copy - 1, 0))] : -1;
   // padding record of this lane: every field on the lane's dummy entry, "nothing to do" set
   const uint64_t dl = (uint64_t)(h + (tid & 63));
   const uint64_t ew = dl | (dl << 14) | (dl << 28) | (dl << 42) | (4ull << 56);
   const uint2 EMPTY = {(uint32_t)ew, (uint32_t)(ew >> 32)};
 
+  // Every global load below is UNCONDITIONAL (indices clamped into valid memory, the value replaced afterwards): a load
+  // behind a branch makes the compiler wait for vmcnt(0) wherever it cannot count the loads in flight, which would drain
+  // the two-batch queue at every use (seen in the first version of this kernel: 0.78 -> 0.64 ms at C5).
+  const int Bm1 = B - 1;
   // ---- the staged-in set of the next phase travels HBM -> registers while the current phase computes
   double un[UN];
   // the hubs of state bb
   auto load_hubs = [&](int bb) {
-    const double* ub = u + (size_t)bb * N;
+    const double* ub = u + (size_t)min(bb, Bm1) * N;
 #pragma unroll
-    for (int x = 0; x < UN; x++) {
-      const int e = tid + x * BS;
-      un[x] = (bb < B && e < h) ? ub[e] : 0.0;
-    }
+    for (int x = 0; x < UN; x++) un[x] = ub[min(tid + x * BS, h - 1)];
   };
   auto store_hubs = [&]() {
 #pragma unroll
@@ -80,12 +81,9 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   };
   auto load_window = [&](int bb, int s) {
     const double* ub = u + (size_t)bb * N + v.win_off[s];
-    const int c = v.win_cnt[s];
+    const int cm1 = v.win_cnt[s] - 1;      // (windows are never empty when there are any)
 #pragma unroll
-    for (int x = 0; x < UN; x++) {
-      const int e = tid + x * BS;
-      un[x] = e < c ? ub[e] : 0.0;
-    }
+    for (int x = 0; x < UN; x++) un[x] = ub[min(tid + x * BS, cm1)];
   };
   auto store_window = [&](int s) {
     const int c = v.win_cnt[s];
@@ -97,10 +95,11 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   };
 
   // ---- record / rate-constant queue: two batches of NB record rows in flight per thread. The producer runs 2 NB
-  // iteration rows ahead of the consumer, across segment and state boundaries. Its segment descriptors live in SGPRs:
-  // `pa` = the segment it is in, `pn` = the one after; `pn` is re-read (scalar loads, which drain the LDS queue) only at
-  // the consumer's segment starts, right behind a barrier. Every segment has >= TILED_GROUP >= 2 NB iteration rows and
-  // the producer changes segment lazily (at the first request beyond the end), so it does so at most once in between.
+  // iteration rows ahead of the consumer, across segment and state boundaries. The segment descriptors are part of the
+  // kernel arguments (scalar loads from the kernarg segment); `pa` = the producer's segment, `pn` = the one after, re-read
+  // only at the consumer's segment starts, right behind a barrier (a scalar load's wait also drains the LDS queue). Every
+  // segment has >= TILED_GROUP >= 2 NB iteration rows and the producer changes segment lazily (at the first request beyond
+  // the end), so it does so at most once in between.
   constexpr int NB = Batch<TMODE>::NB;
   static_assert(TILED_GROUP % (2 * NB) == 0, "segments are padded to whole pairs of batches");
   int pb = blockIdx.x, ps = 0, pi = 0;   // state, segment, iteration row inside the segment of the next request
@@ -111,39 +110,40 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       if (++ps == T) { ps = 0; pb += gridDim.x; }
     }
     const bool live = pb < B;
-    const double* kb = TMODE ? nullptr : k_lib + (size_t)(live ? pb : 0) * KL;
+    const double* kb = TMODE ? nullptr : k_lib + (size_t)min(pb, Bm1) * KL;
 #pragma unroll
     for (int x = 0; x < NB; x++) {
       const int off = (pi + x) * BS + tid;
       const bool ok = live && off < pa.y;
-      const int p = pa.x + off;
-      G.w[x] = ok ? v.rec[p] : EMPTY;
-      if constexpr (TMODE) G.p[x] = ok ? v.par[p] : make_double4(0.0, 0.0, 0.0, 0.0);
-      else G.k[x] = ok ? *reinterpret_cast<const double2*>(kb + 2 * (size_t)p) : make_double2(0.0, 0.0);
+      const int p = ok ? pa.x + off : 0;
+      const uint2 w = v.rec[p];
+      G.w[x].x = ok ? w.x : EMPTY.x;
+      G.w[x].y = ok ? w.y : EMPTY.y;
+      if constexpr (TMODE) G.p[x] = v.par[p];
+      else G.k[x] = *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
     }
     pi += NB;
   };
 
   double RT = 1.0, inv_RT = 1.0;
-  // rows of a batch are processed two at a time: all eight LDS reads of the pair in flight together, then its atomics
+  // Rows of a batch are processed two at a time: the pair's eight LDS reads in flight together, both net rates formed,
+  // then the pair's atomics back to back - nothing waits between them, and the next pair's reads queue up behind them
+  // (the LDS executes a wave's operations in order). An all-padding row has EMPTY records: rate constants times
+  // dummy entries, added to dummy entries; its wavefronts skip the atomics.
   auto consume = [&](const Batch<TMODE>& G) {
 #pragma unroll
     for (int x0 = 0; x0 < NB; x0 += 2) {
       uint32_t fl[2];
-      double uf[2], ur[2];
+      double net[2];
 #pragma unroll
       for (int y = 0; y < 2; y++) {
         // all four fields are read whatever the flags say (an unused field sits on the lane's dummy entry, u = 1): no
         // branch between the LDS reads
-        fl[y] = __builtin_amdgcn_readfirstlane(G.w[x0 + y].y >> 24);
-        const Labels L = decode(G.w[x0 + y]);
-        uf[y] = u_s[L.l0] * u_s[L.l1];
-        ur[y] = u_s[L.l2] * u_s[L.l3];
-      }
-#pragma unroll
-      for (int y = 0; y < 2; y++) {
         const int x = x0 + y;
-        if (fl[y] & 4u) continue;
+        fl[y] = __builtin_amdgcn_readfirstlane(G.w[x].y >> 24);
+        const Labels L = decode(G.w[x]);
+        const double uf = u_s[L.l0] * u_s[L.l1];
+        const double ur = u_s[L.l2] * u_s[L.l3];
         double kf, kr;
         if constexpr (TMODE) {
           kf = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].x, G.p[x].y, G.p[x].y, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
@@ -151,20 +151,25 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
         } else {
           kf = G.k[x].x; kr = G.k[x].y;
         }
-        const double net = kf * uf[y] - kr * ur[y];
-        const Labels L = decode(G.w[x]);
-        __hip_atomic_fetch_add(du_s + L.l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (fl[y] & 1u) __hip_atomic_fetch_add(du_s + L.l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(du_s + L.l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (fl[y] & 2u) __hip_atomic_fetch_add(du_s + L.l3, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        net[y] = kf * uf - kr * ur;
+      }
+#pragma unroll
+      for (int y = 0; y < 2; y++) {
+        if (fl[y] & 4u) continue;
+        const Labels L = decode(G.w[x0 + y]);
+        __hip_atomic_fetch_add(du_s + L.l0, -net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (fl[y] & 1u) __hip_atomic_fetch_add(du_s + L.l1, -net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(du_s + L.l2, net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (fl[y] & 2u) __hip_atomic_fetch_add(du_s + L.l3, net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   };
 
   int b = blockIdx.x;
   load_hubs(b);
-  double ucn = (csrc >= 0 && b < B) ? u[(size_t)b * N + csrc] : 0.0;
-  double Tn = (TMODE && b < B) ? Tb[b] : 1.0;
+  const int csrc_c = max(csrc, 0);
+  double ucn = u[(size_t)min(b, Bm1) * N + csrc_c];
+  double Tn = TMODE ? Tb[min(b, Bm1)] : 1.0;
   Batch<TMODE> G0, G1;
   load_batch(G0);
   load_batch(G1);
@@ -179,8 +184,8 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
     // global -> LDS copy per state
     if (v.win_cnt_max > 0) { load_window(b, 0); store_window(0); }
     __syncthreads();
-    ucn = (csrc >= 0 && bn < B) ? u[(size_t)bn * N + csrc] : 0.0;
-    if (TMODE) Tn = bn < B ? Tb[bn] : 1.0;
+    ucn = u[(size_t)min(bn, Bm1) * N + csrc_c];
+    if (TMODE) Tn = Tb[min(bn, Bm1)];
     for (int s = 0; s < T; s++) {
       const bool last = s == T - 1;
       if (last) load_hubs(bn); else load_window(b, s + 1);

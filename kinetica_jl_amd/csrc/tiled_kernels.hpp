@@ -8,10 +8,11 @@ namespace kin {
 struct TiledView {   // passed to the kernel by value
   int N, P, h, n_copy, wbase, E, T, win_cnt_max;
   const uint2* rec;
-  const int4* seginfo;     // per segment: first record, records, iteration rows (>= TILED_GROUP, a multiple of it), 0
-  const int32_t* win_off;
-  const int32_t* win_cnt;
   const int32_t* copy_src;
+  // per segment, inside the kernel arguments (read with scalar loads from the kernarg segment, never through the
+  // vector memory path): first record, records, iteration rows (>= TILED_GROUP, a multiple of it), 0; the window
+  int4 seginfo[TILED_MAX_SEG];
+  int32_t win_off[TILED_MAX_SEG], win_cnt[TILED_MAX_SEG];
   const double4* par;      // Arrhenius parameters per record (TMODE and the library-order rate table)
   int has_kmax;
   double inv_kmax;
