@@ -19,6 +19,10 @@
 
 #include "exp_tab.hpp"
 
+#ifndef KIN_TILED_SUB
+#define KIN_TILED_SUB 2
+#endif
+
 namespace kin {
 
 namespace {
@@ -26,9 +30,10 @@ namespace {
 
 // rows per batch: 4 with a k stream (two batches = 8 rows of 16-byte loads in flight per thread cover the HBM latency);
 // 2 when the rate constants are computed (the parameters come from L2 and take twice the registers)
-template <bool TMODE> struct Batch;
-template <> struct Batch<false> { static constexpr int NB = 4; double2 k[NB]; uint2 w[NB]; };
-template <> struct Batch<true> { static constexpr int NB = 2; double4 p[NB]; uint2 w[NB]; };
+// (a state that fits LDS whole carries 10 staged doubles per thread instead of 5: two rows per batch there as well)
+template <bool TMODE, int NB_> struct Batch;
+template <int NB_> struct Batch<false, NB_> { static constexpr int NB = NB_; double2 k[NB]; uint2 w[NB]; };
+template <int NB_> struct Batch<true, NB_> { static constexpr int NB = NB_; double4 p[NB]; uint2 w[NB]; };
 
 struct Labels { uint32_t l0, l1, l2, l3; };
 __device__ __forceinline__ Labels decode(uint2 w) {
@@ -100,11 +105,12 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   // only at the consumer's segment starts, right behind a barrier (a scalar load's wait also drains the LDS queue). Every
   // segment has >= TILED_GROUP >= 2 NB iteration rows and the producer changes segment lazily (at the first request beyond
   // the end), so it does so at most once in between.
-  constexpr int NB = Batch<TMODE>::NB;
+  constexpr int NB = (TMODE || UN > 5) ? 2 : 4;
+  using BatchT = Batch<TMODE, NB>;
   static_assert(TILED_GROUP % (2 * NB) == 0, "segments are padded to whole pairs of batches");
   int pb = blockIdx.x, ps = 0, pi = 0;   // state, segment, iteration row inside the segment of the next request
   int4 pa = v.seginfo[0], pn = v.seginfo[T > 1 ? 1 : 0];   // x = first record, y = records, z = iteration rows
-  auto load_batch = [&](Batch<TMODE>& G) {
+  auto load_batch = [&](BatchT& G) {
     if (pi >= pa.z) {
       pi = 0; pa = pn;
       if (++ps == T) { ps = 0; pb += gridDim.x; }
@@ -130,13 +136,14 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   // then the pair's atomics back to back - nothing waits between them, and the next pair's reads queue up behind them
   // (the LDS executes a wave's operations in order). An all-padding row has EMPTY records: rate constants times
   // dummy entries, added to dummy entries; its wavefronts skip the atomics.
-  auto consume = [&](const Batch<TMODE>& G) {
+  auto consume = [&](const BatchT& G) {
+    constexpr int SUB = KIN_TILED_SUB < NB ? KIN_TILED_SUB : NB;
 #pragma unroll
-    for (int x0 = 0; x0 < NB; x0 += 2) {
-      uint32_t fl[2];
-      double net[2];
+    for (int x0 = 0; x0 < NB; x0 += SUB) {
+      uint32_t fl[SUB];
+      double net[SUB];
 #pragma unroll
-      for (int y = 0; y < 2; y++) {
+      for (int y = 0; y < SUB; y++) {
         // all four fields are read whatever the flags say (an unused field sits on the lane's dummy entry, u = 1): no
         // branch between the LDS reads
         const int x = x0 + y;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
         net[y] = kf * uf - kr * ur;
       }
 #pragma unroll
-      for (int y = 0; y < 2; y++) {
+      for (int y = 0; y < SUB; y++) {
         if (fl[y] & 4u) continue;
         const Labels L = decode(G.w[x0 + y]);
         __hip_atomic_fetch_add(du_s + L.l0, -net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   const int csrc_c = max(csrc, 0);
   double ucn = u[(size_t)min(b, Bm1) * N + csrc_c];
   double Tn = TMODE ? Tb[min(b, Bm1)] : 1.0;
-  Batch<TMODE> G0, G1;
+  BatchT G0, G1;
   load_batch(G0);
   load_batch(G1);
 
