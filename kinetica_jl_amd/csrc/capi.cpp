@@ -14,8 +14,15 @@ using namespace kin;
 
 static thread_local std::string g_create_err;
 
+void kin_network::flush_pending_T(hipStream_t s) {
+  if (!k_pending) return;
+  launch_arrhenius(host.R, Ea.p, A.p, has_kmax, k_max, t_mult, T_pending, k.p, s);
+  k_pending = false;
+}
+
 void kin_network::rhs_dev(const double* d_u, double* d_du) {
-  launch_rates(host.R, k.p, d_u, x0.p, x1.p, rate.p, stream);
+  if (k_pending) { launch_rates_T(host.R, pending_at(), k.p, d_u, x0.p, x1.p, rate.p, stream); k_pending = false; }
+  else launch_rates(host.R, k.p, d_u, x0.p, x1.p, rate.p, stream);
   launch_segsum(rhs_plan.view(), SEG_COEF_SET, rate.p, d_du, SegExtra{}, stream);
 }
 
@@ -39,7 +46,8 @@ void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, dou
 }
 
 void kin_network::jac_dev(const double* d_u, double* d_vals) {
-  launch_drates(host.R, k.p, d_u, x0.p, x1.p, dr.p, stream);
+  if (k_pending) { launch_drates_T(host.R, pending_at(), k.p, d_u, x0.p, x1.p, dr.p, stream); k_pending = false; }
+  else launch_drates(host.R, k.p, d_u, x0.p, x1.p, dr.p, stream);
   launch_segsum(jac_plan.view(), SEG_COEF_SET, dr.p, d_vals, SegExtra{}, stream);
 }
 
@@ -144,6 +152,7 @@ int kin_set_rates(kin_network* h, const double* k) {
   h->k.upload(k, h->host.R, h->stream);
   KIN_HIP(hipStreamSynchronize(h->stream));
   h->has_rates = true;
+  h->k_pending = false;
   KIN_CATCH(h)
 }
 
@@ -152,6 +161,7 @@ int kin_get_rates(kin_network* h, double* k_out) {
   KIN_TRY(h)
   require(k_out != nullptr, ERR_INVALID_ARG, "k_out is null");
   require(h->has_rates, ERR_STATE, "rates were never set");
+  h->flush_pending_T(h->stream);
   h->k.download(k_out, h->host.R, h->stream);
   KIN_HIP(hipStreamSynchronize(h->stream));
   KIN_CATCH(h)
@@ -177,6 +187,7 @@ int kin_rates_at(kin_network* h, double T, double* k_out) {
   KIN_TRY(h)
   require(h->has_arrhenius, ERR_STATE, "Arrhenius parameters were never set");
   launch_arrhenius(h->host.R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, T, h->k.p, h->stream);
+  h->k_pending = false;
   if (k_out) h->k.download(k_out, h->host.R, h->stream);
   KIN_HIP(hipStreamSynchronize(h->stream));
   h->has_rates = true;

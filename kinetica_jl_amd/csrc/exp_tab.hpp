@@ -5,6 +5,16 @@
 
 namespace kin {
 
+// Arrhenius: k = A exp(-Ea/(R T)) N_A t_mult, optionally capped 1/(1/k_max + 1/k)
+// (PrecalculatedArrheniusCalculator functor, src/solving/calculator.jl:223-232; constants.jl:4-5), evaluated literally
+__device__ __forceinline__ double arrhenius_one(double Ea, double A, double RT, int has_kmax, double k_max, double t_mult) {
+  const double kr = A * exp(-Ea / RT) * 6.02214076e23 * t_mult;
+  // the cap in the reference's own form 1/(1/k_max + 1/k_r) (calculator.jl:225): exact limits at both ends
+  // (k_r = inf -> k_max, k_r = 0 -> 0), where the cheaper k_r / (1 + k_r/k_max) gives NaN for an overflowing k_r
+  return has_kmax ? 1.0 / (1.0 / k_max + 1.0 / kr) : kr;
+}
+
+
 // Table variant without IEEE divisions (the table kernel is FP64-VALU bound: with two full divisions and the library exp
 // per element it ran at 2.0 ms for 14001 x 50000, against a 1.0 ms pure-store floor). Ea/RT is a multiply by the row's
 // reciprocal plus one FMA residual correction; the cap 1/(1/k_max + 1/k_r) is evaluated in exactly that form,

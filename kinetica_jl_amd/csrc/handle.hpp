@@ -33,6 +33,14 @@ struct kin_network {
   // rate constants / calculator
   kin::DevBuf<double> k, Ea, A, table, T_stops;
   bool has_rates = false, has_arrhenius = false, has_kmax = false;
+  // Continuous-rate solves: a temperature whose rate constants have not been formed yet. The first kernel that reads k
+  // (rates / operand derivatives / the corrector's rates) evaluates the Arrhenius law itself and stores k for the readers
+  // behind it: no launch of its own per step attempt (the reference inlines k(T(t)) into the ODEs, methods.jl:389-419).
+  bool k_pending = false;
+  double T_pending = 0.0;
+  void set_pending_T(double T) { T_pending = T; k_pending = true; has_rates = true; }
+  kin::ArrheniusAt pending_at() const { return kin::ArrheniusAt{Ea.p, A.p, has_kmax ? 1 : 0, k_max, t_mult, T_pending}; }
+  void flush_pending_T(hipStream_t s);   // forms k now if a temperature is still pending
   double k_max = 0.0, t_mult = 1.0;
   int64_t table_rows = 0;
 

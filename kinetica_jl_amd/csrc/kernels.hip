@@ -214,6 +214,45 @@ __global__ __launch_bounds__(256) void drates_kernel(int R, const double* __rest
   reinterpret_cast<double2*>(dr)[r] = make_double2(d0, d1);
 }
 
+// The same two kernels with the rate constants formed on the spot from a temperature (continuous-rate solves: the first
+// reader of k after a change of T evaluates the Arrhenius law itself and stores k for the readers behind it - no launch of
+// its own for the rate constants; calculator.jl:223-232 literally, as arrhenius_kernel)
+__global__ __launch_bounds__(256) void rates_T_kernel(int R, ArrheniusAt at, double* __restrict__ k, const double* __restrict__ u,
+                                                      const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
+                                                      double* __restrict__ rate) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const int32_t a = x0[r], b = x1[r];
+  const double kk = arrhenius_one(at.Ea[r], at.A[r], 8.314462618 * at.T, at.has_kmax, at.k_max, at.t_mult);
+  k[r] = kk;
+  const double ub = b >= 0 ? u[b] : 1.0;
+  rate[r] = kk * u[a] * ub;
+}
+__global__ __launch_bounds__(256) void drates_T_kernel(int R, ArrheniusAt at, double* __restrict__ k, const double* __restrict__ u,
+                                                       const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
+                                                       double* __restrict__ dr) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const int32_t a = x0[r], b = x1[r];
+  const double kk = arrhenius_one(at.Ea[r], at.A[r], 8.314462618 * at.T, at.has_kmax, at.k_max, at.t_mult);
+  k[r] = kk;
+  double d0, d1 = 0.0;
+  if (b < 0) d0 = kk;
+  else if (b == a) d0 = 2.0 * kk * u[a];
+  else { d0 = kk * u[b]; d1 = kk * u[a]; }
+  reinterpret_cast<double2*>(dr)[r] = make_double2(d0, d1);
+}
+void launch_rates_T(int64_t R, const ArrheniusAt& at, double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(rates_T_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s, (int)R, at, k, u, x0, x1, rate);
+  KIN_HIP(hipGetLastError());
+}
+void launch_drates_T(int64_t R, const ArrheniusAt& at, double* k, const double* u, const int32_t* x0, const int32_t* x1, double* dr, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(drates_T_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s, (int)R, at, k, u, x0, x1, dr);
+  KIN_HIP(hipGetLastError());
+}
+
 void launch_rates(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s) {
   if (R == 0) return;
   hipLaunchKernelGGL(rates_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, s, (int)R, k, u, x0, x1, rate);
@@ -229,13 +268,6 @@ void launch_drates(int64_t R, const double* k, const double* u, const int32_t* x
 // Arrhenius: k = A exp(-Ea/(R T)) N_A t_mult, optionally capped 1/(1/k_max + 1/k)
 // (PrecalculatedArrheniusCalculator functor, src/solving/calculator.jl:223-232; constants.jl:4-5)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double arrhenius_one(double Ea, double A, double RT, int has_kmax, double k_max, double t_mult) {
-  const double kr = A * exp(-Ea / RT) * 6.02214076e23 * t_mult;
-  // the cap in the reference's own form 1/(1/k_max + 1/k_r) (calculator.jl:225): exact limits at both ends
-  // (k_r = inf -> k_max, k_r = 0 -> 0), where the cheaper k_r / (1 + k_r/k_max) gives NaN for an overflowing k_r
-  return has_kmax ? 1.0 / (1.0 / k_max + 1.0 / kr) : kr;
-}
-
 __global__ __launch_bounds__(256) void arrhenius_kernel(int n, const double* __restrict__ Ea, const double* __restrict__ A,
                                                         int has_kmax, double k_max, double t_mult, double T,
                                                         double* __restrict__ k) {

@@ -46,6 +46,12 @@ void launch_segsum(const SegPlanView& p, SegOp op, const double* src, double* ou
 void launch_rates(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s);
 void launch_drates(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* dr, hipStream_t s);
 
+// a temperature whose rate constants have not been formed yet (continuous-rate solves): passed by value to the kernels
+// that evaluate the Arrhenius law themselves and store k for the readers behind them
+struct ArrheniusAt { const double* Ea; const double* A; int has_kmax; double k_max, t_mult, T; };
+void launch_rates_T(int64_t R, const ArrheniusAt& at, double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate, hipStream_t s);
+void launch_drates_T(int64_t R, const ArrheniusAt& at, double* k, const double* u, const int32_t* x0, const int32_t* x1, double* dr, hipStream_t s);
+
 // Arrhenius (k_max < 0 or NaN handled by has_kmax flag)
 void launch_arrhenius(int64_t n, const double* Ea, const double* A, int has_kmax, double k_max, double t_mult, double T, double* k, hipStream_t s);
 void launch_rate_table(int64_t n, int64_t n_stops, const double* Ea, const double* A, int has_kmax, double k_max,

@@ -393,7 +393,8 @@ struct Solver {
     ex.psi = psi.p; ex.d = d.p; ex.cscal = c; ex.skip = skip;
     // (forming the rates inside the residual gather - three gathers per entry instead of one, no rate launch - was
     // measured slower: 0.565 against 0.553 s on the C3 solve)
-    launch_rates_skip(h->host.R, h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s);
+    if (h->k_pending) { launch_rates_skip_T(h->host.R, h->pending_at(), h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s); h->k_pending = false; }
+    else launch_rates_skip(h->host.R, h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s);
     launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, q.W.p, ex, s);
     lu.solve(skip, cur_slot, s);
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
@@ -804,6 +805,7 @@ void apply_rates(kin_network* h, const double* T_stops, bool have_table, int64_t
     launch_arrhenius(R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, T_stops[si], h->k.p, h->stream);
   }
   h->has_rates = true;
+  h->k_pending = false;
 }
 
 }  // namespace
@@ -905,9 +907,8 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   };
   double seg_origin = 0.0;   // global time of the current segment's tau = 0
   if (continuous) {
-    S.pre_attempt = [&](double tau) {
-      launch_arrhenius(R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, T_of(seg_origin + tau), h->k.p, s);
-    };
+    // (no launch: the first kernel of the attempt that reads k forms it from this temperature, handle.hpp)
+    S.pre_attempt = [&](double tau) { h->set_pending_T(T_of(seg_origin + tau)); };
     h->has_rates = true;
   } else {
     S.pre_attempt = nullptr;
@@ -1071,6 +1072,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     }
   }
   S.flush_accept();
+  h->flush_pending_T(s);     // a temperature no kernel has consumed yet: k is what the caller may read next
   KIN_HIP(hipStreamSynchronize(s));
   S.pre_attempt = nullptr;   // the lambda captures locals of this call
   S.st.final_abstol = abstol;
@@ -1197,9 +1199,7 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
   // continuous rate updates: the Arrhenius rates are re-evaluated at T(global time) of every step attempt, as in
   // solve_entry (the integrator's span starts at global time t_loc0, its segments run in local time)
   if (!I.t_nodes.empty())
-    S.pre_attempt = [h, &I, s](double tau) {
-      launch_arrhenius(h->host.R, h->Ea.p, h->A.p, h->has_kmax, h->k_max, h->t_mult, I.T_of(I.t_seg + tau), h->k.p, s);
-    };
+    S.pre_attempt = [h, &I](double tau) { h->set_pending_T(I.T_of(I.t_seg + tau)); };
   struct ClearHook { Solver& S; ~ClearHook() { S.pre_attempt = nullptr; } } clear_hook{S};
   while (I.retcode == KIN_RETCODE_SUCCESS && I.t_seg < I.t_loc1 && (max_steps <= 0 || taken < max_steps)) {
     if (!I.in_segment) {
@@ -1225,6 +1225,7 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
       if (I.ends_at_stop) { apply_rates(h, I.T_stops.data(), I.have_table, I.stop_i); I.stop_i++; }
     }
   }
+  h->flush_pending_T(s);
   KIN_HIP(hipStreamSynchronize(s));
   return taken;
 }

@@ -6,6 +6,9 @@
 #include "lu.hpp"
 #include "solver_kernels.hpp"
 
+#include "exp_tab.hpp"
+#include "kernels.hpp"
+
 #include <utility>
 
 namespace kin {
@@ -848,6 +851,22 @@ __global__ __launch_bounds__(256) void rates_skip_kernel(int R, const double* __
   rate[r] = kr * u[a] * ub;
 }
 
+// the same with the rate constants formed from a temperature and stored for the readers behind this launch (kernels.hpp: ArrheniusAt)
+__global__ __launch_bounds__(256) void rates_skip_T_kernel(int R, ArrheniusAt at, double* __restrict__ k, const double* __restrict__ u,
+                                                           const int32_t* __restrict__ x0, const int32_t* __restrict__ x1,
+                                                           double* __restrict__ rate, const int* skip) {
+  const int sk = skip ? *skip : 0;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const int32_t a = x0[r], b = x1[r];
+  // k is stored whether or not the iteration is skipped: the launches behind this one read it
+  const double kr = arrhenius_one(at.Ea[r], at.A[r], 8.314462618 * at.T, at.has_kmax, at.k_max, at.t_mult);
+  k[r] = kr;
+  if (sk) return;
+  const double ub = b >= 0 ? u[b] : 1.0;
+  rate[r] = kr * u[a] * ub;
+}
+
 #define GRID1(n) dim3((unsigned)ceil_div((n), 256)), dim3(256)
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
@@ -907,6 +926,11 @@ void launch_rates_skip(int64_t R, const double* k, const double* u, const int32_
                        const int* skip, hipStream_t s) {
   if (R == 0) return;
   hipLaunchKernelGGL(rates_skip_kernel, GRID1(R), 0, s, (int)R, k, u, x0, x1, rate, skip);
+}
+void launch_rates_skip_T(int64_t R, const ArrheniusAt& at, double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate,
+                         const int* skip, hipStream_t s) {
+  if (R == 0) return;
+  hipLaunchKernelGGL(rates_skip_T_kernel, GRID1(R), 0, s, (int)R, at, k, u, x0, x1, rate, skip);
 }
 
 }  // namespace kin

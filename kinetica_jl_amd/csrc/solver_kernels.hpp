@@ -64,6 +64,9 @@ void launch_clip_negative(int N, const double* a, double* out, hipStream_t s);  
 void launch_bdf_norms(int N, const double* y0, const double* f0, const double* f1, double atol, double rtol, BdfCtrl* ctrl, hipStream_t s);
 void launch_rowdot(int N, int64_t M, const double* U, const double* w, double* out, hipStream_t s);
 void launch_colmax(int N, int64_t M, const double* U, double* out, hipStream_t s);
+struct ArrheniusAt;
+void launch_rates_skip_T(int64_t R, const ArrheniusAt& at, double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate,
+                         const int* skip, hipStream_t s);
 void launch_rates_skip(int64_t R, const double* k, const double* u, const int32_t* x0, const int32_t* x1, double* rate,
                        const int* skip, hipStream_t s);
 
