@@ -263,8 +263,17 @@ int kin_newton_solve(kin_network* h, double c, const double* u, const double* b,
 
 /* ---- device / build information ------------------------------------------------------- */
 int kin_device_count(int* n);
+/* Selects the device for handles created afterwards by this thread; a handle remembers the device it was created on
+ * and every later call on it runs there, whatever the calling thread's current device is. Handles are independent:
+ * K handles driven by K host threads may share one GPU (concurrent replicas of an ensemble) or sit on different ones. */
 int kin_set_device(int device);
 const char* kin_version(void);
+/* Layout version of this header's structs and argument lists. A binding compares it (and, if it wants certainty, the
+ * struct sizes) with the values it was written against before the first call: kin_params / kin_stats have grown between
+ * versions (1: round 1; 2: + dtmin and the LU-cache counters; 3: + the library-order sweep entry points). */
+#define KIN_ABI_VERSION 3
+int kin_abi_version(void);
+int64_t kin_struct_size(int which); /* 0: sizeof(kin_params), 1: sizeof(kin_stats), else -1 */
 
 #ifdef __cplusplus
 }

@@ -28,8 +28,9 @@ SYMBOLS = [
     "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version", "kin_solution_dot", "kin_rate_table_rows",
     "kin_solution_max_dev", "kin_rate_table_dev", "kin_rhs_block_dev",
     "kin_lib_layout", "kin_lib_layout_host", "kin_states_to_lib_dev", "kin_states_from_lib_dev", "kin_rates_to_lib_dev", "kin_rate_table_lib_dev",
-    "kin_rhs_tiled_dev", "kin_rhs_batched_T_dev",
+    "kin_rhs_tiled_dev", "kin_rhs_batched_T_dev", "kin_abi_version", "kin_struct_size",
 ]
+ABI_VERSION = 3   # include/kinetica_hip.h: KIN_ABI_VERSION this binding was written against
 
 
 class KinParams(ctypes.Structure):
@@ -68,6 +69,12 @@ def lib():
                               "(the HIP extension is mandatory, there is no CPU fallback)")
         L = ctypes.CDLL(LIB_PATH)
         P64, PD = POINTER(c_int64), POINTER(c_double)
+        L.kin_struct_size.restype = c_int64
+        L.kin_struct_size.argtypes = [c_int]
+        if L.kin_abi_version() != ABI_VERSION or L.kin_struct_size(0) != ctypes.sizeof(KinParams) or \
+                L.kin_struct_size(1) != ctypes.sizeof(KinStats):
+            raise ImportError(f"{LIB_PATH}: ABI version {L.kin_abi_version()} / struct sizes do not match this binding "
+                              f"(version {ABI_VERSION}); rebuild the library")
         L.kin_version.restype = c_char_p
         L.kin_last_error.restype = c_char_p
         L.kin_last_error.argtypes = [c_void_p]

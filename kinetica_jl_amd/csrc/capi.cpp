@@ -72,7 +72,13 @@ static void require(bool c, int code, const char* msg) {
 
 extern "C" {
 
-const char* kin_version(void) { return "kinetica-hip 0.1 (gfx950)"; }
+const char* kin_version(void) { return "kinetica-hip 0.3 (gfx950)"; }
+
+int kin_abi_version(void) { return KIN_ABI_VERSION; }
+
+int64_t kin_struct_size(int which) {
+  return which == 0 ? (int64_t)sizeof(kin_params) : which == 1 ? (int64_t)sizeof(kin_stats) : -1;
+}
 
 int kin_device_count(int* n) {
   if (!n) return KIN_ERR_INVALID_ARG;

@@ -1,0 +1,98 @@
+"""Independent cross-check of the committed C3 / C4 truths (tests/golden/truth_c3.npz, truth_c4.npz).
+
+Those truths come from oracle/cpu_bdf.cpp - the same BDF family as the device integrator, at 1000x tighter tolerances.
+A semantic error shared by both (restart rule, zero-order hold of the rate constants, chunk stitching) would be invisible
+in a comparison between them. This script integrates the same problems with an integrator that shares nothing with
+them - SciPy's Radau IIA (order 5, own step control, SuperLU) on the oracle's RHS and analytic sparse Jacobian, straight
+through [0, t_end] for the static case and segment by segment between rate updates for the ramp (no chunking, no BDF
+history, no LU cache) - and stores its deviation from the committed truth, in units of the default tolerances
+(abstol 1e-10 + reltol 1e-8 |u|), as `self_check_independent` inside the truth files. The tests assert it.
+
+    python tests/golden/make_truth_independent.py c3 c4        (tens of minutes on one core each)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.integrate import solve_ivp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from kinetica_jl_amd.synth import synthetic_crn  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+ABSTOL, RELTOL = 1e-10, 1e-8
+TIGHT = 1e-3                      # the independent run uses the tolerances the stored truth was made with
+
+
+def units(u, ref):
+    return np.abs(u - ref) / (ABSTOL + RELTOL * np.abs(ref))
+
+
+def radau(on, k, u0, t0, t1, t_eval):
+    n = [0]
+
+    def f(t, u):
+        n[0] += 1
+        return on.rhs(k, u)
+
+    sol = solve_ivp(f, (t0, t1), u0, method="Radau", jac=lambda t, u: on.jac(k, u).tocsc(), rtol=RELTOL * TIGHT, atol=ABSTOL * TIGHT,
+                    t_eval=t_eval, first_step=1e-22)
+    assert sol.success, sol.message
+    return sol.y.T, sol.nfev, sol.njev, sol.nlu
+
+
+def update(path, **fields):
+    d = dict(np.load(path))
+    d.update(fields)
+    np.savez_compressed(path, **d)
+
+
+def c3():
+    path = os.path.join(HERE, "truth_c3.npz")
+    tr = np.load(path)
+    net, Ea, A = synthetic_crn(10000, 50000)
+    on = orc.OracleNetwork.from_flat(net)
+    k = orc.arrhenius(Ea, A, float(tr["T"]), k_max=1e12)
+    u0 = np.zeros(10000); u0[0] = 1.0
+    t0 = time.time()
+    t_eval = tr["t"][1:]
+    u, nfev, njev, nlu = radau(on, k, u0, 0.0, float(tr["t"][-1]), t_eval)
+    dev = units(u, tr["u"][1:])
+    print(f"c3: Radau {nfev} rhs, {njev} jac, {nlu} lu, {time.time() - t0:.0f} s; max deviation from the stored truth {dev.max():.3f} units, "
+          f"rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
+    update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
+           independent_method="scipy Radau, oracle rhs + analytic sparse Jacobian, rtol 1e-11, atol 1e-13, no chunking")
+
+
+def c4():
+    """First chunk of the ramp (10 ms, 10 rate updates, saves at 0 / 5 / 10 ms): piecewise-constant k, one Radau
+    integration per interval between rate updates."""
+    path = os.path.join(HERE, "truth_c4.npz")
+    tr = np.load(path)
+    net, Ea, A = synthetic_crn(10000, 50000)
+    on = orc.OracleNetwork.from_flat(net)
+    tst, T = tr["tstops"], tr["T_stops"]
+    u = np.zeros(10000); u[0] = 1.0
+    saves = {}
+    t0 = time.time()
+    for i in range(10):                                     # [tst[i], tst[i+1]) with the rates of stop i
+        k = orc.arrhenius(Ea, A, float(T[i]), k_max=1e12)
+        # segment-local time: the first steps after a rate switch are ~1e-20 s, below the resolution of t = 5e-3
+        y, nfev, njev, nlu = radau(on, k, u, 0.0, float(tst[i + 1] - tst[i]), [float(tst[i + 1] - tst[i])])
+        u = y[-1]
+        print(f"   segment {i}: {nfev} rhs, {nlu} lu, {time.time() - t0:.0f} s", flush=True)
+        for ts in (5e-3, 1e-2):
+            if abs(tst[i + 1] - ts) < 1e-12:
+                saves[ts] = u.copy()
+    idx = {5e-3: int(np.argmin(np.abs(tr["t"] - 5e-3))), 1e-2: int(np.argmin(np.abs(tr["t"] - 1e-2)))}
+    dev = np.stack([units(saves[ts], tr["u"][idx[ts]]) for ts in (5e-3, 1e-2)])
+    print(f"c4: max deviation from the stored truth {dev.max():.3f} units, rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
+    update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
+           independent_method="scipy Radau per rate interval (zero-order hold), first chunk (saves at 5 and 10 ms), rtol 1e-11, atol 1e-13")
+
+
+if __name__ == "__main__":
+    for name in sys.argv[1:] or ["c3", "c4"]:
+        {"c3": c3, "c4": c4}[name]()

@@ -189,6 +189,18 @@ def test_full_size_properties_c3():
     dU2 = h.rhs_batched(U)
     for b in (0, B // 2, B - 1):
         assert (np.abs(dU2[b] - dU[b]) / (on.abs_rhs(k, U[b]) + 1e-300)).max() < 1e-14
+    # The exact instantiation bench.py times (sweep_reg_kernel<8, 4, false, 1024>: 10k / 50k, more states than compute units,
+    # every state with its OWN rate constants - Arrhenius at its own temperature, as the bench builds them), element by
+    # element against the oracle on sampled states: the first and last state of the first wave of workgroups, states of
+    # later trips of the state loop (their u and first k batch were prefetched across the state boundary), the last state
+    B3 = 300
+    U3 = np.stack([_state(10000, 500 + b) for b in range(B3)])
+    T3 = np.linspace(500.0, 1200.0, B3)
+    K3 = np.stack([orc.arrhenius(Ea, A, T, k_max=1e12) for T in T3])
+    dU3 = h.rhs_batched(U3, K3)
+    for b in (0, 1, 255, 256, 257, 280, B3 - 1):
+        sc = on.abs_rhs(K3[b], U3[b]) + 1e-300
+        assert (np.abs(dU3[b] - on.rhs(K3[b], U3[b])) / sc).max() < TOL, b
     h.close()
 
 
