@@ -237,7 +237,7 @@ def output_tree(out):
     discovery levels) are written as empty collections."""
     sol, pars, cs = out.sol, out.pars, out.conditions
     sol_vcs = None if out.sol_vcs is None else {str(k): np.asarray(v, dtype=np.float64) for k, v in out.sol_vcs.items()}
-    sol_k = None if out.sol_k is None else OrderedDict([("u", ("vecvec", out.sol_k.u)), ("t", np.asarray(out.sol_k.t, dtype=np.float64))])
+    sol_k = None if out.sol_k is None else OrderedDict([("u", ("vecvec", np.asarray(out.sol_k.u))), ("t", np.asarray(out.sol_k.t, dtype=np.float64))])
     u0 = pars.u0
     if isinstance(u0, dict):
         u0 = ("dict_sf", dict(u0))

@@ -24,7 +24,7 @@ from .synth import FlatNetwork, from_lists
 __all__ = ["SpeciesData", "RxData", "RxFilter", "get_filter_mask", "DummyKineticCalculator",
            "PrecalculatedArrheniusCalculator", "PrecalculatedLindemannCalculator", "allows_continuous",
            "has_conditions", "setup_network", "ODESimulationParams", "StaticODESolve", "VariableODESolve",
-           "solve_network", "identify_next_seeds", "insert_inert", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
+           "HIPBDF", "HIPRK45", "ArrheniusRates", "solve_network", "identify_next_seeds", "insert_inert", "ODESolveOutput", "ODESolution", "tconvert", "make_u0", "apply_low_k_cutoff",
            "get_max_rates", "get_initial_rates", "calculate_discrete_rates"]
 
 _T_UNIT = {  # src/utils.jl:77-97
@@ -229,6 +229,22 @@ def _call_calc(calc, conds: dict):
     return calc(T=conds["T"])
 
 
+# ---- solver sentinels: what `pars.solver` holds to select this backend (HIPBDF / HIPRK45) -------------
+@dataclass
+class HIPBDF:
+    """`ODESimulationParams(solver=HIPBDF(), ...)`: the library's variable-order BDF with the on-device sparse LU
+    (kin_solve). The reference hands `pars.solver` to `init` together with `dtmin = eps(solve_chunkstep)` or
+    `eps(tspan[end])` (methods.jl:164, 232, 694, 770) and `ODESimulationParams` has no field for it (params.jl:3-27):
+    a solver-level option therefore lives on the solver object. `dtmin=None` keeps the reference's value."""
+    dtmin: Optional[float] = None
+
+
+@dataclass
+class HIPRK45:
+    """`ODESimulationParams(solver=HIPRK45(), ...)`: the explicit Dormand-Prince 5(4) pair (kin_solve_explicit)."""
+    dtmin: Optional[float] = None
+
+
 # ---- ODESimulationParams (src/solving/params.jl) ---------------------------------------------------
 @dataclass
 class ODESimulationParams:
@@ -251,7 +267,8 @@ class ODESimulationParams:
     low_k_cutoff: Union[float, str] = "auto"     # :auto / :none / number
     low_k_maxconc: float = 2.0
     allow_short_u0: bool = False
-    dtmin: Optional[float] = None   # EXTENSION (not a field of the reference's struct): None = what the reference hard-codes,
+    dtmin: Optional[float] = None   # EXTENSION kept for earlier callers (not a field of the reference's struct; prefer
+                                    # `solver=HIPBDF(dtmin=...)`): None = what the reference hard-codes,
                                     # eps(solve_chunkstep) / eps(tspan[end]) (methods.jl:164, 232, 694, 770)
 
     def __post_init__(self):
@@ -273,11 +290,21 @@ class ODESimulationParams:
     @property
     def explicit(self):
         """True when `solver` selects the explicit integrator."""
+        if isinstance(self.solver, HIPRK45):
+            return True
+        if isinstance(self.solver, HIPBDF):
+            return False
         if self.solver is None or (isinstance(self.solver, str) and self.solver.upper() in ("BDF", "CVODE_BDF", "IMPLICIT")):
             return False
         if isinstance(self.solver, str) and self.solver.upper() in ("RK45", "DP5", "EXPLICIT"):
             return True
-        raise ValueError(f"solver must be None / 'BDF' or 'RK45' / 'DP5' / 'explicit', got {self.solver!r}")
+        raise ValueError(f"solver must be None / 'BDF' / HIPBDF() or 'RK45' / 'DP5' / 'explicit' / HIPRK45(), got {self.solver!r}")
+
+    @property
+    def solver_dtmin(self):
+        """dtmin of the solver sentinel, else the extension field, else None (the reference's own choice)."""
+        d = getattr(self.solver, "dtmin", None)
+        return self.dtmin if d is None else d
 
     def to_kin_params(self):
         return capi.KinParams(tspan0=self.tspan[0], tspan1=self.tspan[1], abstol=self.abstol, reltol=self.reltol,
@@ -285,7 +312,7 @@ class ODESimulationParams:
                               solve_chunks=int(self.solve_chunks), ban_negatives=int(self.ban_negatives),
                               solve_chunkstep=self.solve_chunkstep, maxiters=int(self.maxiters),
                               save_interval=-1.0 if self.save_interval is None else self.save_interval,
-                              dtmin=0.0 if self.dtmin is None else float(self.dtmin))
+                              dtmin=0.0 if self.solver_dtmin is None else float(self.solver_dtmin))
 
 
 # ---- solve methods (src/solving/methods.jl:7-58) -----------------------------------------------------
@@ -365,6 +392,17 @@ def make_u0(sd, pars):
     return out
 
 
+def discrete_stop_temperatures(conditions):
+    """(tstops, T(tstops)): the condition-interpolation half of calculate_discrete_rates (solve_utils.jl:91-104) for a
+    calculator that reads :T only - what kin_solve needs instead of a rate table."""
+    if not conditions.discrete_updates:
+        raise RuntimeError("Cannot calculate discrete rates for a continuous ConditionSet.")
+    tstops = get_tstops(conditions)
+    prof = conditions.profiles[conditions.symbols.index("T")]
+    T = np.full(len(tstops), float(prof.value)) if isstatic(prof) else np.asarray(prof.sol(tstops), dtype=float)
+    return tstops, T
+
+
 def calculate_discrete_rates(conditions, calculator, nr, handle=None):
     """solve_utils.jl:91-109: k_precalc[s] = calculator(conditions interpolated at tstop_s).
     With the Arrhenius calculator and a live network handle the S x R table is generated by the
@@ -408,6 +446,63 @@ class DiscreteRates:
     """sol_k: DiffEqArray(k_precalc, tstops) (methods.jl:739, io.jl:38)."""
     t: np.ndarray
     u: np.ndarray            # [S][R']
+
+
+class ArrheniusRates:
+    """sol_k of a discrete-update solve with the Arrhenius calculator: the same DiffEqArray(k_precalc, tstops) seen from
+    outside (`t`, `u[s]`, `len`), but no S x R table exists anywhere - not on the host, not on the device (C4: 14 001 x
+    50 000 doubles = 5.6 GB). The solve received the temperatures at the stops and formed each stop's rate constants on
+    the device when it reached it (kin_solve with T_stops); a row asked for here is evaluated by the same device functor
+    (kin_arrhenius_eval: calculator.jl:223-232 literally), so `u[s]` is bit for bit what the integrator used.
+    `u` of the whole object (`np.asarray(sol_k.u)`, `save_output`) materialises all rows on demand."""
+
+    def __init__(self, t, T, Ea, A, k_max, t_mult):
+        self.t = np.asarray(t, dtype=float)
+        self.T = np.asarray(T, dtype=float)
+        self._Ea, self._A, self._k_max, self._t_mult = np.array(Ea, dtype=float), np.array(A, dtype=float), k_max, t_mult
+        self._full = None
+
+    def __len__(self):
+        return len(self.t)
+
+    def row(self, s):
+        if self._full is not None:
+            return self._full[s]
+        return capi.arrhenius_eval(self._Ea, self._A, float(self.T[s]), self._k_max, self._t_mult)
+
+    __getitem__ = row
+
+    @property
+    def u(self):
+        return _LazyRows(self)
+
+    def materialize(self):
+        if self._full is None:
+            self._full = np.stack([self.row(s) for s in range(len(self.t))]) if len(self.t) else np.empty((0, len(self._Ea)))
+        return self._full
+
+
+class _LazyRows:
+    """`sol_k.u`: rows on demand (`u[s]`), the full [S][R'] array when converted (`np.asarray(u)`, `u.shape`)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def __len__(self):
+        return len(self._o)
+
+    def __getitem__(self, s):
+        if isinstance(s, (int, np.integer)):
+            return self._o.row(int(s))
+        return self._o.materialize()[s]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._o.materialize()
+        return a if dtype is None else a.astype(dtype)
+
+    @property
+    def shape(self):
+        return (len(self._o), len(self._o._Ea))
 
 
 @dataclass
@@ -513,10 +608,11 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
                 h.set_rates(get_initial_rates(conditions, calc))
                 h.integrator_init(pars.to_kin_params(), u0)
             else:
-                tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
                 if arr:
+                    tstops, T = discrete_stop_temperatures(conditions)
                     h.integrator_init(pars.to_kin_params(), u0, tstops=tstops, T_stops=T)
                 else:
+                    tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=None)
                     h.integrator_init(pars.to_kin_params(), u0, tstops=tstops, k_table=table)
             integ, h = HipIntegrator(h, sd_a, rd_a, pars), None      # the integrator owns the handle now
             return integ
@@ -529,11 +625,16 @@ def solve_network(method, sd, rd, copy_network=True, return_integrator=False):
             # k(t) = calculator(T(t)) evaluated on the device at every step attempt
             t, u, rc, st, status = h.solve_continuous(pars.to_kin_params(), u0, nodes_t, nodes_T)
         else:
-            tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=h if arr else None)
-            sol_k = DiscreteRates(tstops, table)
             if arr:
+                # Arrhenius + discrete updates: only T(tstop) is evaluated here (calculate_discrete_rates' interpolation of
+                # the profile solutions, solve_utils.jl:91-104); the rate constants of a stop are formed on the device when
+                # the solve reaches it, and sol_k hands out rows on demand - no S x R table on either side
+                tstops, T = discrete_stop_temperatures(conditions)
+                sol_k = ArrheniusRates(tstops, T, calc.Ea, calc.A, calc.k_max, calc.t_mult)
                 t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, T_stops=T, explicit=pars.explicit)
             else:
+                tstops, T, table = calculate_discrete_rates(conditions, calc, rd_a.nr, handle=None)
+                sol_k = DiscreteRates(tstops, table)
                 t, u, rc, st, status = h.solve(pars.to_kin_params(), u0, tstops=tstops, k_table=table, explicit=pars.explicit)
         if status == capi.KIN_ERR_SOLVE_FAILED:
             raise RuntimeError("ODE solution failed.")      # ErrorException (solve_utils.jl:405-411)

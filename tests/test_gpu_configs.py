@@ -164,3 +164,60 @@ def test_c5_two_chunk_solve_against_truth(golden_dir):
     m = h.solution_dot(net.mass.astype(float))
     np.testing.assert_allclose(m, m[0], rtol=5e-7, atol=0)
     h.close()
+
+
+# ---- the same configurations through the reference's own interface (solving.solve_network), not the raw C ABI ----------
+def _named(net):
+    from kinetica_jl_amd import solving as S
+    return S.SpeciesData.from_names([f"S{i}" for i in range(net.n_species)]), S.RxData.from_flat(net)
+
+
+def test_c3_complete_timespan_through_solve_network(golden_dir, c3):
+    """StaticODESolve with solve_chunks=false (methods.jl:132-183) at 10k species through solve_network: one integration
+    over (0, 2 ms) without chunk restarts, against the chunkwise truth - the same exact solution, so the same bound."""
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    net, Ea, A, k = c3
+    z = np.load(os.path.join(golden_dir, "truth_c3.npz"))
+    sd, rd = _named(net)
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e12)
+    # (dtmin: the first step this CRN needs at 1000 K is 3.1e-19 s - above eps(1e-3) = 2.2e-19, the reference's dtmin for
+    # the default 1 ms chunks, but below eps(2e-3) = 4.3e-19, its dtmin for this complete-timespan solve: DtLessThanMin there)
+    pars = S.ODESimulationParams(tspan=(0.0, 2e-3), u0={"S0": 1.0}, solver=S.HIPBDF(dtmin=RAMP_DTMIN), solve_chunks=False,
+                                 save_interval=1e-3, low_k_cutoff="none")
+    res = S.solve_network(S.StaticODESolve(pars, C.ConditionSet({"T": 1000.0}), calc), sd, rd)
+    assert res.sol.retcode == "Success" and res.sol_k is None
+    np.testing.assert_allclose(res.sol.t, z["t"], rtol=0, atol=1e-18)
+    assert res.sol.stats["n_restarts"] == 1 and res.sol.stats["n_chunks"] == 1
+    assert units(res.sol.u, z["u"]).max() <= 100 and rms_units(res.sol.u, z["u"]) <= 2
+    assert res.rd.nr == 50000 and np.array_equal(res.sol.umax, res.sol.u.max(axis=0))
+
+
+def test_c4_first_chunk_through_solve_network(golden_dir):
+    """VariableODESolve, LinearGradientProfile(50 K/s from 500 K) with ts_update 1 ms, chunk 10 ms, save 5 ms, through
+    solve_network with the solver sentinel carrying dtmin (the reference's hard-coded eps(solve_chunkstep) ends this
+    configuration in DtLessThanMin, see above): the first chunk of C4 against its truth; sol_k hands out rows on demand and
+    no 11 x 50 000 table was ever built."""
+    from kinetica_jl_amd import conditions as C
+    from kinetica_jl_amd import solving as S
+    z = np.load(os.path.join(golden_dir, "truth_c4.npz"))
+    assert float(z["self_check"]) < 5.0
+    net, Ea, A = synthetic_crn(10000, 50000)
+    sd, rd = _named(net)
+    calc = S.PrecalculatedArrheniusCalculator(Ea, A, k_max=1e12)
+    cs = C.ConditionSet({"T": C.LinearGradientProfile(rate=50.0, X_start=500.0, X_end=500.5)}, ts_update=1e-3)
+    pars = S.ODESimulationParams(tspan=(0.0, 1e-2), u0={"S0": 1.0}, solver=S.HIPBDF(dtmin=RAMP_DTMIN), solve_chunkstep=1e-2,
+                                 save_interval=5e-3, low_k_cutoff="none")
+    res = S.solve_network(S.VariableODESolve(pars, cs, calc), sd, rd)
+    assert res.sol.retcode == "Success" and res.sol.stats["n_restarts"] == 10
+    np.testing.assert_allclose(res.sol.t, z["t"][:3], rtol=0, atol=1e-17)
+    assert units(res.sol.u, z["u"][:3]).max() <= 1000 and rms_units(res.sol.u, z["u"][:3]) <= 10
+    assert isinstance(res.sol_k, S.ArrheniusRates) and len(res.sol_k) == 11 and res.sol_k.u.shape == (11, 50000)
+    np.testing.assert_allclose(res.sol_k.t, z["tstops"][:11], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(res.sol_k.T, z["T_stops"][:11], rtol=1e-12)
+    np.testing.assert_allclose(res.sol_k.u[3], orc.arrhenius(Ea, A, float(res.sol_k.T[3]), k_max=1e12), rtol=2e-15)
+    # without the sentinel's dtmin the reference's own value applies and the solve fails as the reference's would
+    pars0 = S.ODESimulationParams(tspan=(0.0, 1e-2), u0={"S0": 1.0}, solver=S.HIPBDF(), solve_chunkstep=1e-2, save_interval=5e-3,
+                                  low_k_cutoff="none")
+    with pytest.raises(RuntimeError, match="ODE solution failed."):
+        S.solve_network(S.VariableODESolve(pars0, cs, calc), sd, rd)

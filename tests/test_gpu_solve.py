@@ -270,7 +270,7 @@ def test_c1_getting_started_static_and_variable(golden_dir):
     assert res.sol.retcode == "Success" and len(res.sol.t) == 13 and res.sol.t[-1] == 6.0
     assert res.sol_k.u.shape == (13, res.rd.nr) and res.rd.nr <= 30
     np.testing.assert_allclose(res.sol_k.u, orc.rate_table(calc.Ea, calc.A, 500.0 + 50.0 * res.sol_k.t, k_max=1e12), rtol=2e-15)
-    ks = res.sol_k.u
+    ks = np.asarray(res.sol_k.u)
     to, uo, rco, sto = oracle_solve(rd_to_flat(res.sd, res.rd), dict(tspan=(0.0, 6.0), solve_chunks=True, solve_chunkstep=1.0,
                                                                         save_interval=0.5), res.sol.u[0], tstops=res.sol_k.t, ks=ks)
     assert rco == 0
