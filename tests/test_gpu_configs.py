@@ -8,8 +8,10 @@ abstol 1e-10, reltol 1e-8 (params.jl:61-62):
   * C3 (static, 2 chunks, ~900 steps):          max e <= 100,  rms e <= 2     (measured 25 / 0.45; the CPU baseline
     at the same tolerances sits at 25.5 / 0.46 from the truth and 23 from the device);
   * C4 / C5 (rate update + integrator restart every 1 ms): the integrator controls the LOCAL error per step in the rms
-    norm over the species, and 30 order-1 restarts accumulate: C4 max e <= 1000, rms e <= 10 (measured 585 / 6.0 on the
-    device; C5, 50k species: max e <= 2000, rms e <= 20, measured 948 / 9.5), 470 / 4.8 for the CPU baseline, 680 / 7.0 for the CPU baseline without the LU cache), and the error is
+    norm over the species, and 30 order-1 restarts accumulate: C4 max e <= 900, rms e <= 9 (measured 773 / 7.9 on the
+    device in round 3, 585 / 6.0 in round 2; C5, 50k species: max e <= 1400, rms e <= 14, measured 556 / 5.5 and 948 / 9.5;
+    470 / 4.8 for the CPU baseline, 680 / 7.0 for the CPU baseline without the LU cache; keeping the difference history
+    across rate updates - KIN_WARM_RESTART=1 - does not tighten it: 705 / 11.0 and 565 / 5.7), and the error is
     tolerance proportional: the same solve with 10x tighter tolerances must come within max e <= 100 (in DEFAULT units).
 """
 import os
@@ -108,7 +110,7 @@ def test_c4_ramp_prefix_against_truth(golden_dir):
     t, u, rc, st, status = h.solve(kp(3e-2, 1e-2, 5e-3, dtmin=RAMP_DTMIN), u0, tstops=tst, T_stops=T)
     assert status == capi.KIN_OK and rc == 0 and st["n_restarts"] == 30 and st["n_chunks"] == 3
     np.testing.assert_allclose(t, z["t"], rtol=0, atol=1e-17)
-    assert units(u, z["u"]).max() <= 1000 and rms_units(u, z["u"]) <= 10
+    assert units(u, z["u"]).max() <= 900 and rms_units(u, z["u"]) <= 9      # measured 773 / 7.9 (tools/ramp_units.py)
     # tolerance proportionality: 10x tighter tolerances, deviation still measured in DEFAULT units
     t2, u2, rc2, st2, _ = h.solve(kp(3e-2, 1e-2, 5e-3, abstol=1e-11, reltol=1e-9, dtmin=RAMP_DTMIN), u0, tstops=tst, T_stops=T)
     assert rc2 == 0 and units(u2, z["u"]).max() <= 100 and rms_units(u2, z["u"]) <= 1
@@ -159,8 +161,9 @@ def test_c5_two_chunk_solve_against_truth(golden_dir):
     assert status == capi.KIN_OK and rc == 0 and st["n_restarts"] == 20
     sel = np.searchsorted(t, z["t"])
     np.testing.assert_allclose(t[sel], z["t"], rtol=0, atol=1e-17)
-    # measured 948 / 9.5 (max over 5x as many species as C4, and a truth whose own looser cousin sits 24 units away)
-    assert units(u[sel], z["u"]).max() <= 2000 and rms_units(u[sel], z["u"]) <= 20
+    # measured 556 / 5.5 (tools/ramp_units.py; 948 / 9.5 with round 2's build: the step sequences of two builds differ and
+    # so does where each lands inside its error band; the bound is 1.5x the larger rms and still flags a regression)
+    assert units(u[sel], z["u"]).max() <= 1400 and rms_units(u[sel], z["u"]) <= 14
     m = h.solution_dot(net.mass.astype(float))
     np.testing.assert_allclose(m, m[0], rtol=5e-7, atol=0)
     h.close()
@@ -211,7 +214,7 @@ def test_c4_first_chunk_through_solve_network(golden_dir):
     res = S.solve_network(S.VariableODESolve(pars, cs, calc), sd, rd)
     assert res.sol.retcode == "Success" and res.sol.stats["n_restarts"] == 10
     np.testing.assert_allclose(res.sol.t, z["t"][:3], rtol=0, atol=1e-17)
-    assert units(res.sol.u, z["u"][:3]).max() <= 1000 and rms_units(res.sol.u, z["u"][:3]) <= 10
+    assert units(res.sol.u, z["u"][:3]).max() <= 900 and rms_units(res.sol.u, z["u"][:3]) <= 9
     assert isinstance(res.sol_k, S.ArrheniusRates) and len(res.sol_k) == 11 and res.sol_k.u.shape == (11, 50000)
     np.testing.assert_allclose(res.sol_k.t, z["tstops"][:11], rtol=0, atol=1e-15)
     np.testing.assert_allclose(res.sol_k.T, z["T_stops"][:11], rtol=1e-12)
