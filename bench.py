@@ -67,11 +67,16 @@ def self_launch(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    # every rank's stderr goes to a file of its own (printed when a rank fails): a rank that dies no longer takes its
+    # reason with it, and the ranks' messages do not interleave on the launcher's stderr
+    logdir = tempfile.mkdtemp(prefix="kin_bench_ranks_", dir="/tmp")
+    logs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        logs.append(open(os.path.join(logdir, f"rank{r}.stderr"), "w"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
     # a rank that dies (e.g. fewer GPUs than ranks) leaves the others waiting at the rendezvous: watch the children and,
     # when one exits with an error, end the rest (these exact child processes) instead of hanging until an outer timeout
     import threading
@@ -93,11 +98,20 @@ def self_launch(args):
                 except subprocess.TimeoutExpired:
                     p.kill()
             print(f"bench.py: a rank exited with status {rc}; the other ranks were stopped", file=sys.stderr)
+            for r, f in enumerate(logs):
+                f.flush()
+                tail = open(f.name).read()[-2000:]
+                if tail.strip():
+                    print(f"---- rank {r} stderr (tail) ----\n{tail}", file=sys.stderr)
             break
         if all(c == 0 for c in states):
             break
         time.sleep(0.2)
     reader.join(timeout=5)
+    for f in logs:
+        f.close()
+    if rc == 0:
+        shutil.rmtree(logdir, ignore_errors=True)
     sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     raise SystemExit(rc)
@@ -235,6 +249,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.pmc_child:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
 
     import torch  # device memory, streams, torch.distributed: plumbing only (importing it makes no GPU call)
 
@@ -248,12 +265,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         backend = os.environ.get("BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        tmo = datetime.timedelta(seconds=int(os.environ.get("BENCH_RENDEZVOUS_TIMEOUT", "180")))   # a missing rank ends the run
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     from kinetica_jl_amd import capi
     from kinetica_jl_amd.distributed import gather_solution_max, max_over_ranks
@@ -527,12 +546,13 @@ def main():
         out["cpu_baseline_all_cores"] = {"value": n_eval / dt, "unit": "RHS evals/s", "cores": cores, "kind": "port",
                                          "sample": f"{n_eval} evaluations, {Ub.shape[0]} states per call, OpenMP over states, "
                                                    f"{dt:.1f} s"}
-    if rank == 0:
-        print(json.dumps(out))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     h.close()
+    if rank == 0:
+        assert out["n_gpus"] == world
+        print(json.dumps(out), flush=True)      # the LAST line of rank 0's stdout (backends may print banners before it)
 
 
 if __name__ == "__main__":

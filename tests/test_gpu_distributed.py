@@ -89,3 +89,27 @@ def test_two_ranks_on_one_card():
         ref = on.rhs(k, uu)
         assert np.max(np.abs(du - ref) / (on.abs_rhs(k, uu) + 1e-300)) < 1e-13
         assert timing["ranks"] == 2 and timing["split_rhs_plus_allreduce_us"] > 0
+
+
+def test_bench_two_ranks_on_one_card_end_to_end():
+    """`python bench.py --gpus 2` as the driver would start it (self-launch, one process per rank), rehearsed on the one
+    card of the test box over gloo: the JSON line is the last line of stdout and carries the contract's fields for N = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--species", "1000", "--reactions", "5000",
+                        "--batch", "256", "--steps", "3", "--warmup", "1", "--solve-chunks", "2", "--no-cpu", "--no-pmc",
+                        "--sustain-seconds", "0", "--replicas", ""], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["unit"] == "RHS evals/s" and rec["dtype"] == "f64"
+    assert rec["solve_network"]["replicas"] == 2 and rec["solve_network"]["retcode"] == 0
+    assert rec["single_trajectory_rhs_allreduce"]["ranks"] == 2
+    # a world size that contradicts --gpus is refused before any GPU work
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-pmc"],
+                         env=dict(os.environ, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

@@ -22,3 +22,13 @@ st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 dt = rc.timed(lambda: h.rhs_batched_dev(B, u.data_ptr(), k.data_ptr(), du.data_ptr(), st.cuda_stream))
 alg = 20 * R2 + B * (8 * R2 + 16 * N)
 print("unpaired (70 %% of C3's reactions): %.3f ms  %.0f GB/s  %.1f %% of 8 TB/s" % (dt * 1e3, alg / dt / 1e9, alg / dt / 8e10))
+# the same network in library order (k as the library-order rate table writes it): tiled sweep, k-stream and temperature form
+h.set_arrhenius(Ea[keep], A[keep], k_max=1e12)
+lay = h.lib_layout()
+T = torch.linspace(500.0, 1200.0, B, dtype=torch.float64, device=dev)
+kl = torch.empty((B, lay["k_len"]), dtype=torch.float64, device=dev)
+h.rate_table_lib_dev(T.cpu().numpy(), kl.data_ptr())
+dt = rc.timed(lambda: h.rhs_tiled_dev(B, u.data_ptr(), du.data_ptr(), d_k_lib=kl.data_ptr(), stream=st.cuda_stream))
+print("  library order, k stream (%d records for %d reactions): %.3f ms  %.0f GB/s  %.1f %% of 8 TB/s" % (lay["records"], R2, dt * 1e3, alg / dt / 1e9, alg / dt / 8e10))
+dt = rc.timed(lambda: h.rhs_tiled_dev(B, u.data_ptr(), du.data_ptr(), d_T=T.data_ptr(), stream=st.cuda_stream))
+print("  library order, temperature form: %.3f ms  %.2f M evals/s" % (dt * 1e3, B / dt / 1e6))
