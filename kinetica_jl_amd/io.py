@@ -154,11 +154,31 @@ def lower_vector_of_vectors(rows, dtype):
                         ("size", [len(rows)]), ("data", [lower_bits_array(np.asarray(r, dtype=dtype)) for r in rows])])
 
 
+def lower_typed_vector(items, eltype_name):
+    """Vector{T} of a NON-bits element type other than Any (Vector{String}, Vector{Symbol}): BSON.jl lowers every Array
+    except Vector{Any} to a tagged `array` document {tag, type = eltype, size, data}; for non-bits elements `data` is the
+    BSON array of the lowered elements (BSON.jl's `lower(x::Array)`; a plain BSON array would come back as Vector{Any})."""
+    return OrderedDict([("tag", "array"), ("type", lower_datatype(eltype_name)), ("size", [len(items)]),
+                        ("data", [lower(v) for v in items])])
+
+
+def _lower_vector_of(values, dt):
+    name = dt["name"]
+    if name == ["Core", "String"]:
+        return lower_typed_vector([str(v) for v in values], name)
+    if name == ["Core", "Int64"]:
+        return lower_bits_array(np.asarray(list(values), dtype=np.int64))
+    if name == ["Core", "Float64"]:
+        return lower_bits_array(np.asarray(list(values), dtype=np.float64))
+    return lower(list(values))
+
+
 def lower_dict(d, ktype, vtype):
-    """Dict{K,V} with non-Symbol keys: BSON.jl's struct form, data = [keys, values]."""
+    """Dict{K,V} with non-Symbol keys: BSON.jl's struct form, data = [keys, values] with keys :: Vector{K} and
+    values :: Vector{V} lowered as TYPED vectors."""
     ks, vs = list(d.keys()), list(d.values())
     return OrderedDict([("tag", "struct"), ("type", lower_datatype(["Base", "Dict"], [ktype, vtype])),
-                        ("data", [lower(ks), lower(vs)])])
+                        ("data", [_lower_vector_of(ks, ktype), _lower_vector_of(vs, vtype)])])
 
 
 class Symbol(str):
@@ -247,7 +267,7 @@ def output_tree(out):
     return OrderedDict([
         ("KineticaCoreVersion", ("version", KINETICA_CORE_VERSION)),
         ("sd", OrderedDict([("toInt", ("dict_si", dict(out.sd.toInt))), ("n", int(out.sd.n)), ("xyz", []), ("level_found", ("dict_ii", {}))])),
-        ("rd", OrderedDict([("nr", int(out.rd.nr)), ("mapped_rxns", []),
+        ("rd", OrderedDict([("nr", int(out.rd.nr)), ("mapped_rxns", ("vec_string", [])),
                             ("id_reacs", ("vecvec_i", out.rd.id_reacs)), ("id_prods", ("vecvec_i", out.rd.id_prods)),
                             ("stoic_reacs", ("vecvec_i", out.rd.stoic_reacs)), ("stoic_prods", ("vecvec_i", out.rd.stoic_prods)),
                             ("dH", np.asarray(out.rd.dH if out.rd.dH is not None else [], dtype=np.float64)),
@@ -261,7 +281,7 @@ def output_tree(out):
                               ("low_k_cutoff", Symbol(lk) if isinstance(lk, str) else float(lk)),
                               ("allow_short_u0", bool(pars.allow_short_u0))])),
         ("sol", OrderedDict([("u", ("vecvec", sol.u)), ("t", np.asarray(sol.t, dtype=np.float64)), ("vcs", sol_vcs), ("k", sol_k)])),
-        ("conditions", OrderedDict([("symbols", [Symbol(s) for s in cs.symbols]), ("profiles", [_profile_dict(p) for p in cs.profiles]),
+        ("conditions", OrderedDict([("symbols", ("vec_symbol", [Symbol(s) for s in cs.symbols])), ("profiles", [_profile_dict(p) for p in cs.profiles]),
                                     ("discrete_updates", bool(cs.discrete_updates)),
                                     ("ts_update", None if cs.ts_update is None else float(cs.ts_update))])),
     ])
@@ -274,6 +294,10 @@ def _lower_tree(x):
             return lower_vector_of_vectors(np.asarray(v, dtype=np.float64), np.float64)
         if kind == "vecvec_i":
             return lower_vector_of_vectors([np.asarray(r, dtype=np.int64) for r in v], np.int64)
+        if kind == "vec_symbol":                      # Vector{Symbol}
+            return lower_typed_vector(v, ["Core", "Symbol"])
+        if kind == "vec_string":                      # Vector{String}
+            return lower_typed_vector(v, ["Core", "String"])
         if kind == "dict_si":
             return lower_dict(v, lower_datatype(["Core", "String"]), lower_datatype(["Core", "Int64"]))
         if kind == "dict_sf":
@@ -305,6 +329,10 @@ def load_output(outfile):
     tree = raise_(loads(open(outfile, "rb").read()))
     sd_t, rd_t, p_t, s_t, c_t = tree["sd"], tree["rd"], tree["pars"], tree["sol"], tree["conditions"]
     toInt = {str(k): int(v) for k, v in sd_t["toInt"].items()}
+    # the profile type named in the file selects a constructor from THIS list only (the reference evaluates the name,
+    # io.jl:238: a file is data, not code)
+    profile_types = {c.__name__: c for c in (C.StaticConditionProfile, C.NullDirectProfile, C.LinearDirectProfile,
+                                             C.NullGradientProfile, C.LinearGradientProfile, C.DoubleRampGradientProfile)}
     sd = S.SpeciesData(toInt, {v: k for k, v in toInt.items()}, int(sd_t["n"]))
     as_rows = lambda rows: [[int(x) for x in r] for r in rows]
     dH = np.asarray(rd_t["dH"], dtype=float)
@@ -326,7 +354,9 @@ def load_output(outfile):
     sol_vcs = None if s_t["vcs"] is None else {k: np.asarray(v, dtype=float) for k, v in s_t["vcs"].items()}
     profiles = {}
     for sym, pd in zip(c_t["symbols"], c_t["profiles"]):
-        cls = getattr(C, str(pd["pType"]))
+        if str(pd["pType"]) not in profile_types:
+            raise ValueError(f"unknown condition profile type {pd['pType']!r} in {outfile}")
+        cls = profile_types[str(pd["pType"])]
         if issubclass(cls, C.StaticConditionProfile):
             profiles[str(sym)] = cls(pd["value"])
             continue

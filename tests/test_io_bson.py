@@ -92,5 +92,23 @@ def test_tree_has_the_references_keys_and_is_valid_bson(tmp_path):
     assert d["sol"]["u"]["tag"] == "array" and d["sol"]["u"]["size"] == [9] and d["sol"]["u"]["data"][0]["size"] == [4]
     assert d["pars"]["tspan"] == {"tag": "tuple", "data": [0.0, 2.0]}
     assert d["pars"]["low_k_cutoff"] == {"tag": "symbol", "name": "auto"}
-    assert d["conditions"]["symbols"][0] == {"tag": "symbol", "name": "T"}
+    # Vector{Symbol} / the keys and values of Dict{String,Int}: TYPED vectors, i.e. tagged `array` documents (BSON.jl lowers
+    # every Array except Vector{Any} that way; a plain BSON array would load as Vector{Any} in Julia)
+    sy = d["conditions"]["symbols"]
+    assert sy["tag"] == "array" and sy["type"]["name"] == ["Core", "Symbol"] and sy["size"] == [2]
+    assert sy["data"][0] == {"tag": "symbol", "name": "T"}
+    keys, vals = d["sd"]["toInt"]["data"]
+    assert keys["tag"] == "array" and keys["type"]["name"] == ["Core", "String"] and isinstance(keys["data"], list)
+    assert vals["tag"] == "array" and vals["type"]["name"] == ["Core", "Int64"] and isinstance(vals["data"], bytes)
     assert d["sol"]["vcs"] is None and d["sol"]["k"]["t"]["size"] == [5]
+
+
+def test_profile_type_names_are_looked_up_in_a_fixed_list(tmp_path):
+    """The reference evaluates the profile type's name (io.jl:238); here a file is data: an unknown name is an error."""
+    f = str(tmp_path / "out.bson")
+    kio.save_output(make_output(), f)
+    tree = kio.loads(open(f, "rb").read())
+    tree["conditions"]["profiles"][0]["pType"]["name"] = "ConditionSet"
+    open(f, "wb").write(kio.dumps(tree))
+    with pytest.raises(ValueError, match="unknown condition profile type"):
+        kio.load_output(f)
