@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-solve-chunks", type=int, default=2, help="chunks the CPU baseline solves (the device is timed on the same ones)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="back-to-back sweeps after the timed region (sustained clock)")
     ap.add_argument("--replicas", default="1,2,4,8", help="concurrent replicas on one GPU to time (comma list, '' = skip)")
+    ap.add_argument("--no-tiled", dest="tiled", action="store_false", help="skip the library-order sweep legs (C3 + C5)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -366,6 +367,47 @@ def main():
                          "sustained_launch_ms": sustained_ms,
                          "sustained_frac": None if not sustained_ms else alg_bytes / (sustained_ms * 1e-3) / 8e12},
         }
+
+    # ---- the sweep in the library's own data layout (kin_rhs_tiled_dev): the same C3 states with k written in library
+    # order by the rate-table kernel and with NO k at all (rate constants formed inside the sweep from T[b], SURVEY M1'),
+    # and the C5 network (50k species / 250k reactions, state too large for LDS: hubs + windows), rank 0 at N = 1
+    if rank == 0 and world == 1 and args.tiled:
+        def tiled_leg(hh, Nn, Rr, Bb, uu, TT):
+            lay = hh.lib_layout()
+            kl = torch.empty((Bb, lay["k_len"]), dtype=torch.float64, device=dev)
+            hh.rate_table_lib_dev(TT.cpu().numpy(), kl.data_ptr())
+            dd = torch.empty_like(uu)
+
+            def ev(fn, reps=10):
+                fn(); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record(); torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+            ms_k = ev(lambda: hh.rhs_tiled_dev(Bb, uu.data_ptr(), dd.data_ptr(), d_k_lib=kl.data_ptr(), stream=stream))
+            ms_T = ev(lambda: hh.rhs_tiled_dev(Bb, uu.data_ptr(), dd.data_ptr(), d_T=TT.data_ptr(), stream=stream))
+            alg_k = 20 * Rr + Bb * (8 * Rr + 16 * Nn)
+            alg_T = 36 * Rr + Bb * (16 * Nn + 8)
+            del kl, dd
+            return {"species": Nn, "reactions": Rr, "states": Bb, "hubs": lay["hubs"], "windows": lay["windows"],
+                    "species_order_is_callers": lay["identity"],
+                    "k_stream": {"ms": ms_k, "evals_per_s": Bb / (ms_k * 1e-3), "algorithmic_bytes_M2": alg_k,
+                                 "GBps": alg_k / (ms_k * 1e-3) / 1e9, "frac_of_8TBps": alg_k / (ms_k * 1e-3) / 8e12, "bound": "hbm / LDS atomics"},
+                    "temperature_form": {"ms": ms_T, "evals_per_s": Bb / (ms_T * 1e-3), "algorithmic_bytes_M1prime": alg_T,
+                                         "GBps": alg_T / (ms_T * 1e-3) / 1e9, "bound": "FP64 VALU (2 exp per record) + LDS atomics"}}
+        out["tiled_sweep"] = {"kernel": "kin::tiled_sweep_kernel (library order: kin_lib_layout / kin_rate_table_lib_dev / kin_rhs_tiled_dev)",
+                              "C3": tiled_leg(h, N, R, B, d_u, T)}
+        net5, Ea5, A5 = synthetic_crn(50000, 250000)
+        h5 = capi.HipNetwork.from_flat(net5)
+        h5.set_arrhenius(Ea5, A5, k_max=1e12)
+        B5 = 1024
+        u5 = torch.pow(10.0, torch.rand((B5, 50000), dtype=torch.float64, device=dev, generator=g) * 12.0 - 12.0)
+        out["tiled_sweep"]["C5"] = tiled_leg(h5, 50000, 250000, B5, u5, torch.linspace(500.0, 1200.0, B5, dtype=torch.float64, device=dev))
+        out["tiled_sweep"]["C5"]["traffic_note"] = "PMC counters of this kernel: profiles/r03_c5_tiled_pmc.json (tools/pmc_tiled.sh)"
+        h5.close()
+        del u5
 
     # ---- ONE trajectory's RHS with the reactions split over the ranks and an all-reduce of du (N doubles):
     # measured at N > 1 so that the cost of the single-trajectory decomposition is a number, not an argument
