@@ -110,6 +110,7 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   static_assert(TILED_GROUP % (2 * NB) == 0, "segments are padded to whole pairs of batches");
   int pb = blockIdx.x, ps = 0, pi = 0;   // state, segment, iteration row inside the segment of the next request
   int4 pa = v.seginfo[0], pn = v.seginfo[T > 1 ? 1 : 0];   // x = first record, y = records, z = iteration rows
+  asm volatile("" : "+s"(pa.x), "+s"(pa.y), "+s"(pa.z), "+s"(pn.x), "+s"(pn.y), "+s"(pn.z));
   auto load_batch = [&](BatchT& G) {
     if (pi >= pa.z) {
       pi = 0; pa = pn;
@@ -197,7 +198,10 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       const bool last = s == T - 1;
       if (last) load_hubs(bn); else load_window(b, s + 1);
       pn = v.seginfo[ps + 1 == T ? 0 : ps + 1];
-      const int rows = v.seginfo[s].z;
+      int rows = v.seginfo[s].z;
+      // the scalar loads above are waited for HERE, behind the barrier: left to the compiler, the wait (lgkmcnt(0), which
+      // also drains the wave's LDS queue) lands on the join inside the record loop, once per batch
+      asm volatile("" : "+s"(pn.x), "+s"(pn.y), "+s"(pn.z), "+s"(rows));
       for (int q = 0; q < rows; q += 2 * NB) {
         consume(G0);
         load_batch(G0);
