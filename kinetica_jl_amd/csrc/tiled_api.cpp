@@ -169,6 +169,10 @@ int kin_rhs_tiled_dev(kin_network* h, int64_t B, const double* d_u_lib, const do
   ensure_tiled(h);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   if (d_T) ensure_params(h, s);
+  if (h->tiled.P == 0) {   // a network without reactions: du = 0
+    KIN_HIP(hipMemsetAsync(d_du_lib, 0, (size_t)B * h->host.N * sizeof(double), s));
+    return KIN_OK;
+  }
   launch_tiled_sweep(view_of(h), h->tiled.BS, h->n_cu, B, d_u_lib, d_k_lib, d_T, d_du_lib, s);
   KIN_CATCH(h)
 }
@@ -181,6 +185,10 @@ int kin_rhs_batched_T_dev(kin_network* h, int64_t B, const double* d_u, const do
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   ensure_params(h, s);
   const int64_t N = h->host.N;
+  if (h->tiled.P == 0) {
+    KIN_HIP(hipMemsetAsync(d_du, 0, (size_t)B * N * sizeof(double), s));
+    return KIN_OK;
+  }
   if (h->tiled.identity) {
     launch_tiled_sweep(view_of(h), h->tiled.BS, h->n_cu, B, d_u, nullptr, d_T, d_du, s);
   } else {

@@ -186,6 +186,34 @@ def test_failure_and_retry_semantics():
     h.close()
 
 
+def test_maxiters_exit_with_every_step_saved_leaves_no_pending_accept():
+    """saveat = [] (save_interval = nothing): every accepted step is saved, and the copy of a step's state into the
+    solution buffer rides in the NEXT step's predictor launch (deferred accept). A MaxIters exit has no next step: the last
+    saved row must still be written, and nothing of the failed call may survive into the next solve on the same handle
+    (whose solution buffer is a new allocation)."""
+    net = from_lists(3, [[(0, 1)], [(1, 2)], [(1, 1), (2, 1)]], [[(1, 1)], [(1, 1), (2, 1)], [(0, 1), (2, 1)]])
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates([0.04, 3e7, 1e4])
+    u0 = [1.0, 0.0, 0.0]
+    t, u, rc, st, status = h.solve(kp((0.0, 40.0), chunks=False, maxiters=40, adaptive=False), u0)
+    assert status == capi.KIN_ERR_SOLVE_FAILED and rc == 1 and len(t) == st["n_steps"] + 1 and st["n_steps"] >= 10
+    # every saved row is a real state of the Robertson problem: finite, positive to rounding, mass 1
+    assert np.all(np.isfinite(u)) and u.min() > -1e-12
+    np.testing.assert_allclose(u.sum(axis=1), 1.0, rtol=1e-9)
+    # the last row continues the trajectory (not stale memory): y1 keeps decreasing monotonically in this phase
+    assert np.all(np.diff(u[:, 0]) < 0) and np.all(np.diff(t) > 0)
+    # the same handle again, now to the end: identical to a fresh handle's result
+    good = h.solve(kp((0.0, 40.0), chunks=False, save=4.0), u0)
+    h2 = capi.HipNetwork.from_flat(net)
+    h2.set_rates([0.04, 3e7, 1e4])
+    ref = h2.solve(kp((0.0, 40.0), chunks=False, save=4.0), u0)
+    assert good[2] == 0 and np.array_equal(good[0], ref[0]) and np.array_equal(good[1], ref[1])
+    # and the every-step rows of the failed run are the first rows of a run that is allowed to continue
+    full = h2.solve(kp((0.0, 40.0), chunks=False), u0)
+    assert np.array_equal(full[1][:len(t)], u) and np.array_equal(full[0][:len(t)], t)
+    h.close(); h2.close()
+
+
 # ---- end-to-end through the mirrored reference interface (solve_network) ---------------------------------
 def c1_network():
     """C1: hand-written methane-pyrolysis-style CRN, 15 reactions + their reverses in the block

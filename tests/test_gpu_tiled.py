@@ -105,6 +105,32 @@ def test_special_stoichiometries_and_unpaired_reactions():
     h.close()
 
 
+def test_degenerate_networks():
+    """No reactions at all; one irreversible reaction; a single state; fewer states than workgroups."""
+    h0 = capi.HipNetwork.from_flat(from_lists(3, [], []))
+    d_u = _dev(np.ones((4, 3)))
+    d_du = torch.full_like(d_u, float("nan"))
+    d_k = torch.zeros((4, 2), dtype=torch.float64, device="cuda")
+    assert h0.lib_layout()["k_len"] == 0
+    h0.rhs_tiled_dev(4, d_u.data_ptr(), d_du.data_ptr(), d_k_lib=d_k.data_ptr())
+    torch.cuda.synchronize()
+    assert np.all(d_du.cpu().numpy() == 0.0)
+    h0.close()
+    net = from_lists(2, [[(0, 1)]], [[(1, 1)]])          # A -> B, no reverse
+    h1 = capi.HipNetwork.from_flat(net)
+    U = np.array([[2.0, 5.0]])
+    K = np.array([[3.0]])
+    du, lay = _tiled_k(h1, U, K)
+    assert lay["k_len"] == 2 and np.array_equal(du, [[-6.0, 6.0]])
+    h1.set_arrhenius(np.array([0.0]), np.array([1.0 / 6.02214076e23]))        # k = 1 at any temperature
+    d_u, d_T = _dev(U), _dev(np.array([700.0]))
+    d_du = torch.full_like(d_u, float("nan"))
+    h1.rhs_batched_T_dev(1, d_u.data_ptr(), d_T.data_ptr(), d_du.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d_du.cpu().numpy(), [[-2.0, 2.0]], rtol=1e-15)
+    h1.close()
+
+
 @pytest.mark.parametrize("k_max", [1e12, None], ids=["kmax", "nokmax"])
 def test_temperature_form_and_library_order_table(k_max):
     """C2-size network: du from T[b] (no k anywhere) against the oracle; the library-order rate table against the plain
