@@ -67,6 +67,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the HIP extension is mandatory, there is no CPU fallback)")
+        # PyTorch (device buffers, streams, torch.distributed in bench / tests) ships a HIP runtime of its own; a process that
+        # loads this library first and torch second ends up with torch seeing no GPU. Loading torch first works both ways.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         P64, PD = POINTER(c_int64), POINTER(c_double)
         L.kin_struct_size.restype = c_int64
