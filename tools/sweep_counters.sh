@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 5 --solve-chunks 0 --no-cpu --no-pmc --sustain-seconds 0 > "$OUT/p$i.log" 2>&1
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 5 --solve-chunks 0 --no-cpu --no-pmc --no-tiled --sustain-seconds 0 > "$OUT/p$i.log" 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections
