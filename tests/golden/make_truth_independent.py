@@ -8,14 +8,15 @@ through [0, t_end] for the static case and segment by segment between rate updat
 history, no LU cache) - and stores its deviation from the committed truth, in units of the default tolerances
 (abstol 1e-10 + reltol 1e-8 |u|), as `self_check_independent` inside the truth files. The tests assert it.
 
-    python tests/golden/make_truth_independent.py c3 c4        (tens of minutes on one core each)
+    python tests/golden/make_truth_independent.py c3 c4        (tens of minutes to hours on one core each)
 """
 import os
 import sys
 import time
 
 import numpy as np
-from scipy.integrate import solve_ivp
+from scipy.integrate import Radau, solve_ivp
+from scipy.sparse.linalg import splu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
@@ -30,6 +31,20 @@ def units(u, ref):
     return np.abs(u - ref) / (ABSTOL + RELTOL * np.abs(ref))
 
 
+class RadauMMD(Radau):
+    """SciPy's Radau with SuperLU's minimum-degree ordering on A' + A instead of the default COLAMD: on these Jacobians
+    (a few hub species with thousands of neighbours) COLAMD fills 32 M entries and takes 22 + 51 s per real + complex
+    factorisation at 10k species, MMD_AT_PLUS_A 1.6 M entries and 0.8 + 0.9 s. Integrator and step control untouched."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+
+        def lu(A):
+            self.nlu += 1
+            return splu(A, permc_spec="MMD_AT_PLUS_A")
+        self.lu = lu
+
+
 def radau(on, k, u0, t0, t1, t_eval):
     n = [0]
 
@@ -37,7 +52,7 @@ def radau(on, k, u0, t0, t1, t_eval):
         n[0] += 1
         return on.rhs(k, u)
 
-    sol = solve_ivp(f, (t0, t1), u0, method="Radau", jac=lambda t, u: on.jac(k, u).tocsc(), rtol=RELTOL * TIGHT, atol=ABSTOL * TIGHT,
+    sol = solve_ivp(f, (t0, t1), u0, method=RadauMMD, jac=lambda t, u: on.jac(k, u).tocsc(), rtol=RELTOL * TIGHT, atol=ABSTOL * TIGHT,
                     t_eval=t_eval, first_step=1e-22)
     assert sol.success, sol.message
     return sol.y.T, sol.nfev, sol.njev, sol.nlu
