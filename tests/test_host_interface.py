@@ -106,6 +106,34 @@ def test_solver_selection():
         S.ODESimulationParams(tspan=(0.0, 1.0), u0={"C": 1.0}, solver="Rodas5").explicit
 
 
+def test_solver_sentinels_carry_dtmin():
+    """`pars.solver = HIPBDF(dtmin=...)`: the option lives on the solver object (the reference's ODESimulationParams has no
+    dtmin field, params.jl:3-27; it hands eps(solve_chunkstep) / eps(tspan[end]) to `init`, methods.jl:164, 232, 694, 770)."""
+    base = dict(tspan=(0.0, 1.0), u0={"A": 1.0}, solve_chunkstep=0.5)
+    p = S.ODESimulationParams(solver=S.HIPBDF(), **base)
+    assert not p.explicit and p.solver_dtmin is None and p.to_kin_params().dtmin == 0.0        # 0 = the reference's value
+    p = S.ODESimulationParams(solver=S.HIPBDF(dtmin=1e-30), **base)
+    assert not p.explicit and p.to_kin_params().dtmin == 1e-30
+    p = S.ODESimulationParams(solver=S.HIPRK45(dtmin=1e-12), **base)
+    assert p.explicit and p.to_kin_params().dtmin == 1e-12
+    p = S.ODESimulationParams(solver=S.HIPBDF(), dtmin=1e-20, **base)                           # the older extension field still works
+    assert p.to_kin_params().dtmin == 1e-20
+    p = S.ODESimulationParams(solver=S.HIPBDF(dtmin=1e-30), dtmin=1e-20, **base)               # the sentinel wins
+    assert p.to_kin_params().dtmin == 1e-30
+
+
+def test_discrete_stop_temperatures_is_the_interpolation_half_of_calculate_discrete_rates():
+    cs = C.ConditionSet({"T": C.LinearGradientProfile(rate=50.0, X_start=500.0, X_end=510.0)}, ts_update=0.05)
+    pars = S.ODESimulationParams(tspan=(0.0, 0.2), u0={"A": 1.0}, solve_chunkstep=0.1)
+    C.solve_variable_conditions(cs, pars)
+    tst, T = S.discrete_stop_temperatures(cs)
+    np.testing.assert_allclose(tst, [0.0, 0.05, 0.1, 0.15, 0.2], atol=1e-15)
+    np.testing.assert_allclose(T, 500.0 + 50.0 * tst, rtol=1e-9)
+    static = C.ConditionSet({"T": 900.0}, ts_update=None)
+    with pytest.raises(RuntimeError):
+        S.discrete_stop_temperatures(static)                      # continuous / static sets have no discrete stops
+
+
 def test_solve_method_constructors():
     pars = S.ODESimulationParams(tspan=(0.0, 1.0), u0=[1.0])
     calc = S.PrecalculatedArrheniusCalculator([1.0], [1.0])
