@@ -205,3 +205,17 @@ def test_ensemble_rhs_equals_single_state_rhs():
     for kk, D in ((k, on.rhs_many(k, U)), (K, on.rhs_many(K, U))):
         for b in range(17):
             assert np.array_equal(D[b], on.rhs(kk if kk.ndim == 1 else kk[b], U[b]))
+
+
+def test_config_truths_are_cross_checked_by_an_independent_integrator(golden_dir):
+    """truth_c3 / truth_c4 come from oracle/cpu_bdf.cpp (the device integrator's own algorithm family at 1000x tighter
+    tolerances). tests/golden/make_truth_independent.py integrated the same problems with SciPy's Radau IIA - nothing shared
+    but the right-hand side - and stored how far it lands from the committed truths, in units of the DEFAULT tolerances:
+    well below one unit means a semantic error common to device and mirror (restart rule, zero-order hold of the rate
+    constants, chunk stitching) would have shown."""
+    import os
+    for name in ("c3", "c4"):
+        z = np.load(os.path.join(golden_dir, f"truth_{name}.npz"))
+        assert "self_check_independent" in z, name
+        assert float(z["self_check_independent"]) < 2.0 and float(z["self_check_independent_rms"]) < 0.2
+        assert "Radau" in str(z["independent_method"])
