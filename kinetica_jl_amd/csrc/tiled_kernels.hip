@@ -9,8 +9,10 @@
 // in L2 / Infinity Cache). A record is four 14-bit LDS labels with fixed roles (fields 0, 1 = reactant instances of the
 // forward reaction, fields 2, 3 = its product instances; net = kf u0 u1 - kr u2 u3, du[0,1] -= net, du[2,3] += net)
 // plus three flag bits that are equal for the 64 records a wavefront processes together: bit 56 = some record of the
-// group has a second reactant, bit 57 = ... a second product, bit 58 = nothing to do. A group without second reactants
-// skips that field's LDS read and ds_add_f64 altogether (3.1 instead of 4 fields per record on the synthetic CRNs).
+// group has a second reactant, bit 57 = ... a second product, bit 58 = nothing to do. All four fields are always read
+// (an unused field sits on a per-lane dummy entry with u = 1, so there is no branch between the LDS reads); a group
+// without second reactants / products skips that field's ds_add_f64 as a whole wavefront (3.1 instead of 4 atomics per
+// record on the synthetic CRNs).
 //
 // TMODE: no k stream at all - the rate constants are formed inside the sweep from the state's temperature and the
 // records' Arrhenius parameters (SURVEY 8(d) M1'; the reference's continuous-rate path inlines k(T(t)) into every
@@ -26,7 +28,6 @@
 namespace kin {
 
 namespace {
-
 
 // rows per batch: 4 with a k stream (two batches = 8 rows of 16-byte loads in flight per thread cover the HBM latency);
 // 2 when the rate constants are computed (the parameters come from L2 and take twice the registers)

@@ -24,7 +24,10 @@ from kinetica_jl_amd.synth import synthetic_crn  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 ABSTOL, RELTOL = 1e-10, 1e-8
-TIGHT = 1e-3                      # the independent run uses the tolerances the stored truth was made with
+# tolerances of the independent run relative to the defaults: 1e-3 = what the stored truths were made with (C4); the static
+# C3 problem at 1000 K runs into the rounding floor of the right-hand side at that setting (step sizes of 1e-7 s late in the
+# run: hours) and uses 1e-2 (INDEP_TIGHT in the environment overrides)
+TIGHT = float(os.environ.get("INDEP_TIGHT", "1e-3"))
 
 
 def units(u, ref):
@@ -78,7 +81,8 @@ def c3():
     print(f"c3: Radau {nfev} rhs, {njev} jac, {nlu} lu, {time.time() - t0:.0f} s; max deviation from the stored truth {dev.max():.3f} units, "
           f"rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
     update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
-           independent_method="scipy Radau, oracle rhs + analytic sparse Jacobian, rtol 1e-11, atol 1e-13, no chunking")
+           independent_method=f"scipy Radau (SuperLU, MMD ordering), oracle rhs + analytic sparse Jacobian, rtol {RELTOL * TIGHT:g}, "
+                              f"atol {ABSTOL * TIGHT:g}, no chunking")
 
 
 def c4():
@@ -105,7 +109,8 @@ def c4():
     dev = np.stack([units(saves[ts], tr["u"][idx[ts]]) for ts in (5e-3, 1e-2)])
     print(f"c4: max deviation from the stored truth {dev.max():.3f} units, rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
     update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
-           independent_method="scipy Radau per rate interval (zero-order hold), first chunk (saves at 5 and 10 ms), rtol 1e-11, atol 1e-13")
+           independent_method=f"scipy Radau (SuperLU, MMD ordering) per rate interval (zero-order hold), first chunk (saves at 5 and "
+                              f"10 ms), rtol {RELTOL * TIGHT:g}, atol {ABSTOL * TIGHT:g}")
 
 
 if __name__ == "__main__":
