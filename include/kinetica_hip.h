@@ -93,7 +93,9 @@ int kin_rhs(kin_network* h, const double* u, double* du);
 int kin_rhs_batched(kin_network* h, int64_t B, const double* u, const double* k, double* du);
 /* The same sweep on device-resident buffers (no PCIe), same state-major layouts u[b][N],
  * k[b][R] (or NULL), du[b][N]. `stream` is a hipStream_t (NULL = the handle's stream); the
- * call only enqueues (no allocation, no synchronisation: graph-capturable). */
+ * call only enqueues (no allocation, no synchronisation: graph-capturable). The handle's stream is a non-blocking
+ * stream of its own: work the caller has queued on OTHER streams (fills, arithmetic on these buffers) is not ordered
+ * before the sweep - pass the stream that work runs on, or synchronise first. The same holds for every *_dev entry point. */
 int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const double* d_k, double* d_du, void* stream);
 
 /* ---- A2 in the library's own data layout ("library order"): the bandwidth path of the batched sweep --------------

@@ -18,6 +18,12 @@ def _dev(a):
     return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
 
 
+def _sync():
+    """The library launches on the handle's own non-blocking stream: whatever torch has queued on ITS stream (fills,
+    arithmetic on the inputs) must have finished before a library call reads or writes those buffers."""
+    torch.cuda.synchronize()
+
+
 def _states(B, n, seed):
     return 10.0 ** np.random.default_rng(seed).uniform(-12, 0, (B, n))
 
@@ -29,8 +35,10 @@ def _tiled_k(h, U, K):
     d_u, d_k = _dev(U), _dev(K)
     d_ul, d_kl = torch.empty_like(d_u), torch.empty((B, lay["k_len"]), dtype=torch.float64, device="cuda")
     d_dul, d_du = torch.full_like(d_u, float("nan")), torch.full_like(d_u, float("nan"))
+    _sync()
     h.states_to_lib_dev(B, d_u.data_ptr(), d_ul.data_ptr())
     h.rates_to_lib_dev(B, d_k.data_ptr(), d_kl.data_ptr())
+    _sync()
     h.rhs_tiled_dev(B, d_ul.data_ptr(), d_dul.data_ptr(), d_k_lib=d_kl.data_ptr())
     h.states_from_lib_dev(B, d_dul.data_ptr(), d_du.data_ptr())
     torch.cuda.synchronize()
@@ -81,6 +89,7 @@ def test_windows_on_a_small_network(monkeypatch):
     T = np.linspace(500.0, 1200.0, B)
     d_u, d_T = _dev(U), _dev(T)
     d_du = torch.full_like(d_u, float("nan"))
+    _sync()
     h.rhs_batched_T_dev(B, d_u.data_ptr(), d_T.data_ptr(), d_du.data_ptr())
     torch.cuda.synchronize()
     duT = d_du.cpu().numpy()
@@ -112,6 +121,7 @@ def test_degenerate_networks():
     d_du = torch.full_like(d_u, float("nan"))
     d_k = torch.zeros((4, 2), dtype=torch.float64, device="cuda")
     assert h0.lib_layout()["k_len"] == 0
+    _sync()
     h0.rhs_tiled_dev(4, d_u.data_ptr(), d_du.data_ptr(), d_k_lib=d_k.data_ptr())
     torch.cuda.synchronize()
     assert np.all(d_du.cpu().numpy() == 0.0)
@@ -125,6 +135,7 @@ def test_degenerate_networks():
     h1.set_arrhenius(np.array([0.0]), np.array([1.0 / 6.02214076e23]))        # k = 1 at any temperature
     d_u, d_T = _dev(U), _dev(np.array([700.0]))
     d_du = torch.full_like(d_u, float("nan"))
+    _sync()
     h1.rhs_batched_T_dev(1, d_u.data_ptr(), d_T.data_ptr(), d_du.data_ptr())
     torch.cuda.synchronize()
     np.testing.assert_allclose(d_du.cpu().numpy(), [[-2.0, 2.0]], rtol=1e-15)
@@ -144,6 +155,7 @@ def test_temperature_form_and_library_order_table(k_max):
     lay = h.lib_layout()
     d_u, d_T = _dev(U), _dev(T)
     d_du = torch.full_like(d_u, float("nan"))
+    _sync()
     h.rhs_batched_T_dev(B, d_u.data_ptr(), d_T.data_ptr(), d_du.data_ptr())
     torch.cuda.synchronize()
     du = d_du.cpu().numpy()
@@ -155,7 +167,9 @@ def test_temperature_form_and_library_order_table(k_max):
     # table in library order
     d_tl = torch.full((B, lay["k_len"]), float("nan"), dtype=torch.float64, device="cuda")
     d_t = torch.empty((B, r), dtype=torch.float64, device="cuda")
+    _sync()
     h.rate_table_lib_dev(T, d_tl.data_ptr())
+    _sync()
     h.rate_table_dev(T, d_t.data_ptr())
     tl, t = d_tl.cpu().numpy(), d_t.cpu().numpy()
     for b in (0, B // 2, B - 1):
@@ -165,6 +179,7 @@ def test_temperature_form_and_library_order_table(k_max):
     assert np.array_equal(tl[:, lay["slot_of_reaction"]], t)
     # the k-stream form fed with that table reproduces the temperature form's arithmetic up to the exp table size
     d_du2 = torch.full_like(d_u, float("nan"))
+    _sync()
     h.rhs_tiled_dev(B, d_u.data_ptr(), d_du2.data_ptr(), d_k_lib=d_tl.data_ptr())
     torch.cuda.synchronize()
     du2 = d_du2.cpu().numpy()
@@ -178,8 +193,10 @@ def test_argument_errors():
     h = capi.HipNetwork.from_flat(net)
     d = torch.zeros((2, 300), dtype=torch.float64, device="cuda")
     with pytest.raises(capi.KineticaHipError):       # neither k nor T
+        _sync()
         h.rhs_tiled_dev(2, d.data_ptr(), d.data_ptr())
     with pytest.raises(capi.KineticaHipError) as e:  # T form without Arrhenius parameters
+        _sync()
         h.rhs_tiled_dev(2, d.data_ptr(), d.data_ptr(), d_T=d.data_ptr())
     assert e.value.code == capi.KIN_ERR_STATE
     # a reaction with three product molecules has no fixed-role record: the layout is refused, the plain sweep still works
@@ -205,8 +222,10 @@ def test_full_size_c3_elementwise_and_c5_tiled_sweep():
         T = np.linspace(500.0, 1200.0, B)
         d_ul = _dev(U[:, lay["species_of_lib"]])
         d_kl = torch.empty((B, lay["k_len"]), dtype=torch.float64, device="cuda")
+        _sync()
         h.rate_table_lib_dev(T, d_kl.data_ptr())
         d_dul = torch.full_like(d_ul, float("nan"))
+        _sync()
         h.rhs_tiled_dev(B, d_ul.data_ptr(), d_dul.data_ptr(), d_k_lib=d_kl.data_ptr())
         torch.cuda.synchronize()
         dul = d_dul.cpu().numpy()
@@ -228,10 +247,12 @@ def test_full_size_c3_elementwise_and_c5_tiled_sweep():
         # linearity in k: doubling k doubles du exactly (power of two)
         d_k2 = d_kl * 2.0
         d_du2 = torch.empty_like(d_dul)
+        _sync()
         h.rhs_tiled_dev(B, d_ul.data_ptr(), d_du2.data_ptr(), d_k_lib=d_k2.data_ptr())
         # temperature form on the same states
         d_T = _dev(T)
         d_duT = torch.full_like(d_ul, float("nan"))
+        _sync()
         h.rhs_tiled_dev(B, d_ul.data_ptr(), d_duT.data_ptr(), d_T=d_T.data_ptr())
         torch.cuda.synchronize()
         du2 = d_du2.cpu().numpy()
