@@ -49,6 +49,7 @@ def sweep_record(name, N, R, B):
     u = torch.pow(10.0, torch.rand((B, N), dtype=torch.float64, device=dev, generator=g) * 12 - 12)
     k = torch.rand((B, R), dtype=torch.float64, device=dev, generator=g) + 0.5
     du = torch.empty_like(u)
+    torch.cuda.synchronize()      # the inputs were made on torch's default stream
     st = torch.cuda.Stream(); torch.cuda.set_stream(st)
     dt = timed(lambda: h.rhs_batched_dev(B, u.data_ptr(), k.data_ptr(), du.data_ptr(), st.cuda_stream))
     alg = 20 * R + B * (8 * R + 16 * N)

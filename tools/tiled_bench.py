@@ -37,6 +37,7 @@ def run(name, N, R, B, reps, with_old=True):
     kl = torch.empty((B, lay["k_len"]), dtype=torch.float64, device=dev)
     h.rate_table_lib_dev(T.cpu().numpy(), kl.data_ptr())
     du = torch.empty_like(u)
+    torch.cuda.synchronize()      # the inputs were made on torch's default stream
     st = torch.cuda.Stream(); torch.cuda.set_stream(st)
     s = st.cuda_stream
     alg = 20 * R + B * (8 * R + 16 * N)

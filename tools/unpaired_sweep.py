@@ -18,6 +18,7 @@ dev = torch.device("cuda"); g = torch.Generator(device=dev); g.manual_seed(1)
 u = torch.pow(10.0, torch.rand((B, N), dtype=torch.float64, device=dev, generator=g) * 12 - 12)
 k = torch.rand((B, R2), dtype=torch.float64, device=dev, generator=g) + 0.5
 du = torch.empty_like(u)
+torch.cuda.synchronize()
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 dt = rc.timed(lambda: h.rhs_batched_dev(B, u.data_ptr(), k.data_ptr(), du.data_ptr(), st.cuda_stream))
 alg = 20 * R2 + B * (8 * R2 + 16 * N)
