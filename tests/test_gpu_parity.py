@@ -233,8 +233,33 @@ def test_full_size_properties_c5_tiled_sweep():
     for b in (0, 255, 256, 511, 512, B2 - 1):
         sc = on.abs_rhs(k, U2[b]) + 1e-300
         assert (np.abs(got2[b] - on.rhs(k, U2[b])) / sc).max() < TOL
+    # the same 600 states through the LIBRARY-ORDER sweep (round 3: hubs + windows of species in LDS, one pass over k; the
+    # full set of its tests is tests/test_gpu_tiled.py): converted on the device, rate constants from the library-order
+    # table kernel at 1000 K, back in the caller's order; against the caller-order kernel's result and the oracle
+    import torch
+    lay = h.lib_layout()
+    assert lay["windows"] > 1 and not lay["identity"] and lay["k_len"] == 250000
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    d_u = torch.tensor(U2, dtype=torch.float64, device="cuda")
+    d_ul, d_dul, d_du = torch.empty_like(d_u), torch.empty_like(d_u), torch.empty_like(d_u)
+    d_kl = torch.empty((B2, lay["k_len"]), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    h.rate_table_lib_dev(np.full(B2, 1000.0), d_kl.data_ptr())
+    h.states_to_lib_dev(B2, d_u.data_ptr(), d_ul.data_ptr())
+    h.rhs_tiled_dev(B2, d_ul.data_ptr(), d_dul.data_ptr(), d_k_lib=d_kl.data_ptr())
+    h.states_from_lib_dev(B2, d_dul.data_ptr(), d_du.data_ptr())
+    torch.cuda.synchronize()
+    got3 = d_du.cpu().numpy()
+    n_terms = np.bincount(np.concatenate([net.reac_idx, net.prod_idx]), minlength=50000)
+    tol3 = np.maximum(TOL, 8.0 * np.sqrt(n_terms) * 2.0 ** -53)       # the top hub sums 58 000 terms in another order
+    k_tab = d_kl[0].cpu().numpy()[lay["slot_of_reaction"]]             # the table kernel's k (within its stated bound of the oracle's)
+    for b in (0, 255, 256, 511, 512, B2 - 1):
+        sc = on.abs_rhs(k_tab, U2[b]) + 1e-300
+        assert np.all(np.abs(got3[b] - on.rhs(k_tab, U2[b])) / sc <= tol3), b
+        assert np.all(np.abs(got3[b] - got2[b]) / sc <= tol3 + 300 * 2.0 ** -53), b     # k differs by the table kernel's <= 2 |Ea/RT| ulps
     # Jacobian at this size: oracle comparison
     rowptr, col = h.jac_pattern()
+    h.set_rates(k)
     Jd = sp.csr_matrix((h.jac_values(U[0]), col, rowptr), shape=(50000, 50000))
     Jo = on.jac(k, U[0])
     assert abs(Jd - Jo).max() <= TOL * abs(Jo).max()
