@@ -8,8 +8,8 @@ through [0, t_end] for the static case and segment by segment between rate updat
 history, no LU cache) - and stores its deviation from the committed truth, in units of the default tolerances
 (abstol 1e-10 + reltol 1e-8 |u|), as `self_check_independent` inside the truth files. The tests assert it.
 
-    INDEP_TIGHT=1e-2 python tests/golden/make_truth_independent.py c3      (5 minutes on one core)
-    python tests/golden/make_truth_independent.py c4                       (25 minutes)
+    python tests/golden/make_truth_independent.py c3      (35 minutes on one core; INDEP_TIGHT=1e-2: 5 minutes, 0.16 units)
+    python tests/golden/make_truth_independent.py c4      (25 minutes)
 """
 import os
 import sys
