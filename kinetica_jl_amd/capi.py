@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkinetica_hip.so")
+LIB_PATH = os.environ.get("KIN_LIB_PATH", os.path.join(_HERE, "libkinetica_hip.so"))   # (override: A/B builds in tools/)
 
 KIN_OK, KIN_ERR_INVALID_ARG, KIN_ERR_UNSUPPORTED, KIN_ERR_DEVICE, KIN_ERR_SOLVE_FAILED, KIN_ERR_CAPACITY, KIN_ERR_STATE = range(7)
 RETCODE_NAMES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable"}
