@@ -499,36 +499,45 @@ __global__ __launch_bounds__(BS) void sweep_reg_kernel(int N, int R, int P, int 
   const uint2 EMPTY = {(uint32_t)ew, (uint32_t)(ew >> 32)};
   if (tid < SWEEP_DUMMY) { u_s[N + tid] = 1.0; du_s[N + tid] = 0.0; }
   // split accumulators of the most referenced species (network.cpp): entry N + 64 + tid mirrors species csp
-  const int csp = tid < n_copy ? copy_species[tid] : -1;
+  const int csp = tid < n_copy ? copy_species[min(tid, max(n_copy - 1, 0))] : -1;
   if (csp >= 0) du_s[N + SWEEP_DUMMY + tid] = 0.0;
+  // Every global load below is UNCONDITIONAL (indices clamped into valid memory; a record beyond the end is the lane's
+  // padding record, whose rate constants meet dummy entries): a load behind a branch makes the compiler wait for
+  // vmcnt(0) wherever it cannot count the loads in flight - before the state's barrier (draining the prefetched rate
+  // constants), between the batches of the register-resident records and in the streamed loop (tiled_kernels.hip has
+  // the same rule and the measurement behind it).
+  const int Pm1 = P - 1, Bm1 = B - 1, csp_c = max(csp, 0);
   uint2 rc[TR > 0 ? TR : 1];
 #pragma unroll
   for (int i = 0; i < TR; i++) {
     const int p = tid + i * BS;
-    rc[i] = p < P ? rec64[p] : EMPTY;
+    const uint2 w = rec64[min(p, Pm1)];
+    rc[i].x = p < P ? w.x : EMPTY.x;
+    rc[i].y = p < P ? w.y : EMPTY.y;
   }
   // software pipeline over states: the next state's u travels HBM -> registers while this state's
   // reactions are processed; du is written out and re-zeroed in one pass. N is even (host check).
   double2 un[UPT];
   int b = blockIdx.x;
+  {
+    const double* ub = u + (size_t)min(b, Bm1) * N;
 #pragma unroll
-  for (int x = 0; x < UPT; x++) {
-    const int i = (tid + x * BS) * 2;
-    un[x] = (b < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)b * N + i) : make_double2(0.0, 0.0);
+    for (int x = 0; x < UPT; x++) {
+      // (component-wise: a whole-vector assignment here leaves `un` in scratch memory - ROCm 7.2 clang)
+      const double2 t = *reinterpret_cast<const double2*>(ub + min((tid + x * BS) * 2, N - 2));
+      un[x].x = t.x; un[x].y = t.y;
+    }
   }
   for (int i = tid * 2; i < N; i += (2 * BS)) *reinterpret_cast<double2*>(du_s + i) = make_double2(0.0, 0.0);
-  double ucn = (csp >= 0 && b < B) ? u[(size_t)b * N + csp] : 0.0;
+  double ucn = u[(size_t)min(b, Bm1) * N + csp_c];
   // the first batch of rate constants of a state is requested before the previous state's barrier /
   // write-out / staging, so the k stream does not drain at state boundaries
   constexpr bool KPRE = TR >= ILP;
   double2 k0[KPRE ? ILP : 1];
   if (KPRE) {
-    const double* kb = k_b ? k_b + (size_t)b * R : k_1;
+    const double* kb = k_b ? k_b + (size_t)min(b, Bm1) * R : k_1;
 #pragma unroll
-    for (int x = 0; x < ILP; x++) {
-      const int p = tid + x * BS;
-      k0[x] = (b < B && p < P) ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
-    }
+    for (int x = 0; x < ILP; x++) k0[x] = load_kpair<BLK>(kb, min(tid + x * BS, Pm1), P);
   }
   for (; b < B; b += gridDim.x) {
     const double* kb = k_b ? k_b + (size_t)b * R : k_1;
@@ -541,11 +550,14 @@ __global__ __launch_bounds__(BS) void sweep_reg_kernel(int N, int R, int P, int 
     if (csp >= 0) u_s[N + SWEEP_DUMMY + tid] = ucn;
     __syncthreads();
     const int bn = b + gridDim.x;
-    ucn = (csp >= 0 && bn < B) ? u[(size_t)bn * N + csp] : 0.0;
+    ucn = u[(size_t)min(bn, Bm1) * N + csp_c];
+    {
+      const double* ub = u + (size_t)min(bn, Bm1) * N;
 #pragma unroll
-    for (int x = 0; x < UPT; x++) {
-      const int i = (tid + x * BS) * 2;
-      un[x] = (bn < B && i < N) ? *reinterpret_cast<const double2*>(u + (size_t)bn * N + i) : make_double2(0.0, 0.0);
+      for (int x = 0; x < UPT; x++) {
+        const double2 t = *reinterpret_cast<const double2*>(ub + min((tid + x * BS) * 2, N - 2));
+        un[x].x = t.x; un[x].y = t.y;
+      }
     }
     // register-resident records
 #pragma unroll
@@ -553,9 +565,8 @@ __global__ __launch_bounds__(BS) void sweep_reg_kernel(int N, int R, int P, int 
       double2 kk[ILP];
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
-        const int p = tid + (i0 + x) * BS;
         if (KPRE && i0 == 0) kk[x] = k0[x];
-        else kk[x] = p < P ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
+        else kk[x] = load_kpair<BLK>(kb, min(tid + (i0 + x) * BS, Pm1), P);
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
@@ -574,19 +585,18 @@ __global__ __launch_bounds__(BS) void sweep_reg_kernel(int N, int R, int P, int 
       for (int x = 0; x < ILP; x++) {
         const int p = p0 + x * BS;
         const bool ok = p < P;
-        kk[x] = ok ? load_kpair<BLK>(kb, p, P) : make_double2(0.0, 0.0);
-        w[x] = ok ? rec64[p] : EMPTY;
+        kk[x] = load_kpair<BLK>(kb, min(p, Pm1), P);
+        const uint2 q = rec64[min(p, Pm1)];
+        w[x].x = ok ? q.x : EMPTY.x;
+        w[x].y = ok ? q.y : EMPTY.y;
       }
 #pragma unroll
       for (int x = 0; x < ILP; x++) sweep_apply(w[x], kk[x], u_s, du_s);
     }
     if (KPRE) {
-      const double* kn = k_b ? k_b + (size_t)bn * R : k_1;
+      const double* kn = k_b ? k_b + (size_t)min(bn, Bm1) * R : k_1;
 #pragma unroll
-      for (int x = 0; x < ILP; x++) {
-        const int p = tid + x * BS;
-        k0[x] = (bn < B && p < P) ? load_kpair<BLK>(kn, p, P) : make_double2(0.0, 0.0);
-      }
+      for (int x = 0; x < ILP; x++) k0[x] = load_kpair<BLK>(kn, min(tid + x * BS, Pm1), P);
     }
     __syncthreads();
     if (n_copy > 0) {   // fold the split accumulators back into their species

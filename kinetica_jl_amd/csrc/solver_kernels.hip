@@ -287,6 +287,9 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
   if (blockIdx.y == 0) {
     const int kn = kb + 1;
     if (blockIdx.x != 0 || kn >= nblk) return;
+#if defined(GJ_PROBE) && GJ_PROBE == 2   // tools/gj_probe.hip: timing without the look-ahead workgroup (wrong result)
+    return;
+#endif
     const int n0 = kn * GJ_NB;                           // next pivot block: rows/cols n0..n0+31 (never pivot rows/cols of step kb)
     const int rb = w >> 1, cb = w & 1;
     // every global operand of this workgroup is requested up front (one load latency instead of two: the
@@ -316,6 +319,9 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
       for (int v = 0; v < 4; v++) A[16 * rb + 4 * v + lk][16 * cb + li] = xd[v] - acc[v];
     }
     __syncthreads();
+#if defined(GJ_PROBE) && GJ_PROBE == 1   // timing without the inversion of the next pivot block (wrong result)
+    return;
+#endif
     gj_invert_block_lds(A, XS, pinv_next, bad);
     return;
   }

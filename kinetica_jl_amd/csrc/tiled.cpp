@@ -149,12 +149,26 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
       seg_of_rec[p] = wdw;
       if (wdw >= 0) nrec[wdw]++; else free_recs.push_back(p);
     }
-    const int64_t target = ceil_div(P, T);
+    // Hub-only records first fill the padding of the segments' last batches (a segment's rows are padded to whole
+    // batches of `quantum` rows, at least TILED_MIN_ROWS), then go in whole batches to the segment with the fewest
+    // records: the iteration space the kernel walks is then the smallest the window records allow (C5: 124 rows of
+    // 1 024 records for 122.07 rows of work; filling up to P / T per segment and padding to 8 rows made it 144).
+    int32_t wmax_now = 0;
+    for (int t = 0; t < T; t++) wmax_now = std::max(wmax_now, fill[t]);
+    L.row_quantum = std::max(h, wmax_now) <= 5 * bs ? 4 : 2;
+    const int64_t Q = (int64_t)bs * L.row_quantum;
     size_t fr = 0;
-    for (int t = 0; t < T; t++)
-      while (fr < free_recs.size() && nrec[t] < target) { seg_of_rec[free_recs[fr++]] = t; nrec[t]++; }
-    while (fr < free_recs.size()) { seg_of_rec[free_recs[fr]] = (int32_t)(fr % T); fr++; }
+    for (int t = 0; t < T; t++) {
+      const int64_t cap = std::max<int64_t>((int64_t)TILED_MIN_ROWS * bs, ceil_div(nrec[t], Q) * Q);
+      while (fr < free_recs.size() && nrec[t] < cap) { seg_of_rec[free_recs[fr++]] = t; nrec[t]++; }
+    }
+    while (fr < free_recs.size()) {
+      int best = 0;
+      for (int t = 1; t < T; t++) if (nrec[t] < nrec[best]) best = t;
+      for (int64_t i = 0; i < Q && fr < free_recs.size(); i++) { seg_of_rec[free_recs[fr++]] = best; nrec[best]++; }
+    }
   } else {
+    L.row_quantum = h <= 5 * bs ? 4 : 2;
     std::fill(seg_of_rec.begin(), seg_of_rec.end(), 0);
   }
   if (T > TILED_MAX_SEG) { L.why = "too many windows"; return L; }
@@ -233,7 +247,7 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
     for (int32_t i = 0; i < n; i++) { L.rec.push_back((uint32_t)words[i]); L.rec.push_back((uint32_t)(words[i] >> 32)); }
     const int32_t rows = (int32_t)ceil_div(n, bs);
     // (at least one group of iteration rows, also for a window without records: the kernel's producer relies on it)
-    const int32_t rows_pad = std::max<int32_t>(1, (int32_t)ceil_div(rows, TILED_GROUP)) * TILED_GROUP;
+    const int32_t rows_pad = std::max<int32_t>(TILED_MIN_ROWS, (int32_t)ceil_div(rows, L.row_quantum) * L.row_quantum);
     L.seginfo.push_back(base); L.seginfo.push_back(n); L.seginfo.push_back(rows_pad); L.seginfo.push_back(0);
     for (int32_t i = 0; i < rows_pad; i++) {
       L.rowtab.push_back(i < rows ? base + i * bs : -1);

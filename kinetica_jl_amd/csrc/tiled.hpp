@@ -27,8 +27,11 @@ namespace kin {
 
 constexpr int TILED_DUMMY = 64;        // per-lane dummy LDS entries (u = 1, du discarded) for unused record fields
 constexpr int TILED_COPIES = 7;        // extra accumulator entries per split hub (copy 0 = the species' own entry)
-constexpr int TILED_BATCH = 4;         // record rows a thread processes together (all LDS reads, then all atomics)
-constexpr int TILED_GROUP = 2 * TILED_BATCH;   // rows per segment are padded (in iteration space only) to this
+constexpr int TILED_BATCH = 4;         // record rows of one batch of the kernel's load queue, at most (tiled_kernels.hip: NB)
+constexpr int TILED_MIN_ROWS = 2 * TILED_BATCH;   // iteration rows of a segment, at least (the queue runs two batches ahead)
+// The rows of a segment are padded (in iteration space only) to whole batches of the kernel that runs the layout: 4 rows
+// for a windowed layout, 2 for a state that fits LDS whole (its staged-in set takes twice the registers). Records that
+// touch hubs only go where they fill such a batch up (tiled.cpp).
 constexpr int TILED_MAX_SEG = 48;              // segments a layout may have (their descriptors travel in the kernel arguments)
 constexpr int TILED_EXP_TAB = 128;             // entries of the exp table the temperature form keeps in LDS (exp_tab.hpp)
 constexpr int TILED_LDS_ENTRIES = 10176;       // entries per LDS array (u, du): (2 x 10176 + 128) x 8 B = 160 kB exactly
@@ -43,6 +46,7 @@ struct TiledHost {
   int32_t wbase = 0;               // first LDS entry of the window region
   int32_t E = 0;                   // LDS entries per array
   int32_t T = 1;                   // segments (windows); T == 1 && win_cnt[0] == 0: no windows at all
+  int32_t row_quantum = TILED_BATCH;   // iteration rows of every segment are a multiple of this (2 or 4, see above)
   bool identity = true;            // library species order == caller's
   std::vector<int32_t> species_of_lib, lib_of_species;   // N each
   std::vector<int32_t> win_off, win_cnt;                 // T each: window s = library species [win_off, win_off + win_cnt)
@@ -51,8 +55,8 @@ struct TiledHost {
   std::vector<int32_t> kf, kr;     // P each: reaction ids of a record's forward / reverse reaction (kr = -1: none)
   std::vector<int32_t> slot_of_reaction;   // R: position of reaction r's rate constant in a k_lib row
   std::vector<int32_t> rowtab;     // 2 per iteration row: first record of the row (-1: padding row), records in it
-  std::vector<int32_t> seg_q;      // T + 1: iteration rows [seg_q[s], seg_q[s + 1]) belong to segment s (multiples of TILED_GROUP)
-  std::vector<int32_t> seginfo;    // 4 per segment: first record, records, iteration rows (>= TILED_GROUP), 0 - what the kernel reads
+  std::vector<int32_t> seg_q;      // T + 1: iteration rows [seg_q[s], seg_q[s + 1]) belong to segment s (multiples of row_quantum)
+  std::vector<int32_t> seginfo;    // 4 per segment: first record, records, iteration rows (>= TILED_MIN_ROWS), 0 - what the kernel reads
   int64_t k_len() const { return 2 * (int64_t)P; }
 };
 

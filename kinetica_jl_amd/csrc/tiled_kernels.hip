@@ -104,11 +104,11 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   // iteration rows ahead of the consumer, across segment and state boundaries. The segment descriptors are part of the
   // kernel arguments (scalar loads from the kernarg segment); `pa` = the producer's segment, `pn` = the one after, re-read
   // only at the consumer's segment starts, right behind a barrier (a scalar load's wait also drains the LDS queue). Every
-  // segment has >= TILED_GROUP >= 2 NB iteration rows and the producer changes segment lazily (at the first request beyond
-  // the end), so it does so at most once in between.
+  // segment has >= TILED_MIN_ROWS >= 2 NB iteration rows, a whole number of batches (tiled.hpp: row_quantum), and the
+  // producer changes segment lazily (at the first request beyond the end), so it does so at most once in between.
   constexpr int NB = (TMODE || UN > 5) ? 2 : 4;
   using BatchT = Batch<TMODE, NB>;
-  static_assert(TILED_GROUP % (2 * NB) == 0, "segments are padded to whole pairs of batches");
+  static_assert(TILED_MIN_ROWS >= 2 * NB && (UN > 5 ? 2 : 4) % NB == 0, "segments are padded to whole batches, two at least");
   int pb = blockIdx.x, ps = 0, pi = 0;   // state, segment, iteration row inside the segment of the next request
   int4 pa = v.seginfo[0], pn = v.seginfo[T > 1 ? 1 : 0];   // x = first record, y = records, z = iteration rows
   asm volatile("" : "+s"(pa.x), "+s"(pa.y), "+s"(pa.z), "+s"(pn.x), "+s"(pn.y), "+s"(pn.z));
@@ -151,8 +151,17 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
         const int x = x0 + y;
         fl[y] = __builtin_amdgcn_readfirstlane(G.w[x].y >> 24);
         const Labels L = decode(G.w[x]);
+#if defined(KIN_TILED_SKIPREAD)
+        double u1v = 1.0, u3v = 1.0;
+        const double u0v = u_s[L.l0];
+        if (fl[y] & 1u) u1v = u_s[L.l1];
+        const double u2v = u_s[L.l2];
+        if (fl[y] & 2u) u3v = u_s[L.l3];
+        const double uf = u0v * u1v, ur = u2v * u3v;
+#else
         const double uf = u_s[L.l0] * u_s[L.l1];
         const double ur = u_s[L.l2] * u_s[L.l3];
+#endif
         double kf, kr;
         if constexpr (TMODE) {
           kf = arrhenius_fast_t<TILED_EXP_TAB>(G.p[x].x, G.p[x].y, G.p[x].y, RT, inv_RT, v.has_kmax, v.inv_kmax, tab_s);
@@ -203,10 +212,21 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       // the scalar loads above are waited for HERE, behind the barrier: left to the compiler, the wait (lgkmcnt(0), which
       // also drains the wave's LDS queue) lands on the join inside the record loop, once per batch
       asm volatile("" : "+s"(pn.x), "+s"(pn.y), "+s"(pn.z), "+s"(rows));
-      for (int q = 0; q < rows; q += 2 * NB) {
+      int q = 0;
+      for (; q + 2 * NB <= rows; q += 2 * NB) {
         consume(G0);
         load_batch(G0);
         consume(G1);
+        load_batch(G1);
+      }
+      if (q < rows) {   // an odd number of batches: the queue keeps its order (G0 = the older batch) by a register move
+        consume(G0);
+#pragma unroll
+        for (int x = 0; x < NB; x++) {   // (component by component: whole-vector copies of register arrays end up in scratch)
+          G0.w[x].x = G1.w[x].x; G0.w[x].y = G1.w[x].y;
+          if constexpr (TMODE) { G0.p[x].x = G1.p[x].x; G0.p[x].y = G1.p[x].y; G0.p[x].z = G1.p[x].z; G0.p[x].w = G1.p[x].w; }
+          else { G0.k[x].x = G1.k[x].x; G0.k[x].y = G1.k[x].y; }
+        }
         load_batch(G1);
       }
       __syncthreads();

@@ -23,7 +23,7 @@ def _check(net, seed=0, hubs=0):
     slots = L["slot_of_reaction"]
     assert len(set(slots)) == R and slots.min() >= 0 and slots.max() < 2 * L["P"]
     assert L["win_cnt"].sum() + L["h"] == N
-    assert all(q % 8 == 0 for q in L["seg_q"])
+    assert all(q % 2 == 0 for q in L["seg_q"]) and all(b - a >= 8 for a, b in zip(L["seg_q"][:-1], L["seg_q"][1:]))
     du_lib = replay(L, u[sp], k_to_lib(L, k))
     du = np.empty(N)
     du[sp] = du_lib
