@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--solve-chunks", type=int, default=100, help="chunks of the timed kin_solve (0 = skip)")
     ap.add_argument("--cpu-solve-chunks", type=int, default=2, help="chunks the CPU baseline solves (the device is timed on the same ones)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="back-to-back sweeps after the timed region (sustained clock)")
+    ap.add_argument("--spinup-seconds", type=float, default=1.0,
+                    help="back-to-back sweeps BEFORE the warm-up steps, untimed: the clocks settle (0 = cold-clock number)")
     ap.add_argument("--replicas", default="1,2,4,8", help="concurrent replicas on one GPU to time (comma list, '' = skip)")
     ap.add_argument("--no-tiled", dest="tiled", action="store_false", help="skip the library-order sweep legs (C3 + C5)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -307,6 +309,16 @@ def main():
     def sweep():
         h.rhs_batched_dev(B, d_u.data_ptr(), d_k.data_ptr(), d_du.data_ptr(), stream)
 
+    # Clock spin-up (untimed, before the W warm-up steps): the chip's power management raises the clocks only after tens
+    # of milliseconds of load - the first 20 launches after an idle period run at 0.48-0.49 ms, the next 20 at 0.43, then
+    # 0.42 (tools/sweep_time.py) - and W = 5 warm-up steps of 0.45 ms are over long before that. The timed region is
+    # unchanged (exactly K steps between barriers); --spinup-seconds 0 gives the cold-clock number.
+    if args.spinup_seconds > 0 and not args.pmc_child:
+        t_end = time.perf_counter() + args.spinup_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(50):
+                sweep()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         sweep()
     torch.cuda.synchronize()
@@ -364,6 +376,7 @@ def main():
                          "traffic_over_algorithmic": None if traffic is None else traffic / alg_bytes,
                          "kernel": "kin::sweep_reg_kernel<8, 4, BLK> (state fits LDS, reactions paired with their reverses; else kin::sweep_gen_kernel / sweep_big_kernel)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kernel_ms,
+                         "spinup_s": args.spinup_seconds,
                          "sustained_launch_ms": sustained_ms,
                          "sustained_frac": None if not sustained_ms else alg_bytes / (sustained_ms * 1e-3) / 8e12},
         }

@@ -161,48 +161,101 @@ __device__ __forceinline__ double fast_recip(double x) {
 // into 16x16 quarters, inv([[A11, A12], [A21, A22]]) = [[B11, B12], [B21, B22]] with S = A22 - A21 A11^-1 A12,
 //   B22 = S^-1,  B12 = -(A11^-1 A12) B22,  B21 = -B22 (A21 A11^-1),  B11 = A11^-1 - B12 (A21 A11^-1).
 // The two 16x16 inversions are 16 dependent Gauss-Jordan steps each inside ONE wavefront (lane = row r, four consecutive
-// columns in registers; pivot row / column / pivot travel by lane shuffles, no workgroup barrier per step); the six
-// 16x16x16 products in between use all 256 threads (one output element each, operands in LDS). 32 dependent steps either
-// way, but a step costs a few shuffles instead of an LDS round trip plus a workgroup barrier (the one-level version,
-// thread = (row, 4 columns) of the whole block, took ~7 us of each 13 us block step).
+// columns in registers; pivot row / column / pivot travel by lane exchanges, no workgroup barrier per step); the six
+// 16x16x16 products in between are matrix-core tiles of the same wavefront. 32 dependent steps either way, but a step
+// costs a few lane exchanges instead of an LDS round trip plus a workgroup barrier (the one-level version, thread =
+// (row, 4 columns) of the whole block, took ~7 us of each 13 us block step).
 // The block is in A on entry (XS and, once read, A serve as scratch); the result goes to `pinv`.
-__device__ __forceinline__ bool gj_inv16_wave(double (&a)[4], int lane) {
+// Lane exchanges of gj_inv16_wave that do not need the LDS crossbar: a wave-uniform source lane (v_readlane), and the
+// broadcast of lane Q of every quad to its quad (DPP quad_perm).
+__device__ __forceinline__ double gj_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+template <int Q>
+__device__ __forceinline__ double gj_quad_bcast(double v) {
+  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Step K of the 16 dependent Gauss-Jordan steps. Every lane carries a private copy `rk` of "its" four columns of the
+// NEXT pivot row, kept up to date with the same operations the row's owner lanes apply, so that the only things on the
+// step-to-step critical path are the pivot's reciprocal and two multiply-adds; the lane shuffle that fetches row K + 1
+// (ds_bpermute, ~100 cycles) is issued a whole step before its result is needed, the pivot and the multipliers travel
+// by v_readlane / DPP. (First version: pivot, multiplier and pivot row all by ds_bpermute after the update, then the
+// reciprocal: ~250 cycles per step, 5.6 us per 32x32 block - tools/gj_probe.hip.) The arithmetic, and with it the
+// result, is bit for bit that of the first version.
+template <int K>
+__device__ __forceinline__ void gj_step16(double (&a)[4], double (&rk)[4], bool& vanished, int lane) {
   const int r = lane >> 2, q = lane & 3;
-  bool vanished = false;
+  constexpr int QK = K >> 2, JK = K & 3;       // column K: lane group QK, register JK
+  // the pivot: every lane of group QK holds it in its copy of the pivot row
+  const double piv = gj_readlane(rk[JK], QK);
+  // next pivot row as it is now (before this step's update), and its multiplier
+  double nr[4] = {0.0, 0.0, 0.0, 0.0};
+  double m = 0.0;
+  if (K < 15) {
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    // my row's element of the pivot column (it sits in lane 4 r + k / 4, register k % 4), the pivot, the pivot row
-    const double own = a[k & 3];
-    const double aik = __shfl(own, 4 * r + (k >> 2), 64);
-    const double piv = __shfl(own, 4 * k + (k >> 2), 64);
-    double rk[4];
+    for (int j = 0; j < 4; j++) nr[j] = __shfl(a[j], 4 * (K + 1) + q, 64);
+    m = gj_readlane(a[JK], 4 * (K + 1) + QK);
+  }
+  const double aik = gj_quad_bcast<QK>(a[JK]);   // my row's element of the pivot column
+  const double inv = fast_recip(piv);
+  // vanished pivot: the multiplier of this row exceeds the growth bound, or the pivot is tiny / 0 / not finite
+  vanished |= (r != K) ? (aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) : !(fabs(piv) >= PIVOT_MIN);
+  // (a single wavefront issues this chain: the instruction count per step is what it costs - only register JK can
+  // hold the pivot column, the other three need no selects for it)
 #pragma unroll
-    for (int j = 0; j < 4; j++) rk[j] = __shfl(a[j], 4 * k + q, 64);
-    const double inv = fast_recip(piv);
-    // vanished pivot: the multiplier of this row exceeds the growth bound, or the pivot is tiny / 0 / not finite
-    vanished |= (r != k) ? (aik != 0.0 && !(fabs(aik * inv) <= PIVOT_GROWTH_MAX)) : !(fabs(piv) >= PIVOT_MIN);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const bool kc = (4 * q + j == k);
+  for (int j = 0; j < 4; j++) {
+    if (j == JK) {
+      const bool kc = q == QK;
       const double rkj = (kc ? 1.0 : rk[j]) * inv;
-      a[j] = (r == k) ? rkj : (kc ? 0.0 : a[j]) - aik * rkj;
+      a[j] = (r == K) ? rkj : (kc ? 0.0 : a[j]) - aik * rkj;
+      nr[j] = (kc ? 0.0 : nr[j]) - m * rkj;
+    } else {
+      const double rkj = rk[j] * inv;
+      a[j] = (r == K) ? rkj : a[j] - aik * rkj;
+      nr[j] = nr[j] - m * rkj;
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; j++) rk[j] = nr[j];
+}
+
+__device__ __forceinline__ bool gj_inv16_wave(double (&a)[4], int lane) {
+  bool vanished = false;
+  double rk[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) rk[j] = __shfl(a[j], lane & 3, 64);   // row 0
+  gj_step16<0>(a, rk, vanished, lane);   gj_step16<1>(a, rk, vanished, lane);   gj_step16<2>(a, rk, vanished, lane);
+  gj_step16<3>(a, rk, vanished, lane);   gj_step16<4>(a, rk, vanished, lane);   gj_step16<5>(a, rk, vanished, lane);
+  gj_step16<6>(a, rk, vanished, lane);   gj_step16<7>(a, rk, vanished, lane);   gj_step16<8>(a, rk, vanished, lane);
+  gj_step16<9>(a, rk, vanished, lane);   gj_step16<10>(a, rk, vanished, lane);  gj_step16<11>(a, rk, vanished, lane);
+  gj_step16<12>(a, rk, vanished, lane);  gj_step16<13>(a, rk, vanished, lane);  gj_step16<14>(a, rk, vanished, lane);
+  gj_step16<15>(a, rk, vanished, lane);
   return vanished;
 }
 
 constexpr int GJ_XS = 4 * (GJ_NB / 2) * (GJ_NB / 2 + 1);     // scratch doubles of gj_invert_block_lds
+// Runs in the workgroup's FIRST wavefront only (the others return at once): the two 16x16 inversions are single-wave
+// work anyway, and the six 16x16x16 products in between are one v_mfma_f64_16x16x4 tile each (4 instructions, operands
+// from LDS) - no workgroup barrier anywhere, the LDS executes a wave's operations in order. (Before: the products as
+// 16-term scalar dot products by all 256 threads, ~200 LDS reads per thread and five barriers: 2.6 of the 5.3 us the
+// inversion added to every launch, tools/gj_probe.hip.)
 __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB + 1], double* __restrict__ XS, double* __restrict__ pinv, int* bad) {
   constexpr int H = GJ_NB / 2, LDX = H + 1;
+  if (threadIdx.x >= 64) return;
   double* X0 = XS;                     // A11^-1
   double* X1 = X0 + H * LDX;           // T = A21 A11^-1
   double* X2 = X1 + H * LDX;           // U = A11^-1 A12
   double* X3 = X2 + H * LDX;           // S, then B22
-  const int t = threadIdx.x, lane = t & 63;
-  const int i = t >> 4, j = t & 15;
+  const int lane = threadIdx.x;
+  const int r = lane >> 2, c0 = (lane & 3) * 4;     // layout of the 16x16 inversions: lane = (row, 4 columns)
+  const int li = lane & 15, lk = lane >> 4;         // MFMA operand / result layout (see the head of this section)
   bool vanished = false;
-  if (t < 64) {
-    const int r = lane >> 2, c0 = (lane & 3) * 4;
+  {
     double a[4];
 #pragma unroll
     for (int x = 0; x < 4; x++) a[x] = A[r][c0 + x];
@@ -210,27 +263,31 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB + 1], doub
 #pragma unroll
     for (int x = 0; x < 4; x++) X0[r * LDX + c0 + x] = a[x];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   {
-    double tt = 0.0, uu = 0.0;
+    gj_d4 tt = {0.0, 0.0, 0.0, 0.0}, uu = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < H; k++) {
-      tt += A[H + i][k] * X0[k * LDX + j];
-      uu += X0[i * LDX + k] * A[k][H + j];
+    for (int ks = 0; ks < 4; ks++) {
+      const int k = 4 * ks + lk;
+      tt = __builtin_amdgcn_mfma_f64_16x16x4f64(A[H + li][k], X0[k * LDX + li], tt, 0, 0, 0);
+      uu = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[li * LDX + k], A[k][H + li], uu, 0, 0, 0);
     }
-    X1[i * LDX + j] = tt;
-    X2[i * LDX + j] = uu;
-  }
-  __syncthreads();
-  {
-    double ss = A[H + i][H + j];
 #pragma unroll
-    for (int k = 0; k < H; k++) ss -= X1[i * LDX + k] * A[k][H + j];
-    X3[i * LDX + j] = ss;
+    for (int v = 0; v < 4; v++) { X1[(4 * v + lk) * LDX + li] = tt[v]; X2[(4 * v + lk) * LDX + li] = uu[v]; }
   }
-  __syncthreads();
-  if (t < 64) {
-    const int r = lane >> 2, c0 = (lane & 3) * 4;
+  __builtin_amdgcn_wave_barrier();
+  {
+    gj_d4 ss = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int k = 4 * ks + lk;
+      ss = __builtin_amdgcn_mfma_f64_16x16x4f64(X1[li * LDX + k], A[k][H + li], ss, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) X3[(4 * v + lk) * LDX + li] = A[H + 4 * v + lk][H + li] - ss[v];
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
     double a[4];
 #pragma unroll
     for (int x = 0; x < 4; x++) a[x] = X3[r * LDX + c0 + x];
@@ -238,26 +295,39 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB + 1], doub
 #pragma unroll
     for (int x = 0; x < 4; x++) X3[r * LDX + c0 + x] = a[x];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   double* Y = &A[0][0];                // B12 (the input block is not needed any more)
   {
-    double b21 = 0.0, b12 = 0.0;
+    gj_d4 p21 = {0.0, 0.0, 0.0, 0.0}, p12 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < H; k++) {
-      b21 -= X3[i * LDX + k] * X1[k * LDX + j];
-      b12 -= X2[i * LDX + k] * X3[k * LDX + j];
+    for (int ks = 0; ks < 4; ks++) {
+      const int k = 4 * ks + lk;
+      p21 = __builtin_amdgcn_mfma_f64_16x16x4f64(X3[li * LDX + k], X1[k * LDX + li], p21, 0, 0, 0);
+      p12 = __builtin_amdgcn_mfma_f64_16x16x4f64(X2[li * LDX + k], X3[k * LDX + li], p12, 0, 0, 0);
     }
-    Y[i * LDX + j] = b12;
-    pinv[(H + i) * GJ_NB + j] = b21;
-    pinv[i * GJ_NB + H + j] = b12;
-    pinv[(H + i) * GJ_NB + H + j] = X3[i * LDX + j];
-  }
-  __syncthreads();
-  {
-    double b11 = X0[i * LDX + j];
+    double b22[4];
 #pragma unroll
-    for (int k = 0; k < H; k++) b11 -= Y[i * LDX + k] * X1[k * LDX + j];
-    pinv[i * GJ_NB + j] = b11;
+    for (int v = 0; v < 4; v++) b22[v] = X3[(4 * v + lk) * LDX + li];
+    __builtin_amdgcn_wave_barrier();   // Y overlays nothing that is still read: A is dead since S was formed
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = 4 * v + lk;
+      Y[i * LDX + li] = -p12[v];
+      pinv[(H + i) * GJ_NB + li] = -p21[v];
+      pinv[i * GJ_NB + H + li] = -p12[v];
+      pinv[(H + i) * GJ_NB + H + li] = b22[v];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    gj_d4 bb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int k = 4 * ks + lk;
+      bb = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[li * LDX + k], X1[k * LDX + li], bb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) pinv[(4 * v + lk) * GJ_NB + li] = X0[(4 * v + lk) * LDX + li] - bb[v];
   }
   if (bad && vanished) *bad = 1;                // benign race: every writer stores the same value
 }

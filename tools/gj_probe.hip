@@ -6,6 +6,7 @@
 #include "../kinetica_jl_amd/csrc/solver_kernels.hip"
 
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -44,6 +45,9 @@ int main(int argc, char** argv) {
       for (int k = 0; k < m; k++) acc += A[(size_t)i * m + k] * Inv[(size_t)k * m + j];
       worst = fmax(worst, fabs(acc - (i == j ? 1.0 : 0.0)));
     }
+  unsigned long long fnv = 1469598103934665603ull;
+  for (size_t i = 0; i < Inv.size(); i++) { unsigned long long w; memcpy(&w, &Inv[i], 8); fnv = (fnv ^ w) * 1099511628211ull; }
+  printf("checksum of the inverse %016llx\n", fnv);
   printf("m=%d  GJ mean %.1f us  best %.1f us  (%d launches)  max|A inv - I| (sampled) %.2e  bad=%d\n", m, sum / reps * 1e3, best * 1e3,
          m / 32 + 1, worst, hbad);
   return 0;
