@@ -462,14 +462,16 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       PA = build_seg_plan((int64_t)ns + m, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, aux.data(), &slotA);
     };
     auto build_C = [&] {   // stage C: x1_i = sum_j V[i,j] y1_j + sum_c NVU[i,c] x2_c
-      std::vector<int32_t> ptr{0}, dst, b;
+      // (aux = the species behind the row: SEG_PROD_SET does not read it, the launch that fuses this stage with the
+      // corrector update does - solver_kernels.hip: stagec_newton_kernel)
+      std::vector<int32_t> ptr{0}, dst, aux, b;
       for (int32_t i = 0; i < ns; i++) {
         for (auto& ce : v_cols[i]) { idC.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_y1 + ce.first)); }
         for (int64_t en = NVU.row_ptr[i]; en < NVU.row_ptr[i + 1]; en++) { idC.push_back((int32_t)(off_NVU + en)); b.push_back((int32_t)(off_x + NVU.col[en])); }
-        ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y + i));
+        ptr.push_back((int32_t)b.size()); dst.push_back((int32_t)(off_y + i)); aux.push_back(perm[i]);
       }
       b.push_back(0);
-      PC = build_seg_plan(ns, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, nullptr, &slotC);
+      PC = build_seg_plan(ns, ptr.data(), dst.data(), nullptr, b.data(), nullptr, false, aux.data(), &slotC);
     };
     { std::thread tA(build_A); build_C(); tA.join(); }
     off_VA = w_end;
@@ -478,6 +480,11 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     if (w_end >= ((int64_t)1 << 30)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
     PA.val_base = (int32_t)off_VA; PC.val_base = (int32_t)off_VC;
     stageA.upload(PA, s); stageC.upload(PC, s);
+    {
+      const std::vector<int32_t> x2(perm.begin() + ns, perm.end());
+      x2_species.upload(x2, s);
+      KIN_HIP(hipStreamSynchronize(s));   // the host vector dies here
+    }
     // relocation of the value IDs
     std::vector<int32_t> relZ(nnzZ, -1), relV(nnzV, -1), relLZ(nnzLZ, -1), relNVU(nnzNVU, -1);
     auto place = [&](int32_t id, int32_t pos) {
@@ -592,6 +599,17 @@ void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipSt
   q.c_fact = c;
   q.crate = 1.0;
   q.valid = true;
+}
+
+void SparseLU::solve_newton(int slot, NewtonFuse f, hipStream_t s) {
+  Slot& q = slots[slot];
+  double* W = q.W.p;
+  SegExtra ex;
+  ex.skip = f.skip;
+  launch_segsum(stageA.view(), SEG_PROD_AUXSUB, W, W, ex, s);
+  launch_gemv(q.sinv, mpad, m, W + off_y + ns, W + off_x, f.skip, s);
+  f.m = m; f.off_x = (int32_t)off_x; f.x2_species = x2_species.p;
+  launch_stagec_newton(stageC.view(), W, f, s);
 }
 
 void SparseLU::solve(const int* skip, int slot, hipStream_t s) {

@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "solver_kernels.hpp"
 
 namespace kin {
 
@@ -98,6 +99,11 @@ struct SparseLU {
   // solves M x = b in place with the factors of `slot`: b was written to W[yloc[v]], x is read from W[xloc[v]]
   // (W = that slot's array). `skip`: optional device flag making every kernel of the solve a no-op.
   void solve(const int* skip, int slot, hipStream_t s);
+  // fused_tri only: the same solve with the corrector update of the BDF step folded into its last launch (the right-hand
+  // side was written to W[yloc], `f` carries what the update and its decision need; f.skip makes every launch a no-op)
+  void solve_newton(int slot, NewtonFuse f, hipStream_t s);
+  int newton_grid() const { return stagec_newton_grid(stageC.view(), m); }   // workgroups of that last launch
+  DevBuf<int32_t> x2_species;               // species behind the dense block's rows
 };
 
 // dense / LU helper kernels (solver_kernels.hip)

@@ -111,6 +111,8 @@ struct Solver {
       if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
       if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
       if (const char* e = getenv("KIN_CARRY_RATE")) carry_rate = atoi(e) != 0;
+      fuse_newton = lu.fused_tri && lu.m > 0 && lu.newton_grid() <= 10;
+      if (const char* e = getenv("KIN_FUSE_NEWTON")) fuse_newton = atoi(e) != 0 && lu.fused_tri && lu.m > 0;
       if (const char* e = getenv("KIN_CRATE_AGE")) crate_max_age = atoll(e);
       if (const char* e = getenv("KIN_CRATE_DYMAX")) crate_dy_max = atof(e);
       if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
@@ -135,7 +137,7 @@ struct Solver {
     y.alloc(N); psi.alloc(N); d.alloc(N); scale.alloc(N); f0.alloc(N); f1.alloc(N); ytmp.alloc(N); umax.alloc(N);
     jv.alloc(H.nnz());
     ctrl.alloc(1);
-    red.alloc((size_t)5 * bdf_reduce_blocks(N));
+    red.alloc((size_t)bdf_reduce_slot() * std::max(bdf_reduce_blocks(N), (lu.fused_tri && lu.m > 0) ? lu.newton_grid() : 0));
     KIN_HIP(hipMemsetAsync(ctrl.p, 0, sizeof(BdfCtrl), s));
     // the step-end hand-over needs device writes to become visible to the spinning host thread while the stream
     // keeps running: fine-grained (coherent), device-mapped pinned memory
@@ -347,6 +349,12 @@ struct Solver {
   // CVODE's carried convergence rate (KIN_CARRY_RATE=0 switches it off): each factorisation remembers the contraction its
   // corrector iterations have shown, and the first iteration of a step is judged with it (solver_kernels.hip)
   bool carry_rate = true;
+  // The corrector update folded into the solve's last gather launch (stagec_newton_kernel). One launch less per iteration,
+  // but every workgroup of the gather then takes part in the reduction hand-over (partial sums + arrival ticket), and that
+  // costs ~0.3 us per workgroup: measured per 20-chunk solve, fused against separate: 300 species 0.101 / 0.110 s, 1 000
+  // 0.107-0.110 / 0.116, 2 000 0.139 / 0.138, 5 000 0.204 / 0.174, 10 000 (65 workgroups) 0.572 / 0.449 s per 100 chunks.
+  // Default: fused when the fused launch has at most 10 workgroups; KIN_FUSE_NEWTON=1 / 0 forces it on / off.
+  bool fuse_newton = false;
   // The remembered rate is trusted for `crate_max_age` accepted steps after it was last measured and never across a
   // restart (new rates, new Jacobian): CVODE resets crate at every linear-solver setup, i.e. at least every 20 steps,
   // with a Jacobian at most 50 steps old. Without a bound a slot whose contraction has degraded is never found out -
@@ -396,13 +404,26 @@ struct Solver {
     if (h->k_pending) { launch_rates_skip_T(h->host.R, h->pending_at(), h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s); h->k_pending = false; }
     else launch_rates_skip(h->host.R, h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s);
     launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, q.W.p, ex, s);
-    lu.solve(skip, cur_slot, s);
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
     const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
-    launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd,
-                      (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0, carry_rate ? q.crate : 1.0,
-                      crate_fresh(q) ? newton_tol : -1.0, crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p,
-                      hc_dev, hseq_dev, seq, last, s);
+    const double rate_max = (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0;
+    const double crate0 = carry_rate ? q.crate : 1.0, tol_first = crate_fresh(q) ? newton_tol : -1.0;
+    if (fuse_newton) {
+      // the solve's last gather stage and the corrector update in one launch
+      NewtonFuse f;
+      f.skip = skip; f.N = N; f.m = 0; f.off_x = 0; f.x2_species = nullptr;
+      f.scale = scale.p; f.y = y.p; f.d = d.p; f.D = D.p; f.order = order;
+      f.upd = upd; f.atol = atol; f.rtol = rtol;
+      f.ec = cf.error_const[order]; f.ec_m = order > 1 ? cf.error_const[order - 1] : 0.0; f.ec_p = cf.error_const[order + 1];
+      f.iter = it; f.maxit = BDF_NEWTON_MAXITER; f.tol = newton_tol; f.rate_max = rate_max; f.crate0 = crate0;
+      f.tol_first = tol_first; f.dy_first_max = crate_dy_max;
+      f.ctrl = ctrl.p; f.part = red.p; f.host_ctrl = hc_dev; f.host_seq = hseq_dev; f.seq = seq; f.publish_always = last ? 1 : 0;
+      lu.solve_newton(cur_slot, f, s);
+    } else {
+      lu.solve(skip, cur_slot, s);
+      launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd, rate_max, crate0, tol_first,
+                        crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, seq, last, s);
+    }
     st.n_rhs++; st.n_linsolve++;
   }
 

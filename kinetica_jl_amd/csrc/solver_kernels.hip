@@ -8,6 +8,7 @@
 
 #include "exp_tab.hpp"
 #include "kernels.hpp"
+#include "segsum_dev.hpp"
 
 #include <utility>
 
@@ -593,6 +594,89 @@ __device__ __forceinline__ double sum_partials(const double* part, int n) {
   return t;
 }
 
+// A workgroup's five partial sums sit in ONE 128-byte line of their own (RED_SLOT doubles apart): write-through stores of 60
+// workgroups into shared lines serialise at the memory side - 325 stores took ~45 us of a 55 us launch with the sums of all
+// workgroups interleaved (part[q * G + g]), and ~7 of the 10.7 us of the 10-workgroup launch before it.
+constexpr int RED_SLOT = 16;
+// The five sums of a corrector launch from the workgroups' partial sums: by the first wavefront of the workgroup that arrived
+// last, one partial per lane and round (all loads in flight together), fixed butterfly order - bitwise reproducible. (A
+// single thread adding them one `sc1` load after the other was fine for 10 workgroups and is ~0.2-1 us per partial: the
+// fused launch below has 60 workgroups at 10k species.)
+__device__ __forceinline__ void newton_totals(const double* part, int G, double (&tot)[5]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    double v = 0.0;
+    for (int g = lane; g < G; g += 64) v += __hip_atomic_load(part + g * RED_SLOT + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[q] = wave_sum(v);
+  }
+}
+
+// The decision of a corrector iteration, taken by ONE thread of the workgroup that arrived last (all partial sums are
+// visible to it): norm of the update, contraction rate, converged / diverged / go on, and - when converged - the step's
+// error-test norms; publishes the control block to the host when the attempt is decided (or `publish_always`).
+struct NewtonDecide {
+  int N, iter, maxit;
+  double tol, rate_max, crate0, tol_first, dy_first_max;
+  BdfCtrl* ctrl; const double* tot;   // tot[5]: the launch's sums (update, error test of order / -1 / +1, negative entries)
+  BdfCtrl* host_ctrl; unsigned long long* host_seq; unsigned long long seq; int publish_always;
+};
+__device__ __forceinline__ void newton_decide(const NewtonDecide& a) {
+  const int N = a.N, iter = a.iter, maxit = a.maxit, publish_always = a.publish_always;
+  const double tol = a.tol, rate_max = a.rate_max, crate0 = a.crate0, tol_first = a.tol_first, dy_first_max = a.dy_first_max;
+  BdfCtrl* ctrl = a.ctrl; BdfCtrl* host_ctrl = a.host_ctrl;
+  unsigned long long* host_seq = a.host_seq; const unsigned long long seq = a.seq;
+  {
+    const double tot = a.tot[0];
+    const double old = ctrl->dy_norm_old;
+    const double dy_norm = sqrt(tot / (double)N);
+    const bool nonfinite = !isfinite(tot);
+    const bool have_rate = iter > 0;
+    const double rate = have_rate ? dy_norm / old : 0.0;
+    // CVODE's carried convergence rate: every factorisation keeps the contraction it has shown (crate <- max(0.3 crate,
+    // rate) after each iteration with a rate; 1 = unknown, set by the host when the factorisation is made). It lets the
+    // FIRST iteration of a step be judged like the later ones instead of always being followed by a second one.
+    double crate = iter == 0 ? crate0 : ctrl->crate;
+    if (have_rate && !nonfinite) crate = fmax(0.3 * crate, rate);
+    ctrl->crate = crate;
+    bool diverged = nonfinite;
+    // rate_max < 1 (a reused factorisation): a contraction slower than that means the matrix no longer matches the
+    // Jacobian well enough for the error of the iteration to be judged from two or three corrections
+    if (!diverged && have_rate) {
+      double rp = rate;                                     // rate^(maxit - iter), 1 <= maxit - iter <= 3
+      for (int e = 1; e < maxit - iter; e++) rp *= rate;
+      if (rate >= rate_max || rp / (1.0 - rate) * dy_norm > tol) diverged = true;
+    }
+    ctrl->n_iter = iter + 1;
+    ctrl->dy_norm = dy_norm;
+    bool done = true, converged = false;
+    if (diverged) { ctrl->nonfinite = nonfinite; }
+    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) ||
+             (!have_rate && (dy_norm < tol || (crate0 < 1.0 && dy_norm <= dy_first_max && crate0 / (1.0 - crate0) * dy_norm < tol_first)))) {
+      converged = true;                             // (first-iteration acceptance as in ode15s / CVODE)
+    }
+    else {
+      ctrl->dy_norm_old = dy_norm;
+      done = iter == maxit - 1;
+    }
+    if (converged) {
+      const double te = a.tot[1];
+      ctrl->err_norm = sqrt(te / (double)N);
+      ctrl->err_m_norm = sqrt(a.tot[2] / (double)N);
+      ctrl->err_p_norm = sqrt(a.tot[3] / (double)N);
+      ctrl->any_negative = a.tot[4] > 0.0;
+      if (!isfinite(te)) ctrl->nonfinite = 1;
+    }
+    ctrl->converged = converged ? 1 : 0;
+    ctrl->newton_done = done ? 1 : 0;
+    if ((done || publish_always) && host_ctrl) {
+      *host_ctrl = *ctrl;
+      __threadfence_system();
+      *(volatile unsigned long long*)host_seq = seq;
+    }
+  }
+}
+
 // One Newton update: y += dy, d += dy, ||dy||, convergence decision - and, folded in, the step's error estimate: every
 // workgroup also reduces the error-test sums of the state THIS iteration produces, so the workgroup that takes the
 // decision has them at hand when the decision is "converged" and publishes the attempt's result to the host itself
@@ -654,7 +738,7 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < 5; q++) store_partial(part + q * G + blockIdx.x, (sh[q] + sh[5 + q]) + (sh[10 + q] + sh[15 + q]));
+    for (int q = 0; q < 5; q++) store_partial(part + blockIdx.x * RED_SLOT + q, (sh[q] + sh[5 + q]) + (sh[10 + q] + sh[15 + q]));
   }
   const bool is_last = last_block_arrives(ctrl, &last);
   // the state update is off the critical path of the decision: its stores go out while the ticket travels
@@ -663,56 +747,158 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     const int i = i0 + 256 * x;
     if (i < N) { y[i] = yy[x]; d[i] = dd[x]; }
   }
-  if (!is_last) return;
-  if (threadIdx.x == 0) {
-    const double tot = sum_partials(part, G);
-    const double old = ctrl->dy_norm_old;
-    const double dy_norm = sqrt(tot / (double)N);
-    const bool nonfinite = !isfinite(tot);
-    const bool have_rate = iter > 0;
-    const double rate = have_rate ? dy_norm / old : 0.0;
-    // CVODE's carried convergence rate: every factorisation keeps the contraction it has shown (crate <- max(0.3 crate,
-    // rate) after each iteration with a rate; 1 = unknown, set by the host when the factorisation is made). It lets the
-    // FIRST iteration of a step be judged like the later ones instead of always being followed by a second one.
-    double crate = iter == 0 ? crate0 : ctrl->crate;
-    if (have_rate && !nonfinite) crate = fmax(0.3 * crate, rate);
-    ctrl->crate = crate;
-    bool diverged = nonfinite;
-    // rate_max < 1 (a reused factorisation): a contraction slower than that means the matrix no longer matches the
-    // Jacobian well enough for the error of the iteration to be judged from two or three corrections
-    if (!diverged && have_rate) {
-      double rp = rate;                                     // rate^(maxit - iter), 1 <= maxit - iter <= 3
-      for (int e = 1; e < maxit - iter; e++) rp *= rate;
-      if (rate >= rate_max || rp / (1.0 - rate) * dy_norm > tol) diverged = true;
+  if (!is_last || threadIdx.x >= 64) return;
+  double tot[5];
+  newton_totals(part, G, tot);
+  if (threadIdx.x == 0)
+    newton_decide(NewtonDecide{N, iter, maxit, tol, rate_max, crate0, tol_first, dy_first_max, ctrl, tot, host_ctrl, host_seq, seq,
+                               publish_always});
+}
+
+// ------------------------------------------------------------------------------------------
+// The last gather stage of the fused solve (lu.hpp: x1 = V y1 + NVU x2) and the corrector update in ONE launch: a row of the
+// stage produces the solution component of one species, and everything the update needs of that species (scale, y, d, two
+// difference rows) is requested together with the row's descriptors, before the gather. The dense block's components
+// (x2, already there from the GEMV) are taken by extra wavefront tasks behind the plan's. Partial sums, ticket and decision
+// as in bdf_newton_kernel. One launch of ~11 us and its dependency gap less per corrector iteration (C3: 5.4 + 10.7 us
+// -> see DESIGN 3.3). The plan's `aux` entries hold the species index of each row (lu.cpp: build_C).
+// ------------------------------------------------------------------------------------------
+struct NewtonElem { double sc, yy, dd, dm, dp; };
+struct NewtonSums { double s = 0.0, se = 0.0, sm = 0.0, sp = 0.0, neg = 0.0; };
+
+__device__ __forceinline__ NewtonElem newton_pre(const NewtonFuse& f, int32_t sp) {
+  NewtonElem e{1.0, 0.0, 0.0, 0.0, 0.0};
+  if (sp < 0) return e;
+  e.sc = f.scale[sp]; e.yy = f.y[sp]; e.dd = f.d[sp];
+  if (f.order > 1) e.dm = f.D[(size_t)f.order * f.N + sp];
+  if (f.order < 5) e.dp = f.D[(size_t)(f.order + 1) * f.N + sp];
+  return e;
+}
+// the update of species sp with solution component x (the arithmetic of bdf_newton_kernel, element by element)
+__device__ __forceinline__ void newton_apply(const NewtonFuse& f, int32_t sp, double x, NewtonElem e, NewtonSums& t) {
+  const double dy = f.upd * x;
+  const double q = dy / e.sc;
+  t.s += q * q;
+  e.yy += dy; e.dd += dy;
+  if (e.yy < 0.0) t.neg = 1.0;
+  const double sce = f.atol + f.rtol * fabs(e.yy);
+  const double er = f.ec * e.dd / sce;
+  t.se += er * er + (isfinite(e.yy) ? 0.0 : INFINITY);
+  if (f.order > 1) { const double em = f.ec_m * (e.dm + e.dd) / sce; t.sm += em * em; }
+  if (f.order < 5) { const double ep = f.ec_p * (e.dd - e.dp) / sce; t.sp += ep * ep; }
+  f.y[sp] = e.yy; f.d[sp] = e.dd;
+}
+
+template <int SEG_WG>
+__global__ __launch_bounds__(SEG_WG) void stagec_newton_kernel(SegPlanView p, double* W, NewtonFuse f) {
+  constexpr int OP = SEG_PROD_SET;
+  constexpr int SEG_WAVES = SEG_WG / 64, BLK_PER_THREAD = SegPlanHost::BLK_PASS / 1024;
+  __shared__ double sh[5 * SEG_WAVES];
+  __shared__ double shb[SEG_WAVES];
+  __shared__ int last;
+  const int skip = *f.skip;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool impl = p.val_base >= 0;
+  const SegExtra ex;
+  NewtonSums t;
+  if (SEG_WG == 1024 && (int)blockIdx.x < p.B) {       // one long row for the whole workgroup
+    const int r = blockIdx.x;
+    const int32_t e0 = p.blk_beg[r], e1 = p.blk_end[r];
+    const int32_t bdst = p.blk_dst[r];
+    const int32_t bsp = p.blk_aux[r];
+    if (skip) return;      // (whole grid: the flag is uniform and only this launch's LAST workgroup can raise it)
+    const NewtonElem pre = newton_pre(f, threadIdx.x == 0 ? bsp : -1);
+    double acc = 0.0;
+    for (int32_t base = e0; base < e1; base += SegPlanHost::BLK_PASS)
+      acc += seg_gather<OP, BLK_PER_THREAD, false>(p, W, ex, impl, [&](int x) {
+        const int32_t e = base + (int32_t)threadIdx.x + 1024 * x;
+        return e < e1 ? e : -1;
+      });
+    acc = wave_sum(acc);
+    if (lane == 0) shb[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < SEG_WAVES; w++) tot += shb[w];     // fixed order
+      W[bdst] = tot;
+      newton_apply(f, bsp, tot, pre, t);
     }
-    ctrl->n_iter = iter + 1;
-    ctrl->dy_norm = dy_norm;
-    bool done = true, converged = false;
-    if (diverged) { ctrl->nonfinite = nonfinite; }
-    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < tol) ||
-             (!have_rate && (dy_norm < tol || (crate0 < 1.0 && dy_norm <= dy_first_max && crate0 / (1.0 - crate0) * dy_norm < tol_first)))) {
-      converged = true;                             // (first-iteration acceptance as in ode15s / CVODE)
-    }
-    else {
-      ctrl->dy_norm_old = dy_norm;
-      done = iter == maxit - 1;
-    }
-    if (converged) {
-      const double te = sum_partials(part + G, G);
-      ctrl->err_norm = sqrt(te / (double)N);
-      ctrl->err_m_norm = sqrt(sum_partials(part + 2 * G, G) / (double)N);
-      ctrl->err_p_norm = sqrt(sum_partials(part + 3 * G, G) / (double)N);
-      ctrl->any_negative = sum_partials(part + 4 * G, G) > 0.0;
-      if (!isfinite(te)) ctrl->nonfinite = 1;
-    }
-    ctrl->converged = converged ? 1 : 0;
-    ctrl->newton_done = done ? 1 : 0;
-    if ((done || publish_always) && host_ctrl) {
-      *host_ctrl = *ctrl;
-      __threadfence_system();
-      *(volatile unsigned long long*)host_seq = seq;
+  } else {
+    const int task = ((int)blockIdx.x - p.B) * SEG_WAVES + wv;
+    if (task < p.G) {                                   // an ELL group: one short row per lane
+      const int32_t dst = p.grp_dst[task * 64 + lane];
+      const int32_t sp = dst >= 0 ? p.grp_aux[task * 64 + lane] : -1;
+      const int32_t c0 = p.grp_off[task], c1 = p.grp_off[task + 1];
+      if (skip) return;
+      const NewtonElem pre = newton_pre(f, sp);
+      double acc = 0.0;
+      for (int32_t col = c0; col < c1; col += 8)
+        acc += seg_gather<OP, 8, true>(p, W, ex, impl, [&](int x) { return col + x < c1 ? (col + x) * 64 + lane : -1; });
+      if (dst >= 0) { W[dst] = acc; newton_apply(f, sp, acc, pre, t); }
+    } else if (task < p.G + p.S) {                      // one medium row per wavefront
+      const int sidx = task - p.G;
+      const int32_t e0 = p.seg_beg[sidx], e1 = p.seg_end[sidx];
+      const int32_t sdst = p.seg_dst[sidx];
+      const int32_t ssp = p.seg_aux[sidx];
+      if (skip) return;
+      const NewtonElem pre = newton_pre(f, lane == 0 ? ssp : -1);
+      double acc;
+      if (e1 - e0 <= 256)
+        acc = seg_gather<OP, 4, false>(p, W, ex, impl, [&](int x) { const int32_t e = e0 + lane + 64 * x; return e < e1 ? e : -1; });
+      else
+        acc = seg_gather<OP, 16, false>(p, W, ex, impl, [&](int x) { const int32_t e = e0 + lane + 64 * x; return e < e1 ? e : -1; });
+      acc = wave_sum(acc);
+      if (lane == 0) { W[sdst] = acc; newton_apply(f, ssp, acc, pre, t); }
+    } else {                                            // the dense block's species: x2 is in place since the GEMV
+      if (skip) return;
+      const int j = (task - p.G - p.S) * 64 + lane;
+      if (j < f.m) {
+        const int32_t sp = f.x2_species[j];
+        const NewtonElem pre = newton_pre(f, sp);
+        newton_apply(f, sp, W[f.off_x + j], pre, t);
+      }
     }
   }
+  // five sums over the workgroup, one pair of barriers
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    t.s += __shfl_down(t.s, off, 64); t.se += __shfl_down(t.se, off, 64); t.sm += __shfl_down(t.sm, off, 64);
+    t.sp += __shfl_down(t.sp, off, 64); t.neg += __shfl_down(t.neg, off, 64);
+  }
+  if (lane == 0) { sh[5 * wv] = t.s; sh[5 * wv + 1] = t.se; sh[5 * wv + 2] = t.sm; sh[5 * wv + 3] = t.sp; sh[5 * wv + 4] = t.neg; }
+  __syncthreads();
+  const int G = gridDim.x;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < SEG_WAVES; w++) tot += sh[5 * w + q];     // fixed order
+      store_partial(f.part + blockIdx.x * RED_SLOT + q, tot);
+    }
+  }
+  if (!last_block_arrives(f.ctrl, &last) || threadIdx.x >= 64) return;
+  double tot[5];
+  newton_totals(f.part, G, tot);
+  if (threadIdx.x == 0)
+    newton_decide(NewtonDecide{f.N, f.iter, f.maxit, f.tol, f.rate_max, f.crate0, f.tol_first, f.dy_first_max, f.ctrl, tot,
+                               f.host_ctrl, f.host_seq, f.seq, f.publish_always});
+}
+
+static bool stagec_big_wg(const SegPlanView& p) {
+  static const int force = getenv("KIN_FUSE_WG") ? atoi(getenv("KIN_FUSE_WG")) : 0;
+  return p.B > 0 || force == 1024;
+}
+int stagec_newton_grid(const SegPlanView& p, int m) {
+  const int tasks = p.G + p.S + (int)ceil_div(m, 64);
+  return stagec_big_wg(p) ? p.B + (int)ceil_div(tasks, 16) : (int)ceil_div(tasks, 4);
+}
+void launch_stagec_newton(const SegPlanView& p, double* W, const NewtonFuse& f, hipStream_t s) {
+  const int grid = stagec_newton_grid(p, f.m);
+  if (stagec_big_wg(p)) hipLaunchKernelGGL((stagec_newton_kernel<1024>), dim3(grid), dim3(1024), 0, s, p, W, f);
+  else hipLaunchKernelGGL((stagec_newton_kernel<256>), dim3(grid), dim3(256), 0, s, p, W, f);
+  KIN_HIP(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void bdf_accept_kernel(int N, int order, double* __restrict__ D, const double* __restrict__ d,
@@ -950,6 +1136,7 @@ void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, do
   hipLaunchKernelGGL(bdf_predict_kernel, GRID1(N), 0, s, N, order, D, cf, atol, rtol, y, psi, d, scale, ctrl);
 }
 int bdf_reduce_blocks(int N) { return (int)ceil_div(N, RED_ELEMS); }
+int bdf_reduce_slot() { return RED_SLOT; }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
                        double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max,
                        int order, const double* D, double atol, double rtol, const BdfCoef& cf, BdfCtrl* ctrl, double* part,

@@ -38,6 +38,24 @@ void launch_slot_drift(int N, int n_slots, const double* jv, const int32_t* j_di
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
                         double* d, double* scale, BdfCtrl* ctrl, hipStream_t s);   // also clears *ctrl
+// The same with the solve's last gather stage in the same launch (solver_kernels.hip: stagec_newton_kernel). W = the slot's
+// value array; the plan is SparseLU::stageC, whose aux entries are species indices.
+struct NewtonFuse {
+  const int* skip;
+  int N, m;                     // species; size of the dense block
+  int32_t off_x;                // W position of the dense block's solution
+  const int32_t* x2_species;    // m: species behind the dense block's rows
+  const double* scale; double* y; double* d; const double* D;
+  int order;
+  double upd, atol, rtol, ec, ec_m, ec_p;   // error constants of order, order - 1, order + 1
+  int iter, maxit;
+  double tol, rate_max, crate0, tol_first, dy_first_max;
+  BdfCtrl* ctrl; double* part; BdfCtrl* host_ctrl; unsigned long long* host_seq; unsigned long long seq; int publish_always;
+};
+struct SegPlanView;
+int stagec_newton_grid(const SegPlanView& p, int m);   // workgroups of the launch (5 partial sums each in `part`)
+void launch_stagec_newton(const SegPlanView& p, double* W, const NewtonFuse& f, hipStream_t s);
+
 // One corrector iteration's update + decision + (folded in) the step's error estimate; the launch that decides publishes
 // the control block to host_ctrl / host_seq (device-visible pinned host memory, or null), the batch's last launch
 // (`publish_always`) also when nothing is decided yet. dy = upd * x; crate0: carried rate, whose first-iteration test needs
@@ -46,7 +64,8 @@ void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xl
                        double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max,
                        int order, const double* D, double atol, double rtol, const BdfCoef& cf, BdfCtrl* ctrl, double* part,
                        BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s);
-// `part`: 5 * bdf_reduce_blocks(N) doubles of partial sums
+// `part`: bdf_reduce_slot() * bdf_reduce_blocks(N) doubles of partial sums
+int bdf_reduce_slot();   // doubles per workgroup in the `part` buffer of the corrector launches
 int bdf_reduce_blocks(int N);
 void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s);   // copy_out (optional): the new state
 // accept of the previous step (order `ao`) + predictor of the next one in one pass (the host defers the accept)
