@@ -553,7 +553,11 @@ __global__ __launch_bounds__(256) void bdf_predict_kernel(int N, int order, cons
 // thread, all loads in flight): each workgroup stores its partial sums, the last one to arrive (ticket in
 // BdfCtrl) adds them in workgroup order - bitwise reproducible - and takes the decision. A single
 // 1024-thread workgroup walking the whole state took 17 us at N = 10k, most of it load latency.
-constexpr int RED_ELEMS = 1024;   // elements per workgroup
+#ifndef KIN_RED_ELEMS
+#define KIN_RED_ELEMS 1024
+#endif
+constexpr int RED_ELEMS = KIN_RED_ELEMS;   // elements per workgroup
+constexpr int RED_PT = RED_ELEMS / 256;     // per thread
 
 __device__ __forceinline__ double block_sum_256(double v, double* sh) {
 #pragma unroll
@@ -699,9 +703,9 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
   // A non-finite update makes the sum of squares non-finite: one reduction carries both the norm and the flag.
   double s = 0.0, se = 0.0, sm = 0.0, sp = 0.0, neg = 0.0;
   const int i0 = blockIdx.x * RED_ELEMS + threadIdx.x;
-  int32_t xl[4]; double dy[4], sc[4], yy[4], dd[4], dm[4], dp[4];
+  int32_t xl[RED_PT]; double dy[RED_PT], sc[RED_PT], yy[RED_PT], dd[RED_PT], dm[RED_PT], dp[RED_PT];
 #pragma unroll
-  for (int x = 0; x < 4; x++) {
+  for (int x = 0; x < RED_PT; x++) {
     const int i = i0 + 256 * x;
     const bool ok = i < N;
     xl[x] = ok ? xloc[i] : -1; sc[x] = ok ? scale[i] : 1.0;
@@ -710,9 +714,9 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     dp[x] = (ok && order < 5) ? D[(size_t)(order + 1) * N + i] : 0.0;
   }
 #pragma unroll
-  for (int x = 0; x < 4; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
+  for (int x = 0; x < RED_PT; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
 #pragma unroll
-  for (int x = 0; x < 4; x++) {
+  for (int x = 0; x < RED_PT; x++) {
     const double q = dy[x] / sc[x];
     s += q * q;
     yy[x] += dy[x]; dd[x] += dy[x];
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
   const bool is_last = last_block_arrives(ctrl, &last);
   // the state update is off the critical path of the decision: its stores go out while the ticket travels
 #pragma unroll
-  for (int x = 0; x < 4; x++) {
+  for (int x = 0; x < RED_PT; x++) {
     const int i = i0 + 256 * x;
     if (i < N) { y[i] = yy[x]; d[i] = dd[x]; }
   }
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(256) void rk_error_kernel(int N, RkVec e, const dou
   const int G = gridDim.x;
   double se = 0.0;
   int neg = 0, bad = 0;
-  for (int x = 0; x < 4; x++) {
+  for (int x = 0; x < RED_PT; x++) {
     const int i = blockIdx.x * RED_ELEMS + threadIdx.x + 256 * x;
     if (i >= N) continue;
     double err = 0.0;
