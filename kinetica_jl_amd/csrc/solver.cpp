@@ -60,7 +60,8 @@ struct Solver {
   SegPlanDev resid_plan;                  // Newton residual written straight into the permuted solve vector
   DevBuf<double> D, y, psi, d, scale, f0, f1, ytmp, jv, umax, red;
   DevBuf<BdfCtrl> ctrl;
-  BdfCtrl* hc = nullptr;                  // pinned host mirror
+  BdfCtrl* hc = nullptr;                  // pinned host mirror: the block of the hand-over last waited for (hc_buf[seq & 1])
+  BdfCtrl* hc_buf = nullptr;
   BdfCoef cf;
   // integrator state
   double t = 0, h_abs = 0, atol = 0, rtol = 0, newton_tol = 0, dtmin = 0;
@@ -111,6 +112,7 @@ struct Solver {
       if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
       if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
       if (const char* e = getenv("KIN_CARRY_RATE")) carry_rate = atoi(e) != 0;
+      if (const char* e = getenv("KIN_SPECULATE")) speculate = atoi(e) != 0;
       fuse_newton = lu.fused_tri && lu.m > 0 && lu.newton_grid() <= 10;
       if (const char* e = getenv("KIN_FUSE_NEWTON")) fuse_newton = atoi(e) != 0 && lu.fused_tri && lu.m > 0;
       if (const char* e = getenv("KIN_CRATE_AGE")) crate_max_age = atoll(e);
@@ -141,10 +143,13 @@ struct Solver {
     KIN_HIP(hipMemsetAsync(ctrl.p, 0, sizeof(BdfCtrl), s));
     // the step-end hand-over needs device writes to become visible to the spinning host thread while the stream
     // keeps running: fine-grained (coherent), device-mapped pinned memory
-    KIN_HIP(hipHostMalloc((void**)&hc, sizeof(BdfCtrl), hipHostMallocCoherent | hipHostMallocMapped));
+    // (two blocks, used alternately by consecutive hand-overs: with a speculatively enqueued step behind the one the host
+    // is reading, the next publication must not land in the block being read)
+    KIN_HIP(hipHostMalloc((void**)&hc_buf, 2 * sizeof(BdfCtrl), hipHostMallocCoherent | hipHostMallocMapped));
+    hc = hc_buf;
     KIN_HIP(hipHostMalloc((void**)&hseq, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
     *hseq = 0;
-    if (hipHostGetDevicePointer((void**)&hc_dev, hc, 0) != hipSuccess ||
+    if (hipHostGetDevicePointer((void**)&hc_dev, hc_buf, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&hseq_dev, hseq, 0) != hipSuccess || getenv("KIN_NO_FAST_SYNC")) {
       (void)hipGetLastError();
       fast_sync = false; fast_sync_allowed = false; hc_dev = nullptr; hseq_dev = nullptr;
@@ -155,7 +160,7 @@ struct Solver {
     for (int j = 0; j <= BDF_MAX_ORDER; j++) cf.error_const[j] = KAPPA[j] * cf.gamma[j] + 1.0 / (j + 1);
     cf.error_const[BDF_MAX_ORDER + 1] = 0.0;
   }
-  ~Solver() { if (hc) (void)hipHostFree(hc); if (hseq) (void)hipHostFree(hseq); if (h_drift) (void)hipHostFree(h_drift); }
+  ~Solver() { if (hc_buf) (void)hipHostFree(hc_buf); if (hseq) (void)hipHostFree(hseq); if (h_drift) (void)hipHostFree(h_drift); }
 
   void set_tols(double a, double r) {
     atol = a; rtol = r;
@@ -178,11 +183,14 @@ struct Solver {
   int64_t n_sync_fallbacks = 0;   // step-end hand-overs that timed out and went through copy + stream sync (KIN_TIMING=1)
   int sync_ok_streak = 0;
   double sync_wait_s = 0.0;   // host time spent blocked in sync_ctrl (diagnostic, KIN_TIMING=1)
+  BdfCtrl* hc_dev_at(unsigned long long seq) const { return hc_dev ? hc_dev + (seq & 1) : nullptr; }
   void wait_ctrl(unsigned long long want) {
     auto t0 = std::chrono::steady_clock::now();
+    hc = hc_buf + (want & 1);
     if (fast_sync) {
       for (unsigned spins = 0;; spins++) {
-        if (*(volatile unsigned long long*)hseq == want) {
+        // (>=: a speculative batch behind the awaited one may have published its own number by the time the host looks)
+        if (*(volatile unsigned long long*)hseq >= want) {
           std::atomic_thread_fence(std::memory_order_acquire);
           sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           return;
@@ -199,13 +207,15 @@ struct Solver {
     sync_ctrl();
     // a slow wait may have been a one-off (first-launch code loading, a profiler, a preempted GPU): after 64
     // synchronising hand-overs in a row whose sequence number DID arrive the fast path is tried again
-    if (fast_sync_allowed && !fast_sync && *(volatile unsigned long long*)hseq == want && ++sync_ok_streak >= 64) {
+    if (fast_sync_allowed && !fast_sync && *(volatile unsigned long long*)hseq >= want && ++sync_ok_streak >= 64) {
       fast_sync = true; sync_ok_streak = 0;
     }
   }
   int64_t iter_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // corrector iterations executed per converged attempt (diagnostic)
   void sync_ctrl() {
-    KIN_HIP(hipMemcpyAsync(hc, ctrl.p, sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
+    // (with a speculative step enqueued behind the awaited batch the device block has moved on by the time the stream
+    // is idle; the awaited batch's last launch has published its block to hc all the same)
+    if (!spec.enq) KIN_HIP(hipMemcpyAsync(hc, ctrl.p, sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
     auto t0 = std::chrono::steady_clock::now();
     KIN_HIP(hipStreamSynchronize(s));
     sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -259,6 +269,7 @@ struct Solver {
   // (re)start the integrator at time t0 from the state in y (reinit! semantics: order 1, fresh
   // initial step, fresh Jacobian). Returns false when f(y0) is not finite.
   bool restart(double t0, double t_bound) {
+    spec = Spec{};
     flush_accept();
     t = t0;
     st.n_restarts++;
@@ -336,6 +347,7 @@ struct Solver {
   // ~1e-20 s first step, i.e. ~60 steps and ~20 factorisations per segment); results agree within
   // the solver tolerance. Opt-in (KIN_WARM_RESTART=1); the default re-initialises like the reference.
   void resume(bool rates_changed) {
+    spec = Spec{};
     t = 0.0;
     st.n_restarts++;
     flush_accept();
@@ -394,7 +406,10 @@ struct Solver {
   bool slot_is_fresh = false;
   // `last`: the batch's last launch publishes the control block even when nothing is decided yet (seq = the number the
   // host waits for; the launch that decides publishes it itself - there is no separate error-estimate launch)
-  void newton_iteration(int it, double c, unsigned long long seq, bool last) {
+  // `spec_it`: an iteration of a speculatively enqueued step - the carried rate comes from the device's control block (the
+  // host does not know yet what the step before leaves there), it counts as fresh (enqueue_speculative checked that it will
+  // be whatever that step does)
+  void newton_iteration(int it, double c, unsigned long long seq, bool last, bool spec_it = false) {
     const int* skip = &ctrl.p->newton_done;
     SparseLU::Slot& q = lu.slots[cur_slot];
     SegExtra ex;
@@ -407,7 +422,8 @@ struct Solver {
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
     const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
     const double rate_max = (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0;
-    const double crate0 = carry_rate ? q.crate : 1.0, tol_first = crate_fresh(q) ? newton_tol : -1.0;
+    const double crate0 = carry_rate ? q.crate : 1.0, tol_first = ((spec_it && carry_rate) || crate_fresh(q)) ? newton_tol : -1.0;
+    const bool from_ctrl = spec_it && carry_rate;
     if (fuse_newton) {
       // the solve's last gather stage and the corrector update in one launch
       NewtonFuse f;
@@ -416,16 +432,55 @@ struct Solver {
       f.upd = upd; f.atol = atol; f.rtol = rtol;
       f.ec = cf.error_const[order]; f.ec_m = order > 1 ? cf.error_const[order - 1] : 0.0; f.ec_p = cf.error_const[order + 1];
       f.iter = it; f.maxit = BDF_NEWTON_MAXITER; f.tol = newton_tol; f.rate_max = rate_max; f.crate0 = crate0;
-      f.tol_first = tol_first; f.dy_first_max = crate_dy_max;
-      f.ctrl = ctrl.p; f.part = red.p; f.host_ctrl = hc_dev; f.host_seq = hseq_dev; f.seq = seq; f.publish_always = last ? 1 : 0;
+      f.tol_first = tol_first; f.dy_first_max = crate_dy_max; f.crate_from_ctrl = from_ctrl ? 1 : 0; f.ban_negatives = ban_negatives ? 1 : 0;
+      f.ctrl = ctrl.p; f.part = red.p; f.host_ctrl = hc_dev_at(seq); f.host_seq = hseq_dev; f.seq = seq; f.publish_always = last ? 1 : 0;
       lu.solve_newton(cur_slot, f, s);
     } else {
       lu.solve(skip, cur_slot, s);
       launch_bdf_newton(N, it, BDF_NEWTON_MAXITER, newton_tol, lu.xloc.p, q.W.p, scale.p, y.p, d.p, upd, rate_max, crate0, tol_first,
-                        crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p, hc_dev, hseq_dev, seq, last, s);
+                        crate_dy_max, order, D.p, atol, rtol, cf, ctrl.p, red.p, hc_dev_at(seq), hseq_dev, seq, last, s, from_ctrl, ban_negatives);
     }
-    st.n_rhs++; st.n_linsolve++;
   }
+
+  // ---- Speculative enqueue of the next step (KIN_SPECULATE=0 switches it off). The quasi-constant-step BDF keeps step size
+  // and order for order + 1 steps, so after most steps the next one is fully known in advance IF this one is accepted: its
+  // accept + predictor launch and its first corrector batch are enqueued right behind this step's batch, before the host has
+  // seen this step's result. The deciding corrector launch writes `spec_go` (1 = accepted, by the host's own rule); the
+  // speculative predictor does nothing unless it reads 1, and then the iterations behind it stay no-ops as well. The host
+  // takes the batch up when it enters the next step (same arithmetic, bit-identical results) - the device no longer idles
+  // for the hand-over, the host's decision and the launch latency of the next predictor (~8-10 us of ~100 per step).
+  bool speculate = true;
+  struct Spec {
+    bool enq = false;      // a speculative batch sits behind the batch being waited for
+    bool alive = false;    // ... and the device ran it: step() takes it up instead of enqueueing
+    unsigned long long seq = 0;
+    double t_new = 0.0, hh = 0.0, c = 0.0;
+    int slot = -1, blind = 0, order = 0;
+  } spec;
+  int64_t n_spec = 0, n_spec_dead = 0;   // speculative batches taken up / enqueued for nothing (KIN_TIMING=1)
+  // called right after the blind batch of an attempt that ends at t_new (step size h_abs, order, slot cur_slot) is enqueued
+  void enqueue_speculative(double t_new, double t_bound, int blind) {
+    if (!speculate || !fast_sync || pre_attempt || trace || inject_bad_pivot_at >= 0 || lu_band <= 0.0 || cache_suspended) return;
+    if (n_equal >= order) return;                      // the step after this one may change order / step size
+    if (iters_left < 1) return;
+    const double t2 = t_new + h_abs;
+    if (t2 - t_bound > 0.0) return;                    // would be cut at the segment end
+    if (h_abs < std::max(dtmin, 10.0 * (std::nextafter(t_new, INF) - t_new))) return;
+    const double hh2 = t2 - t_new, c2 = hh2 / cf.alpha[order];
+    if (nearest_slot(c2) != cur_slot) return;          // (the slot can only drop out by the rule that also clears spec_go)
+    const SparseLU::Slot& q = lu.slots[cur_slot];
+    // the carried rate must count as fresh in the next step whether or not this one measures it anew
+    if (carry_rate && !(q.crate < 1.0 && q.crate_restart == st.n_restarts && (st.n_steps + 1) - q.crate_step <= crate_max_age)) return;
+    spec.enq = true; spec.alive = false;
+    spec.t_new = t2; spec.hh = hh2; spec.c = c2; spec.slot = cur_slot; spec.blind = blind; spec.order = order;
+    spec.seq = ++seq_no;
+    launch_bdf_accept_predict(N, order, order, D.p, cf, atol, rtol, y.p, psi.p, d.p, scale.p, ctrl.p, nullptr, s, &ctrl.p->spec_go);
+    const bool keep = slot_is_fresh;
+    slot_is_fresh = q.c_fact == c2;
+    for (int b = 0; b < blind; b++) newton_iteration(b, c2, spec.seq, b == blind - 1, true);
+    slot_is_fresh = keep;
+  }
+  void drop_speculation() { if (spec.enq || spec.alive) n_spec_dead++; spec.enq = false; spec.alive = false; }
 
   void invalidate_lu_keep_counters() {
     for (auto& q : lu.slots) q.valid = false;
@@ -519,7 +574,8 @@ struct Solver {
       rhs(rk_ynew.p, rk_K.p + (size_t)6 * N);
       RkVec e;
       for (int j = 0; j < 7; j++) e.v[j] = hh * E[j];
-      launch_rk_error(N, e, D.p, rk_ynew.p, rk_K.p, atol, rtol, ctrl.p, red.p, hc_dev, hseq_dev, ++seq_no, s);
+      ++seq_no;
+      launch_rk_error(N, e, D.p, rk_ynew.p, rk_K.p, atol, rtol, ctrl.p, red.p, hc_dev_at(seq_no), hseq_dev, seq_no, s);
       wait_ctrl(seq_no);
       if (hc->nonfinite) {
         // SciPy would propagate the NaN; here a non-finite stage is treated like a failed step (halve)
@@ -561,6 +617,9 @@ struct Solver {
     }
     bool accepted = false, first_attempt = true;
     double safety = 0.9, err_norm = 0.0, t_new = t;
+    // this step's first batch is on the device already (enqueued speculatively behind the previous step's)
+    bool take_up = spec.alive;
+    spec.alive = false; spec.enq = false;
     while (!accepted) {
       if (iters_left-- <= 0) return STEP_OK;  // caller checks iters_left < 0 -> MaxIters
       const double min_step = std::max(dtmin, 10.0 * (std::nextafter(t, INF) - t));
@@ -584,6 +643,8 @@ struct Solver {
       const double hh = t_new - t;
       h_abs = std::fabs(hh);
       const double c = hh / cf.alpha[order];
+      if (take_up && !(t_new == spec.t_new && hh == spec.hh && c == spec.c && order == spec.order))
+        throw KinError(ERR_STATE, "speculative step does not match the step the host arrived at");
       if (pre_attempt) pre_attempt(t_new);
       bool converged = false;
       if (attempt_no++ == inject_bad_pivot_at) KIN_HIP(hipMemsetAsync(&ctrl.p->lu_bad, 1, sizeof(int), s));
@@ -599,6 +660,8 @@ struct Solver {
       const double lu_band = cache_suspended ? 0.0 : this->lu_band;   // shadows the member for this attempt
       if (lu_band > 0.0) {
         const int hit = nearest_slot(c);
+        if (take_up && (hit != spec.slot || force_fresh_lu))
+          throw KinError(ERR_STATE, "speculative step ran on another factorisation than the host would choose");
         if (hit >= 0 && !force_fresh_lu) { cur_slot = hit; lu.slots[hit].last_use = ++use_clock; st.n_lu_reused++; }
         else {
           if (force_fresh_lu && !jac_current && steps_since_jac > 20) {   // an old Jacobian is refreshed on the way
@@ -618,21 +681,35 @@ struct Solver {
       for (;;) {
         // a matrix made in this attempt for this c counts as fresh even when the Jacobian behind it is a few steps old
         slot_is_fresh = fresh || lu.slots[cur_slot].c_fact == c;
-        predict();
         // Blind depth: two iterations are enqueued ahead of the decision, one when this factorisation converged the previous
         // step in its first iteration (the carried rate makes that the common case; the second launch chain would be
         // six no-ops). Whatever is not decided when the host looks gets up to two more iterations per hand-over.
         int it = 0;
-        const int blind = (last_iters == 1 && last_iter_slot == cur_slot && crate_fresh(lu.slots[cur_slot])) ? 1 : 2;
-        ++seq_no;
-        for (int b = 0; b < blind; b++, it++) newton_iteration(it, c, seq_no, b == blind - 1);
-        wait_ctrl(seq_no);
+        int blind = (last_iters == 1 && last_iter_slot == cur_slot && crate_fresh(lu.slots[cur_slot])) ? 1 : 2;
+        unsigned long long batch_seq;
+        if (take_up) {          // predictor and `blind` iterations of this attempt are running already
+          take_up = false;
+          blind = spec.blind; it = blind; batch_seq = spec.seq;
+          n_spec++;
+        } else {
+          predict();
+          batch_seq = ++seq_no;
+          for (int b = 0; b < blind; b++, it++) newton_iteration(it, c, batch_seq, b == blind - 1);
+        }
+        enqueue_speculative(t_new, t_bound, blind);
+        wait_ctrl(batch_seq);
         while (!hc->newton_done && it < BDF_NEWTON_MAXITER) {
+          if (spec.enq) {       // undecided: the speculative batch behind has ended itself and left newton_done raised
+            KIN_HIP(hipMemsetAsync(&ctrl.p->newton_done, 0, sizeof(int), s));
+            drop_speculation();
+          }
           const int more = std::min(2, BDF_NEWTON_MAXITER - it);
           ++seq_no;
           for (int b = 0; b < more; b++, it++) newton_iteration(it, c, seq_no, b == more - 1);
           wait_ctrl(seq_no);
         }
+        if (spec.enq && !(hc->newton_done && hc->spec_go)) drop_speculation();   // the device did not run it either
+        st.n_rhs += hc->n_iter; st.n_linsolve += hc->n_iter;   // iterations the device executed (blind launches behind the decision are no-ops)
         if (hc->n_iter > 1) {        // a rate was measured in this attempt
           SparseLU::Slot& q = lu.slots[cur_slot];
           q.crate = hc->crate; q.crate_step = st.n_steps; q.crate_restart = st.n_restarts;
@@ -713,7 +790,12 @@ struct Solver {
     fail_score = std::max(0.0, fail_score - 0.2);
     n_equal++;
     t = t_new;
-    accept_pending = true; accept_order = order; accept_copy = nullptr;   // rides in the next predictor launch
+    if (spec.enq) {   // the device has accepted this step and is computing the next one: nothing is pending
+      spec.alive = true; spec.enq = false;
+      accept_pending = false; accept_copy = nullptr;
+    } else {
+      accept_pending = true; accept_order = order; accept_copy = nullptr;   // rides in the next predictor launch
+    }
     jac_current = false;
     pending_order_change = (n_equal >= order + 1);
     if (pending_order_change) {
@@ -874,6 +956,7 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   S.st = kin_stats{};
   S.invalidate_lu();   // the LU cache lives within one solve: identical calls give identical results
   S.accept_pending = false; S.accept_copy = nullptr;   // nothing of an earlier call (its solution buffer may be gone)
+  S.spec = Solver::Spec{};
   S.explicit_mode = explicit_solver;
   S.sync_wait_s = 0.0;
   std::fill(S.iter_hist, S.iter_hist + 8, 0);
@@ -1110,6 +1193,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   if (getenv("KIN_TIMING"))
     fprintf(stderr, "[kin_solve] corrector iterations per converged attempt: 1:%lld 2:%lld 3:%lld 4:%lld\n", (long long)S.iter_hist[1],
             (long long)S.iter_hist[2], (long long)S.iter_hist[3], (long long)S.iter_hist[4]);
+  if (getenv("KIN_TIMING"))
+    fprintf(stderr, "[kin_solve] speculatively enqueued steps taken up: %lld of %lld steps, enqueued for nothing: %lld\n",
+            (long long)S.n_spec, (long long)S.st.n_steps, (long long)S.n_spec_dead);
   if (stats) *stats = S.st;
   return retcode;
 }
@@ -1178,6 +1264,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
   S.st = kin_stats{};
   S.invalidate_lu();
   S.accept_pending = false; S.accept_copy = nullptr;
+  S.spec = Solver::Spec{};
   S.explicit_mode = false;
   S.ban_negatives = p.ban_negatives != 0;
   S.dtmin = resolve_dtmin(p);

@@ -622,13 +622,15 @@ __device__ __forceinline__ void newton_totals(const double* part, int G, double 
 struct NewtonDecide {
   int N, iter, maxit;
   double tol, rate_max, crate0, tol_first, dy_first_max;
+  int crate_from_ctrl, ban_negatives;
   BdfCtrl* ctrl; const double* tot;   // tot[5]: the launch's sums (update, error test of order / -1 / +1, negative entries)
   BdfCtrl* host_ctrl; unsigned long long* host_seq; unsigned long long seq; int publish_always;
 };
 __device__ __forceinline__ void newton_decide(const NewtonDecide& a) {
   const int N = a.N, iter = a.iter, maxit = a.maxit, publish_always = a.publish_always;
-  const double tol = a.tol, rate_max = a.rate_max, crate0 = a.crate0, tol_first = a.tol_first, dy_first_max = a.dy_first_max;
+  const double tol = a.tol, rate_max = a.rate_max, tol_first = a.tol_first, dy_first_max = a.dy_first_max;
   BdfCtrl* ctrl = a.ctrl; BdfCtrl* host_ctrl = a.host_ctrl;
+  const double crate0 = (a.crate_from_ctrl && iter == 0) ? ctrl->crate : a.crate0;
   unsigned long long* host_seq = a.host_seq; const unsigned long long seq = a.seq;
   {
     const double tot = a.tot[0];
@@ -673,6 +675,10 @@ __device__ __forceinline__ void newton_decide(const NewtonDecide& a) {
     }
     ctrl->converged = converged ? 1 : 0;
     ctrl->newton_done = done ? 1 : 0;
+    // the verdict the host will reach from the same numbers (solver.cpp, step()): an accepted step with nothing that makes
+    // the next one more than a continuation (every allowed iteration used = the host may drop the factorisation)
+    ctrl->spec_go = (done && converged && !ctrl->nonfinite && !ctrl->lu_bad && !(a.ban_negatives && ctrl->any_negative) &&
+                     !(ctrl->err_norm > 1.0) && iter + 1 < maxit) ? 1 : 0;
     if ((done || publish_always) && host_ctrl) {
       *host_ctrl = *ctrl;
       __threadfence_system();
@@ -695,7 +701,8 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
                                                          double rate_max, double crate0, double tol_first, double dy_first_max,
                                                          int order, const double* __restrict__ D, double atol, double rtol, BdfCoef cf,
                                                          BdfCtrl* ctrl, double* __restrict__ part, BdfCtrl* host_ctrl,
-                                                         unsigned long long* host_seq, unsigned long long seq, int publish_always) {
+                                                         unsigned long long* host_seq, unsigned long long seq, int publish_always,
+                                                         int crate_from_ctrl, int ban_negatives) {
   __shared__ double sh[20];
   __shared__ int last;
   if (ctrl->newton_done) return;
@@ -755,8 +762,8 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
   double tot[5];
   newton_totals(part, G, tot);
   if (threadIdx.x == 0)
-    newton_decide(NewtonDecide{N, iter, maxit, tol, rate_max, crate0, tol_first, dy_first_max, ctrl, tot, host_ctrl, host_seq, seq,
-                               publish_always});
+    newton_decide(NewtonDecide{N, iter, maxit, tol, rate_max, crate0, tol_first, dy_first_max, crate_from_ctrl, ban_negatives, ctrl, tot,
+                               host_ctrl, host_seq, seq, publish_always});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -886,8 +893,8 @@ __global__ __launch_bounds__(SEG_WG) void stagec_newton_kernel(SegPlanView p, do
   double tot[5];
   newton_totals(f.part, G, tot);
   if (threadIdx.x == 0)
-    newton_decide(NewtonDecide{f.N, f.iter, f.maxit, f.tol, f.rate_max, f.crate0, f.tol_first, f.dy_first_max, f.ctrl, tot,
-                               f.host_ctrl, f.host_seq, f.seq, f.publish_always});
+    newton_decide(NewtonDecide{f.N, f.iter, f.maxit, f.tol, f.rate_max, f.crate0, f.tol_first, f.dy_first_max, f.crate_from_ctrl,
+                               f.ban_negatives, f.ctrl, tot, f.host_ctrl, f.host_seq, f.seq, f.publish_always});
 }
 
 static bool stagec_big_wg(const SegPlanView& p) {
@@ -927,8 +934,15 @@ __global__ __launch_bounds__(256) void bdf_accept_predict_kernel(int N, int ao, 
                                                                  double atol, double rtol, double* __restrict__ y,
                                                                  double* __restrict__ psi, double* __restrict__ d,
                                                                  double* __restrict__ scale, BdfCtrl* ctrl,
-                                                                 double* __restrict__ copy_out) {
+                                                                 double* __restrict__ copy_out, const int* go) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // A speculatively enqueued step (go = &ctrl->spec_go): when the step before it did not end the way the host assumed, this
+  // launch leaves everything alone and makes sure the iterations behind it stay no-ops (newton_done is 1 already unless the
+  // batch before ended undecided; nothing in this launch writes spec_go, so every workgroup reads the same value).
+  if (go && !*go) {
+    if (i == 0) ctrl->newton_done = 1;
+    return;
+  }
   if (i == 0) {
     ctrl->newton_done = 0; ctrl->converged = 0; ctrl->n_iter = 0; ctrl->nonfinite = 0; ctrl->any_negative = 0; ctrl->ticket = 0;
     ctrl->dy_norm_old = 0.0; ctrl->dy_norm = 0.0; ctrl->err_norm = 0.0; ctrl->err_m_norm = 0.0; ctrl->err_p_norm = 0.0;
@@ -1144,13 +1158,15 @@ int bdf_reduce_slot() { return RED_SLOT; }
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
                        double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max,
                        int order, const double* D, double atol, double rtol, const BdfCoef& cf, BdfCtrl* ctrl, double* part,
-                       BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s) {
+                       BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s,
+                       bool crate_from_ctrl, bool ban_negatives) {
   hipLaunchKernelGGL(bdf_newton_kernel, dim3(bdf_reduce_blocks(N)), dim3(256), 0, s, N, iter, maxit, tol, xloc, W, scale, y, d, upd, rate_max,
-                     crate0, tol_first, dy_first_max, order, D, atol, rtol, cf, ctrl, part, host_ctrl, host_seq, seq, publish_always ? 1 : 0);
+                     crate0, tol_first, dy_first_max, order, D, atol, rtol, cf, ctrl, part, host_ctrl, host_seq, seq, publish_always ? 1 : 0,
+                     crate_from_ctrl ? 1 : 0, ban_negatives ? 1 : 0);
 }
 void launch_bdf_accept_predict(int N, int ao, int order, double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
-                               double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s) {
-  hipLaunchKernelGGL(bdf_accept_predict_kernel, GRID1(N), 0, s, N, ao, order, D, cf, atol, rtol, y, psi, d, scale, ctrl, copy_out);
+                               double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s, const int* go) {
+  hipLaunchKernelGGL(bdf_accept_predict_kernel, GRID1(N), 0, s, N, ao, order, D, cf, atol, rtol, y, psi, d, scale, ctrl, copy_out, go);
 }
 void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s) {
   hipLaunchKernelGGL(bdf_accept_kernel, GRID1(N), 0, s, N, order, D, d, copy_out);

@@ -27,7 +27,8 @@ struct BdfCtrl {
   int newton_done, converged, n_iter, nonfinite, any_negative;
   int ticket;   // arrival counter of the multi-workgroup reductions (back to 0 when a launch ends)
   int lu_bad;   // set by a factorisation that met a vanishing pivot (|multiplier| > 1e8); cleared by the host, NOT by the predictor
-  int pad_;
+  int spec_go;  // written by every corrector decision: 1 = the attempt ended as an accepted step (what the host will conclude
+                // from the same numbers), so a speculatively enqueued next step may run (solver.cpp: speculation)
 };
 
 // LU cache: per-slot copies of diag(J) and the drift test of Solver::restart (at most LU_MAX_SLOTS slots)
@@ -50,6 +51,7 @@ struct NewtonFuse {
   double upd, atol, rtol, ec, ec_m, ec_p;   // error constants of order, order - 1, order + 1
   int iter, maxit;
   double tol, rate_max, crate0, tol_first, dy_first_max;
+  int crate_from_ctrl, ban_negatives;   // see launch_bdf_newton
   BdfCtrl* ctrl; double* part; BdfCtrl* host_ctrl; unsigned long long* host_seq; unsigned long long seq; int publish_always;
 };
 struct SegPlanView;
@@ -63,14 +65,18 @@ void launch_stagec_newton(const SegPlanView& p, double* W, const NewtonFuse& f, 
 void launch_bdf_newton(int N, int iter, int maxit, double tol, const int32_t* xloc, const double* W, const double* scale,
                        double* y, double* d, double upd, double rate_max, double crate0, double tol_first, double dy_first_max,
                        int order, const double* D, double atol, double rtol, const BdfCoef& cf, BdfCtrl* ctrl, double* part,
-                       BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s);
+                       BdfCtrl* host_ctrl, unsigned long long* host_seq, unsigned long long seq, bool publish_always, hipStream_t s,
+                       bool crate_from_ctrl = false, bool ban_negatives = false);
+// crate_from_ctrl: iteration 0 takes the carried rate from ctrl->crate (what the previous step left there) instead of
+// crate0 - a speculatively enqueued step cannot know it on the host; ban_negatives: part of the `spec_go` verdict.
 // `part`: bdf_reduce_slot() * bdf_reduce_blocks(N) doubles of partial sums
 int bdf_reduce_slot();   // doubles per workgroup in the `part` buffer of the corrector launches
 int bdf_reduce_blocks(int N);
 void launch_bdf_accept(int N, int order, double* D, const double* d, double* copy_out, hipStream_t s);   // copy_out (optional): the new state
 // accept of the previous step (order `ao`) + predictor of the next one in one pass (the host defers the accept)
 void launch_bdf_accept_predict(int N, int ao, int order, double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
-                               double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s);
+                               double* d, double* scale, BdfCtrl* ctrl, double* copy_out, hipStream_t s, const int* go = nullptr);
+// `go` (optional device flag): the launch does nothing but end the batch behind it (newton_done = 1) when *go == 0
 void launch_bdf_change_D(int N, int order, const BdfMat& ru, double* D, hipStream_t s);
 void launch_bdf_init_D(int N, int nrows, const double* y0, const double* f0, double h, double* D, hipStream_t s);
 void launch_bdf_interp(int N, int order, const double* D, const BdfVec& p, double* out, hipStream_t s);

@@ -194,6 +194,53 @@ def test_corrector_update_fused_into_the_solve_and_separate(n, r, chunks, monkey
     assert abs(st1["n_steps"] - st0["n_steps"]) <= max(3, 0.03 * st0["n_steps"])
 
 
+def test_speculative_enqueue_of_the_next_step_changes_nothing(monkeypatch):
+    """The next step's predictor and first corrector batch are enqueued behind the current step's batch, before the host
+    knows how it ended (solver.cpp: enqueue_speculative; KIN_SPECULATE=0 switches it off): same arithmetic on the device,
+    so every mode of the driver must return bit-identical results and counters - chunkwise on a save grid, every step
+    saved, one integration over the whole span, rate updates at tstops, negative states banned, manual stepping."""
+    net, Ea, A = synthetic_crn(300, 1500)
+    u0 = np.zeros(300); u0[0] = 1.0
+    tst = np.arange(0, 9) * 1e-3
+    Tst = 900.0 + 2.0e4 * tst
+
+    def run_all():
+        out = []
+        h = capi.HipNetwork.from_flat(net)
+        h.set_arrhenius(Ea, A, k_max=1e12)
+        h.rates_at(1000.0)
+        whole = kp((0.0, 3e-3), False, 1e-3, 5e-4)
+        whole.dtmin = 1e-30          # (the first step after a restart is below the reference's eps(tspan[end]), DESIGN 4.1)
+        for pars in (kp((0.0, 4e-3), True, 1e-3, 2.5e-4), kp((0.0, 2e-3), True, 1e-3), whole, kp((0.0, 2e-3), True, 1e-3, 5e-4, ban=True)):
+            t, u, rc, st, _ = h.solve(pars, u0)
+            out.append((t, u, rc, st["n_steps"], st["n_rejected"], st["n_factor"], st["n_linsolve"], st["n_newton_fail"]))
+        t, u, rc, st, _ = h.solve(kp((0.0, 8e-3), True, 2e-3, 1e-3), u0, tstops=tst, T_stops=Tst)
+        out.append((t, u, rc, st["n_steps"], st["n_rejected"], st["n_factor"], st["n_linsolve"], st["n_restarts"]))
+        h.rates_at(1000.0)
+        manual = kp((0.0, 2e-3), False)
+        manual.dtmin = 1e-30
+        h.integrator_init(manual, u0)
+        seen = []
+        for n in (1, 3, 50, 0):
+            h.integrator_step(n)
+            ti, ui, rci, sti = h.integrator_state()
+            seen.append((ti, ui.copy(), rci, sti["n_steps"]))
+        out.append(seen)
+        h.close()
+        return out
+
+    monkeypatch.setenv("KIN_SPECULATE", "0")
+    ref = run_all()
+    monkeypatch.setenv("KIN_SPECULATE", "1")
+    got = run_all()
+    for a, b in zip(ref[:-1], got[:-1]):
+        assert a[2] == 0 and b[2] == 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[3:] == b[3:]
+    for (ta, ua, ra, na), (tb, ub, rb, nb) in zip(ref[-1], got[-1]):
+        assert ta == tb and ra == rb and na == nb and np.array_equal(ua, ub)
+
+
 def test_failure_and_retry_semantics():
     net = from_lists(3, [[(0, 1)], [(1, 2)], [(1, 1), (2, 1)]], [[(1, 1)], [(1, 1), (2, 1)], [(0, 1), (2, 1)]])
     h = capi.HipNetwork.from_flat(net)
