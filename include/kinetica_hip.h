@@ -174,6 +174,8 @@ typedef struct kin_params {
 
 typedef struct kin_stats {
   int64_t n_steps, n_rejected, n_rhs, n_jac, n_factor, n_linsolve, n_newton_fail;
+  /* n_rhs / n_linsolve: corrector iterations the device executed (launches enqueued ahead of a decision that turn into
+   * no-ops are not counted), plus the right-hand sides of restarts */
   int64_t n_chunks, n_restarts, n_retries;
   double final_abstol, final_reltol; /* what update_tols writes back (solve_utils.jl:397-401) */
   double wall_seconds;
