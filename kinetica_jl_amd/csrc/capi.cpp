@@ -27,6 +27,7 @@ void kin_network::rhs_dev(const double* d_u, double* d_du) {
 }
 
 void kin_network::sweep_dev(int64_t B, const double* d_u, const double* d_k, double* d_du, hipStream_t s) {
+  if (!d_k) flush_pending_T(s);   // the handle's own k is about to be read: a temperature still pending is formed first
   if (host.N >= 65535) {
     // the packed sweep records hold species ids in 16 bits; wider networks take the single-state kernels
     // (32-bit ids) state after state on the same stream - correct at any size, one state per launch pair
@@ -432,6 +433,7 @@ int kin_rhs_block_dev(kin_network* h, int64_t r_lo, int64_t r_hi, const double* 
   require(h->has_rates, ERR_STATE, "rates were never set");
   require(0 <= r_lo && r_lo <= r_hi && r_hi <= h->host.R, ERR_INVALID_ARG, "reaction block out of range");
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  h->flush_pending_T(s);
   // rates of the block, zeros elsewhere; the species-major gather then sums exactly this block's contributions
   KIN_HIP(hipMemsetAsync(h->rate.p, 0, (size_t)h->host.R * sizeof(double), s));
   launch_rates(r_hi - r_lo, h->k.p + r_lo, d_u, h->x0.p + r_lo, h->x1.p + r_lo, h->rate.p + r_lo, s);

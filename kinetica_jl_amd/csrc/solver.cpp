@@ -450,6 +450,7 @@ struct Solver {
   // takes the batch up when it enters the next step (same arithmetic, bit-identical results) - the device no longer idles
   // for the hand-over, the host's decision and the launch latency of the next predictor (~8-10 us of ~100 per step).
   bool speculate = true;
+  bool hold_speculation = false;   // set by integrator_step for the LAST step of a call: nothing half-run may outlive the call
   struct Spec {
     bool enq = false;      // a speculative batch sits behind the batch being waited for
     bool alive = false;    // ... and the device ran it: step() takes it up instead of enqueueing
@@ -460,7 +461,7 @@ struct Solver {
   int64_t n_spec = 0, n_spec_dead = 0;   // speculative batches taken up / enqueued for nothing (KIN_TIMING=1)
   // called right after the blind batch of an attempt that ends at t_new (step size h_abs, order, slot cur_slot) is enqueued
   void enqueue_speculative(double t_new, double t_bound, int blind) {
-    if (!speculate || !fast_sync || pre_attempt || trace || inject_bad_pivot_at >= 0 || lu_band <= 0.0 || cache_suspended) return;
+    if (!speculate || hold_speculation || !fast_sync || pre_attempt || trace || inject_bad_pivot_at >= 0 || lu_band <= 0.0 || cache_suspended) return;
     if (n_equal >= order) return;                      // the step after this one may change order / step size
     if (iters_left < 1) return;
     const double t2 = t_new + h_abs;
@@ -643,8 +644,11 @@ struct Solver {
       const double hh = t_new - t;
       h_abs = std::fabs(hh);
       const double c = hh / cf.alpha[order];
-      if (take_up && !(t_new == spec.t_new && hh == spec.hh && c == spec.c && order == spec.order))
-        throw KinError(ERR_STATE, "speculative step does not match the step the host arrived at");
+      // the speculative batch ran for another step than the one the host arrived at (cannot happen by the rules of
+      // enqueue_speculative; kept as a recovery, not a throw): the device HAS accepted the previous step, so D is current
+      // and nothing is pending - the normal path below re-runs the predictor (which clears the control block) and
+      // enqueues a batch of its own; what the speculative iterations left in y / d is rebuilt by that predictor
+      if (take_up && !(t_new == spec.t_new && hh == spec.hh && c == spec.c && order == spec.order)) { take_up = false; n_spec_dead++; }
       if (pre_attempt) pre_attempt(t_new);
       bool converged = false;
       if (attempt_no++ == inject_bad_pivot_at) KIN_HIP(hipMemsetAsync(&ctrl.p->lu_bad, 1, sizeof(int), s));
@@ -660,8 +664,7 @@ struct Solver {
       const double lu_band = cache_suspended ? 0.0 : this->lu_band;   // shadows the member for this attempt
       if (lu_band > 0.0) {
         const int hit = nearest_slot(c);
-        if (take_up && (hit != spec.slot || force_fresh_lu))
-          throw KinError(ERR_STATE, "speculative step ran on another factorisation than the host would choose");
+        if (take_up && (hit != spec.slot || force_fresh_lu)) { take_up = false; n_spec_dead++; }   // same recovery
         if (hit >= 0 && !force_fresh_lu) { cur_slot = hit; lu.slots[hit].last_use = ++use_clock; st.n_lu_reused++; }
         else {
           if (force_fresh_lu && !jac_current && steps_since_jac > 20) {   // an old Jacobian is refreshed on the way
@@ -953,6 +956,17 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   if (!h->solver) h->solver.reset(new Solver(h));
   Solver& S = *h->solver;
   hipStream_t s = h->stream;
+  // whatever way this call ends (a throw included): no temperature stays pending on the handle (kin_rhs / kin_jac and the
+  // batched sweeps would otherwise see rate constants of different temperatures), the hook that captures this call's
+  // locals is gone, and no speculative batch is left half-taken-up
+  struct ExitGuard {
+    kin_network* h; Solver& S;
+    ~ExitGuard() {
+      S.pre_attempt = nullptr;
+      S.spec = Solver::Spec{};
+      if (h->k_pending) { try { h->flush_pending_T(h->stream); } catch (...) { h->k_pending = false; } }
+    }
+  } exit_guard{h, S};
   S.st = kin_stats{};
   S.invalidate_lu();   // the LU cache lives within one solve: identical calls give identical results
   S.accept_pending = false; S.accept_copy = nullptr;   // nothing of an earlier call (its solution buffer may be gone)
@@ -1308,7 +1322,13 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
   // solve_entry (the integrator's span starts at global time t_loc0, its segments run in local time)
   if (!I.t_nodes.empty())
     S.pre_attempt = [h, &I](double tau) { h->set_pending_T(I.T_of(I.t_seg + tau)); };
-  struct ClearHook { Solver& S; ~ClearHook() { S.pre_attempt = nullptr; } } clear_hook{S};
+  struct ClearHook {
+    kin_network* h; Solver& S;
+    ~ClearHook() {
+      S.pre_attempt = nullptr; S.hold_speculation = false;
+      if (h->k_pending) { try { h->flush_pending_T(h->stream); } catch (...) { h->k_pending = false; } }
+    }
+  } clear_hook{h, S};
   while (I.retcode == KIN_RETCODE_SUCCESS && I.t_seg < I.t_loc1 && (max_steps <= 0 || taken < max_steps)) {
     if (!I.in_segment) {
       I.seg_end = I.t_loc1;
@@ -1319,6 +1339,9 @@ int64_t integrator_step(kin_network* h, int64_t max_steps) {
       I.in_segment = true;
     }
     const double seg_len = I.seg_end - I.t_seg;
+    // the last step of this call gets no speculative batch behind it: other entry points on the handle (kin_set_rates,
+    // kin_rates_at, kin_newton_solve) may run before the next call and must not find a half-run step
+    S.hold_speculation = max_steps > 0 && taken + 1 >= max_steps;
     StepStatus ss = S.step(seg_len);
     if (S.iters_left < 0) { I.retcode = KIN_RETCODE_MAXITERS; S.flush_accept(); break; }
     if (ss == STEP_DT_MIN) { I.retcode = KIN_RETCODE_DTLESSTHANMIN; S.flush_accept(); break; }
@@ -1366,6 +1389,8 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
   Solver& S = *h->solver;
   hipStream_t s = h->stream;
   const int N = S.N;
+  S.flush_accept();
+  S.spec = Solver::Spec{};
   S.y.upload(u, N, s);
   S.eval_jac(S.y.p);
   S.lu.factor(c, S.jv.p, 0, &S.ctrl.p->lu_bad, s);

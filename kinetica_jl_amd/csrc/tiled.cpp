@@ -96,7 +96,11 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
     if (h_force > 0) cands.push_back(h_force);
     else for (int pc = 30; pc <= 85; pc += 5) cands.push_back((int32_t)((int64_t)E_cap * pc / 100));
     for (int32_t hc : cands) {
-      const int32_t wc = E_cap - hc - TILED_DUMMY - L.n_copy;
+      // the windows start at an EVEN label (wbase below is rounded up) and the label space ends at an even E: the window
+      // capacity is what is left behind the rounded base, rounded down - a completely full window still ends at E <= E_cap
+      int32_t wb_c = hc + TILED_DUMMY + L.n_copy;
+      wb_c += wb_c & 1;
+      const int32_t wc = ((E_cap & ~1) - wb_c) & ~1;
       if (wc < 64) continue;
       UnionFind uf(N);
       for (const Rec& q : recs) {
@@ -197,6 +201,7 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   L.E = L.wbase + wmax;
   L.E += L.E & 1;
   if (L.E > (1 << 14)) { L.why = "LDS label space exceeded"; return L; }
+  if (h < N && L.E > E_cap) { L.why = "internal: a window overflows the on-chip label space"; return L; }
 
   // ---- split hubs
   std::vector<int32_t> copy_rank(N, -1);

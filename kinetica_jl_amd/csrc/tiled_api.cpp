@@ -36,12 +36,18 @@ void ensure_tiled(kin_network* h) {
   if (!h->tiled.ok) throw KinError(ERR_UNSUPPORTED, "network has no tiled layout: " + h->tiled.why);
 }
 
-void ensure_params(kin_network* h, hipStream_t s) {
+// Per-record Arrhenius parameters in library order: rebuilt once per kin_set_arrhenius, on the HANDLE's stream and waited
+// for - consumers run on whatever stream the caller passes (the handle's own stream is non-blocking: nothing orders it
+// against them), so the table must be complete before the first of them is enqueued; the device-wide wait in front also
+// lets sweeps still reading the OLD table on other streams finish before it is overwritten.
+void ensure_params(kin_network* h, hipStream_t) {
   if (!h->has_arrhenius) throw KinError(ERR_STATE, "Arrhenius parameters were never set");
   if (h->t_par_valid) return;
   const TiledHost& L = h->tiled;
+  KIN_HIP(hipDeviceSynchronize());
   h->t_par.alloc((size_t)4 * std::max(1, L.P));
-  launch_tiled_params(L.P, h->t_kf.p, h->t_kr.p, h->Ea.p, h->A.p, h->has_kmax, h->t_mult, h->t_par.p, s);
+  launch_tiled_params(L.P, h->t_kf.p, h->t_kr.p, h->Ea.p, h->A.p, h->has_kmax, h->t_mult, h->t_par.p, h->stream);
+  KIN_HIP(hipStreamSynchronize(h->stream));
   h->t_par_valid = true;
 }
 

@@ -70,3 +70,16 @@ def test_c5_size_layout():
     assert L["BS"] == 1024 and L["T"] <= 12 and L["P"] == 125000
     # every window fits next to the hubs
     assert L["wbase"] + L["win_cnt"].max() <= L["E"] <= 10176
+
+
+@pytest.mark.parametrize("cap", [1399, 1400, 1401, 1402, 1405])
+@pytest.mark.parametrize("hubs", [0, 601, 602])
+def test_window_capacity_follows_the_rounded_window_base(monkeypatch, cap, hubs):
+    """the window capacity is what is left behind the EVEN window base - whatever the parities of the hub count, the
+    split-hub copies and the capacity, a full window ends inside the label space the launch sizes its LDS for."""
+    monkeypatch.setenv("KIN_TILED_ENTRIES", str(cap))
+    net, _, _ = synthetic_crn(3000, 15000)
+    L = capi.lib_layout_host(net, hubs)
+    assert L["T"] > 1
+    assert L["wbase"] % 2 == 0 and L["E"] % 2 == 0
+    assert L["wbase"] + int(L["win_cnt"].max()) <= L["E"] <= cap
