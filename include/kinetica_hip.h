@@ -122,6 +122,14 @@ int kin_lib_layout_host(int64_t n_species, int64_t n_reactions, const int64_t* r
                         const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
                         int index_base, int hubs, int64_t* info, int64_t* species_of_lib, int64_t* slot_of_reaction,
                         uint64_t* rec, int32_t* rowtab, int32_t* seg_q, int32_t* win_off, int32_t* win_cnt, int32_t* copy_src);
+/* Symbolic analysis of the Newton-matrix factorisation (I - c J; the reference's solver does this inside KLU,
+ * docs/src/getting-started.md:69) WITHOUT a device: sizes only. Arguments <= 0 take the library's defaults.
+ * info[0..11] = sparse pivots, dense block dimension, elimination rounds, nnz(U), nnz(L11^-1), nnz(U11^-1), nnz(L21 L11^-1),
+ * nnz(U11^-1 U12), doubles per factorisation, symbolic products of the fused solve, gather-plan entries, wavefront tasks. */
+int kin_lu_analyze_host(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr, const int64_t* reac_idx,
+                        const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
+                        int index_base, int hub_degree, int max_rounds, int max_tail_degree, int max_degree, int min_round,
+                        int64_t* info);
 /* Layout conversions on device buffers (each a coalesced write with a gather on the source side; enqueue only):
  * states u[b][N] caller order <-> library order, rate constants k[b][R] -> k_lib[b][k_len]. */
 int kin_states_to_lib_dev(kin_network* h, int64_t B, const double* d_in, double* d_out, void* stream);
@@ -203,6 +211,20 @@ typedef struct kin_stats {
 int kin_solve(kin_network* h, const kin_params* params, const double* u0,
               const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops,
               int64_t* n_saved, int32_t* retcode, kin_stats* stats);
+/* An ENSEMBLE of K independent trajectories of one network in ONE launch (the reference leaves ensembles to the user:
+ * docs/src/tutorials/ode-solution.md:190 solves member after member through solve_network, exploration/methods.jl:221).
+ * Every member is integrated by the same algorithm as kin_solve, resident on the GPU - one workgroup owns one
+ * trajectory from u0 to the end of the span - so a member's result is bit-identical to a K = 1 call with its inputs.
+ *   u0[K][N]; rate constants per member k[K][R], or temperatures T[K] (Arrhenius parameters of the handle), or neither
+ *   (the handle's current rates for all); discrete rate updates (tstops / T_stops / k_table as in kin_solve) are shared
+ *   by all members and exclude k / T. `params` needs a save grid (solve_chunks or save_interval).
+ * Outputs (any may be NULL): *n_rows = rows of the save grid; out_t[n_rows]; out_u[K][n_rows][N]; n_saved[K] rows a member
+ * actually wrote; retcodes[K] (KIN_RETCODE_*); stats[K]. A call with out_u == NULL and n_saved == NULL only reports *n_rows.
+ * Returns KIN_OK when the call ran, whatever the members' retcodes; KIN_ERR_UNSUPPORTED for networks beyond the resident
+ * integrator's size (dense Schur block > 1024): solve those member by member with kin_solve. */
+int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, const double* u0, const double* k, const double* T,
+                       const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* n_rows,
+                       double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats);
 /* Same call with an explicit integrator: `pars.solver` may be any SciML algorithm (params.jl:9); BASELINE config 2
  * exercises the RHS kernel with an explicit one. The pair is Dormand-Prince 5(4) with FSAL and 4th-order dense
  * output, step-size control as in SciPy's RK45 (which is the oracle, step for step); no Jacobian, no linear solve.
@@ -274,8 +296,9 @@ int kin_set_device(int device);
 const char* kin_version(void);
 /* Layout version of this header's structs and argument lists. A binding compares it (and, if it wants certainty, the
  * struct sizes) with the values it was written against before the first call: kin_params / kin_stats have grown between
- * versions (1: round 1; 2: + dtmin and the LU-cache counters; 3: + the library-order sweep entry points). */
-#define KIN_ABI_VERSION 3
+ * versions (1: round 1; 2: + dtmin and the LU-cache counters; 3: + the library-order sweep entry points; 4: + kin_solve_ensemble,
+ * kin_lu_analyze_host - structs unchanged). */
+#define KIN_ABI_VERSION 4
 int kin_abi_version(void);
 int64_t kin_struct_size(int which); /* 0: sizeof(kin_params), 1: sizeof(kin_stats), else -1 */
 

@@ -29,8 +29,9 @@ SYMBOLS = [
     "kin_solution_max_dev", "kin_rate_table_dev", "kin_rhs_block_dev",
     "kin_lib_layout", "kin_lib_layout_host", "kin_states_to_lib_dev", "kin_states_from_lib_dev", "kin_rates_to_lib_dev", "kin_rate_table_lib_dev",
     "kin_rhs_tiled_dev", "kin_rhs_batched_T_dev", "kin_abi_version", "kin_struct_size",
+    "kin_solve_ensemble", "kin_lu_analyze_host",
 ]
-ABI_VERSION = 3   # include/kinetica_hip.h: KIN_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # include/kinetica_hip.h: KIN_ABI_VERSION this binding was written against
 
 
 class KinParams(ctypes.Structure):
@@ -107,6 +108,8 @@ def lib():
                                 POINTER(KinStats)]
         L.kin_solve_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64, P64, POINTER(c_int32),
                                            POINTER(KinStats)]
+        L.kin_solve_ensemble.argtypes = [c_void_p, POINTER(KinParams), c_int64, PD, PD, PD, PD, PD, PD, c_int64, P64, PD, PD, P64,
+                                         POINTER(c_int32), POINTER(KinStats)]
         L.kin_integrator_init.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, PD, c_int64]
         L.kin_integrator_init_continuous.argtypes = [c_void_p, POINTER(KinParams), PD, PD, PD, c_int64]
         L.kin_integrator_step.argtypes = [c_void_p, c_int64, P64]
@@ -169,6 +172,22 @@ def lib_layout_host(net, hubs=0):
     assert st == KIN_OK
     return dict(h=h, T=T, P=P, E=E, n_copy=n_copy, BS=BS, wbase=wbase, Q=Q, species_of_lib=sp, slot_of_reaction=slot,
                 rec=rec[:P], rowtab=rowtab[:2 * Q].reshape(Q, 2), seg_q=seg_q, win_off=woff, win_cnt=wcnt, copy_src=copy_src[:n_copy])
+
+
+def lu_analyze_host(net, hub_degree=0, max_rounds=0, max_tail_degree=0, max_degree=0, min_round=0):
+    """Sizes of the symbolic Newton-matrix factorisation of a FlatNetwork, computed on the host (no device). Arguments left at 0
+    take the library's defaults (lu.hpp: LUOptions)."""
+    L = lib()
+    arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (net.reac_ptr, net.reac_idx, net.reac_sto, net.prod_ptr,
+                                                              net.prod_idx, net.prod_sto)]
+    L.kin_lu_analyze_host.argtypes = [c_int64, c_int64] + [POINTER(c_int64)] * 6 + [c_int] * 6 + [POINTER(c_int64)]
+    info = np.zeros(12, np.int64)
+    st = L.kin_lu_analyze_host(int(net.n_species), int(net.n_reactions), *[_p64(a) for a in arrs], 0, int(hub_degree), int(max_rounds),
+                               int(max_tail_degree), int(max_degree), int(min_round), _p64(info))
+    if st != KIN_OK:
+        raise KineticaHipError(st, "symbolic LU analysis failed")
+    keys = ("ns", "m", "rounds", "nnzU", "nnzZ", "nnzV", "nnzLZ", "nnzNVU", "w_size", "fused_products", "plan_entries", "plan_tasks")
+    return {k: int(v) for k, v in zip(keys, info)}
 
 
 def arrhenius_eval(Ea, A, T, k_max=None, t_mult=1.0):
@@ -346,6 +365,31 @@ class HipNetwork:
         if n_saved.value:
             self._chk(lib().kin_solution_copy(self._h, _pd(t), _pd(u)))
         return t, u, rc.value, stats.as_dict(), st
+
+    def solve_ensemble(self, params: KinParams, u0, k=None, T=None, tstops=None, T_stops=None, k_table=None):
+        """kin_solve_ensemble: K trajectories of this network in ONE launch (one workgroup per trajectory, resident on the GPU).
+        u0[K][N]; k[K][R] or T[K] (or neither: the handle's current rates); tstops / T_stops / k_table are shared by the members.
+        Returns (t[M], u[K][M][N], n_saved[K], retcodes[K], [stats dict] * K)."""
+        u0 = np.ascontiguousarray(np.atleast_2d(_f64(u0)))
+        K = u0.shape[0]
+        assert u0.shape == (K, self.n)
+        k = None if k is None else np.ascontiguousarray(_f64(k).reshape(K, self.nr))
+        T = None if T is None else np.ascontiguousarray(_f64(T).reshape(K))
+        n_stops = 0
+        if tstops is not None:
+            tstops = _f64(tstops); n_stops = len(tstops)
+            T_stops = None if T_stops is None else _f64(T_stops)
+            k_table = None if k_table is None else np.ascontiguousarray(_f64(k_table).reshape(n_stops, self.nr))
+        rows = c_int64(0)
+        fn = lib().kin_solve_ensemble
+        self._chk(fn(self._h, ctypes.byref(params), K, _pd(u0), _pd(k), _pd(T), _pd(tstops), _pd(T_stops), _pd(k_table), n_stops,
+                     ctypes.byref(rows), None, None, None, None, None))
+        M = rows.value
+        t = np.empty(M); u = np.empty((K, M, self.n)); ns = np.zeros(K, np.int64); rcs = np.zeros(K, np.int32)
+        stats = (KinStats * K)()
+        self._chk(fn(self._h, ctypes.byref(params), K, _pd(u0), _pd(k), _pd(T), _pd(tstops), _pd(T_stops), _pd(k_table), n_stops,
+                     ctypes.byref(rows), _pd(t), _pd(u), ns.ctypes.data_as(POINTER(c_int64)), rcs.ctypes.data_as(POINTER(c_int32)), stats))
+        return t, u, ns, rcs, [s_.as_dict() for s_ in stats]
 
     def solve_continuous(self, params: KinParams, u0, t_nodes, T_nodes):
         """kin_solve_continuous + kin_solution_copy: k(t) = Arrhenius(T(t)), T piecewise linear."""

@@ -7,6 +7,8 @@
 #include <numeric>
 
 #include "handle.hpp"
+#include "lu.hpp"
+#include "resident_setup.hpp"
 #include "solver.hpp"
 #include "solver_kernels.hpp"
 
@@ -73,7 +75,7 @@ static void require(bool c, int code, const char* msg) {
 
 extern "C" {
 
-const char* kin_version(void) { return "kinetica-hip 0.3 (gfx950)"; }
+const char* kin_version(void) { return "kinetica-hip 0.4 (gfx950)"; }
 
 int kin_abi_version(void) { return KIN_ABI_VERSION; }
 
@@ -136,6 +138,38 @@ int kin_network_create(int64_t n_species, int64_t n_reactions, const int64_t* re
     g_create_err = e.what();
     delete h;
     return KIN_ERR_DEVICE;
+  }
+  return KIN_OK;
+}
+
+// Symbolic analysis of the Newton-matrix factorisation without a device (sizes only): info[0..11] = ns, m, rounds, nnzU, nnzZ,
+// nnzV, nnzLZ, nnzNVU, w_size, fused products, gather-plan entries, gather-plan wavefront tasks
+int kin_lu_analyze_host(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr, const int64_t* reac_idx,
+                        const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
+                        int index_base, int hub_degree, int max_rounds, int max_tail_degree, int max_degree, int min_round,
+                        int64_t* info) {
+  try {
+    const NetworkHost H = compile_network(n_species, n_reactions, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto, index_base);
+    SparseLU lu;
+    lu.host_only = true;
+    LUOptions opt;
+    if (hub_degree > 0) opt.hub_degree = hub_degree;
+    if (max_rounds > 0) opt.max_rounds = max_rounds;
+    if (max_tail_degree > 0) opt.max_tail_degree = max_tail_degree;
+    if (max_degree > 0) opt.max_degree = max_degree;
+    if (min_round > 0) opt.min_round = min_round;
+    lu.analyze((int32_t)H.N, H.j_ptr, H.j_col, opt, nullptr);
+    if (info) {
+      info[0] = lu.ns; info[1] = lu.m; info[2] = lu.nrounds; info[3] = lu.nnzU; info[4] = lu.nnzZ; info[5] = lu.nnzV;
+      info[6] = lu.nnzLZ; info[7] = lu.nnzNVU; info[8] = lu.w_size; info[9] = lu.n_fused_products; info[10] = lu.plan_entries;
+      info[11] = lu.plan_tasks;
+    }
+  } catch (const KinError& e) {
+    g_create_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return KIN_ERR_INVALID_ARG;
   }
   return KIN_OK;
 }
@@ -304,6 +338,25 @@ int kin_solve(kin_network* h, const kin_params* params, const double* u0, const 
   if (n_saved) *n_saved = h->n_saved;
   if (retcode) *retcode = rc;
   if (rc != KIN_RETCODE_SUCCESS) throw KinError(ERR_SOLVE_FAILED, "ODE solution failed.");
+  KIN_CATCH(h)
+}
+
+int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, const double* u0, const double* k, const double* T,
+                       const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* n_rows,
+                       double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(params && u0 && K >= 1, ERR_INVALID_ARG, "params / u0 is null, or K < 1");
+  require(!(k && T), ERR_INVALID_ARG, "give per-member rate constants or per-member temperatures, not both");
+  require(!(n_stops > 0 && (k || T)), ERR_INVALID_ARG, "discrete rate updates are shared by the ensemble: no per-member k / T with tstops");
+  require(!T || h->has_arrhenius, ERR_STATE, "temperatures given but Arrhenius parameters were never set");
+  require(res_has_grid(*params), ERR_INVALID_ARG, "an ensemble solve needs a save grid (solve_chunks or save_interval)");
+  validate_solve(h, *params, tstops, T_stops, k_table, n_stops, nullptr, nullptr, 0, !(k || T));
+  if (n_rows && !out_u && !n_saved) { *n_rows = make_res_grid(*params).cap; }   // size query
+  else {
+    if (h->k_pending) h->flush_pending_T(h->stream);
+    resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
+  }
   KIN_CATCH(h)
 }
 

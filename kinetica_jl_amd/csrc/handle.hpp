@@ -8,7 +8,10 @@
 #include "network.hpp"
 #include "tiled.hpp"
 
-namespace kin { struct Solver; struct IntegratorState; }
+namespace kin {
+struct Solver; struct IntegratorState; struct ResidentSolver;
+struct ResidentDeleter { void operator()(ResidentSolver* p) const; };   // resident.cpp (the type is complete there only)
+}
 
 struct kin_network {
   kin::NetworkHost host;
@@ -64,6 +67,7 @@ struct kin_network {
   // solver + stored solution (solver.cpp)
   std::unique_ptr<kin::Solver> solver;
   std::unique_ptr<kin::IntegratorState> integ;   // return_integrator=true stepping state
+  std::unique_ptr<kin::ResidentSolver, kin::ResidentDeleter> resident;   // one-workgroup-per-trajectory integrator (resident.cpp)
   std::vector<double> sol_t, sol_u;
   kin::DevBuf<double> d_sol_u;   // saved states on the device, [n_saved][N]
   int64_t n_saved = 0;

@@ -96,7 +96,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       if (ok) { mark[i] = r; I.push_back(i); }
     }
     // stop when a round no longer pays for its two dependent kernel launches
-    if (I.empty() || (r > 0 && (int)I.size() < 8)) { for (int32_t i : I) mark[i] = -1; break; }
+    if (I.empty() || (r > 0 && (int)I.size() < opt.min_round)) { for (int32_t i : I) mark[i] = -1; break; }
     for (int32_t i : I) {
       auto& nb = adj[i];
       for (int32_t t : nb) {
@@ -354,15 +354,15 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
         int64_t p = pos_of(iperm[i], iperm[j]);
         jm[e] = (int32_t)p | (i == j ? (int32_t)0x80000000 : 0);
       }
-    jmap.upload(jm, s);
-    ent_pivot.upload(ent_piv, s);
+    up(jmap, jm, s);
+    up(ent_pivot, ent_piv, s);
     std::vector<int32_t> yl(n), xl(n);
     for (int32_t v = 0; v < n; v++) {
       yl[v] = (int32_t)(off_y + iperm[v]);
       xl[v] = iperm[v] < ns ? (int32_t)(off_y + iperm[v]) : (int32_t)(off_x + iperm[v] - ns);
     }
-    yloc.upload(yl, s); xloc.upload(xl, s);
-    KIN_HIP(hipStreamSynchronize(s));
+    up(yloc, yl, s); up(xloc, xl, s);
+    sync(s);
   }
 
   // ---- per-round Schur update plans
@@ -389,7 +389,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       });
     for (auto& t : th) t.join();
     for (auto& e : errs) if (e) std::rethrow_exception(e);
-    for (int r = 0; r < nrounds; r++) { schur_macs += macs[r]; schur[r].upload(hp[r], s); }
+    for (int r = 0; r < nrounds; r++) { schur_macs += macs[r]; up(schur[r], hp[r], s); }
   }
   lap("scatter map + Schur plans");
   // ---- forward substitution: y_q -= sum_{p < q, q in nb(p)} L[q][p] * y_p, grouped by the round of q
@@ -404,10 +404,10 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
         int32_t q = nbr[e];
         per_round[round_of(q)].push_back({off_y + q, (int32_t)(off_L + e), (int32_t)(off_y + p)});
       }
-    for (int r = 0; r < nrounds; r++) fwd[r].upload(plan_from_triples(per_round[r], false, 0, 0), s);
+    for (int r = 0; r < nrounds; r++) up(fwd[r], plan_from_triples(per_round[r], false, 0, 0), s);
     if (explicit_tri)   // the dense rows read y1 from its own vector (the sparse rows are not updated in place any more)
       for (Triple& t : per_round[nrounds]) t.b = (int32_t)(off_y1 + (t.b - off_y));
-    fwd_dense.upload(plan_from_triples(per_round[nrounds], false, 0, 0), s);
+    up(fwd_dense, plan_from_triples(per_round[nrounds], false, 0, 0), s);
   }
   if (explicit_tri && !fused_tri) {
     // y1_i = b_i - sum_p Z'[i,p] b_p
@@ -418,7 +418,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
         ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y1 + i)); aux.push_back((int32_t)(off_y + i));
       }
       a.push_back(0); b.push_back(0);
-      fwdZ.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+      up(fwdZ, build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
     }
     // t_p = y1_p - sum_{c dense} U[p,c] x2_c
     {
@@ -429,7 +429,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
         ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_t + p)); aux.push_back((int32_t)(off_y1 + p));
       }
       a.push_back(0); b.push_back(0);
-      bwdT.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+      up(bwdT, build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
     }
     // x1_i = sum_j V[i,j] t_j
     {
@@ -438,7 +438,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
         for (auto& ce : v_cols[i]) { a.push_back((int32_t)(off_V + ce.second)); b.push_back((int32_t)(off_t + ce.first)); }
         ptr.push_back((int32_t)a.size()); dst.push_back((int32_t)(off_y + i));
       }
-      bwdV.upload(build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
+      up(bwdV, build_seg_plan(ns, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false), s);
     }
   }
   if (fused_tri) {
@@ -479,11 +479,11 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
     w_end = align(off_VC + PC.ell_total + PC.long_total + 8);
     if (w_end >= ((int64_t)1 << 30)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
     PA.val_base = (int32_t)off_VA; PC.val_base = (int32_t)off_VC;
-    stageA.upload(PA, s); stageC.upload(PC, s);
+    up(stageA, PA, s); up(stageC, PC, s);
     {
       const std::vector<int32_t> x2(perm.begin() + ns, perm.end());
-      x2_species.upload(x2, s);
-      KIN_HIP(hipStreamSynchronize(s));   // the host vector dies here
+      up(x2_species, x2, s);
+      sync(s);   // the host vector dies here
     }
     // relocation of the value IDs
     std::vector<int32_t> relZ(nnzZ, -1), relV(nnzV, -1), relLZ(nnzLZ, -1), relNVU(nnzNVU, -1);
@@ -531,13 +531,13 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       Pnvu = build_seg_plan((int64_t)dst.size(), ptr.data(), dst.data(), a.data(), b.data(), nullptr, false);
     };
     { std::thread tL(build_lzp); build_nvup(); tL.join(); }
-    lz_build.upload(Plz, s); nvu_build.upload(Pnvu, s);
-    KIN_HIP(hipStreamSynchronize(s));
+    up(lz_build, Plz, s); up(nvu_build, Pnvu, s);
+    sync(s);
   }
   if (explicit_tri) {
-    mono_ent_ptr.upload(m_ent_ptr, s); mono_ptr.upload(m_ptr, s); mono_fac.upload(m_fac, s); mono_dst.upload(m_dst, s);
-    mono_sign.upload(m_sign, s);
-    KIN_HIP(hipStreamSynchronize(s));
+    up(mono_ent_ptr, m_ent_ptr, s); up(mono_ptr, m_ptr, s); up(mono_fac, m_fac, s); up(mono_dst, m_dst, s);
+    up(mono_sign, m_sign, s);
+    sync(s);
   }
   w_size = w_end;
   if (w_size >= (1ll << 31)) throw KinError(ERR_UNSUPPORTED, "Newton matrix workspace exceeds int32 indexing");
@@ -557,13 +557,11 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       aux.push_back((int32_t)(off_diag + p));
     }
     a.push_back(0); b.push_back(0);  // keep data() valid for all-empty rounds
-    bwd[r].upload(build_seg_plan(p1 - p0, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
+    up(bwd[r], build_seg_plan(p1 - p0, ptr.data(), dst.data(), a.data(), b.data(), nullptr, false, aux.data()), s);
   }
 
-  pinv.alloc(2 * 32 * 32);
-  slots.clear();
-  ensure_slots(1, s);
-  KIN_HIP(hipStreamSynchronize(s));
+  if (!host_only) { pinv.alloc(2 * 32 * 32); slots.clear(); ensure_slots(1, s); }
+  sync(s);
   lap("backward plans + first slot");
 }
 

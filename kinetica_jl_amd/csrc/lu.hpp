@@ -20,6 +20,7 @@
 // the integrator answers with a fresh Jacobian and a shorter step (M -> I as h -> 0).
 #pragma once
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "common.hpp"
@@ -33,6 +34,8 @@ struct LUOptions {
   int max_rounds = 8;
   int max_tail_degree = 8;   // candidate filter: non-hub neighbours at elimination time
   int max_degree = 60;       // candidate filter: all neighbours at elimination time
+  int min_round = 8;         // a round with fewer pivots than this ends the sparse elimination (it no longer pays for its two
+                             // dependent launches; inside the resident integrator a round is two barriers, and 2 is enough)
 };
 
 struct SparseLU {
@@ -92,6 +95,25 @@ struct SparseLU {
 
   void analyze(int32_t n, const std::vector<int32_t>& j_ptr, const std::vector<int32_t>& j_col,
                const LUOptions& opt, hipStream_t s);
+  // host_only: the symbolic analysis without a device (nothing is uploaded or allocated; sizes and plan statistics only) -
+  // kin_lu_analyze_host, used to choose elimination parameters and by the CPU tests
+  bool host_only = false;
+  int64_t plan_entries = 0, plan_tasks = 0, plan_long_rows = 0;   // summed over every gather plan built (host_only statistics)
+  // keep_host: host copies of everything analyze() would upload, keyed by the address of the device-side member (the CPU
+  // replay of the factorisation in tests/native/ reads them; test infrastructure - the product never sets it)
+  bool keep_host = false;
+  std::map<const void*, std::vector<int32_t>> host_i32;
+  std::map<const void*, std::vector<float>> host_f32;
+  std::map<const void*, SegPlanHost> host_plan;
+  void up(DevBuf<int32_t>& d, const std::vector<int32_t>& h, hipStream_t s) { if (keep_host) host_i32[&d] = h; if (!host_only) d.upload(h, s); }
+  void up(DevBuf<float>& d, const std::vector<float>& h, hipStream_t s) { if (keep_host) host_f32[&d] = h; if (!host_only) d.upload(h, s); }
+  void up(SegPlanDev& d, const SegPlanHost& h, hipStream_t s) {
+    plan_entries += (int64_t)std::max(h.ell_a.size(), h.ell_b.size()) + (int64_t)std::max(h.long_a.size(), h.long_b.size());
+    plan_tasks += h.n_groups() + h.n_segs(); plan_long_rows += h.n_blks();
+    if (keep_host) host_plan[&d] = h;
+    if (!host_only) d.upload(h, s);
+  }
+  void sync(hipStream_t s) { if (!host_only) KIN_HIP(hipStreamSynchronize(s)); }
   // M = I - c*J, factorised into slot `slot`
   // `bad`: device flag raised when a pivot vanishes (a multiplier exceeds 1e8 in magnitude or is not finite): pivoting
   // is static (diagonal), so the caller answers with a fresh Jacobian and a shorter step

@@ -1,0 +1,860 @@
+// Resident integrator (gfx950): one 1024-thread workgroup owns one trajectory for the whole solve. The controller is
+// resident_core.hpp, compiled here with a backend whose operations are workgroup-wide phases over the trajectory's
+// vectors in global memory (L2-resident for the network sizes this path takes: up to ~2 000 species), separated by
+// workgroup barriers where the multi-workgroup integrator of solver.cpp has kernel boundaries.
+//   * Wavefront 0 runs the controller (its 64 lanes redundantly, on identical scalars); the other fifteen wait at a barrier
+//     for its next command - the phase to run and its scalar arguments, posted in LDS - run that phase together with
+//     wavefront 0 and come back. (First version: all 1 024 threads ran the controller redundantly. Its live scalars are
+//     spilled per LANE around every phase call, and sixteen wavefronts doing that cost 70 us per step at 300 species.)
+//   * The phases are NOT inlined into the controller (each is a function of its own with the whole register file; the
+//     controller's live scalars are saved once per call instead of being spilled inside the phases' loops), and they take
+//     their pointers from a context block in LDS and give them an address space: a pointer read from memory is generic to
+//     the compiler, and generic accesses (flat_load / flat_store) cost this kernel a factor of ten in its first version.
+//   * The LU cache's slot table lives in registers, slot i in lane i of every wavefront (reads = lane broadcasts, writes =
+//     one predicated move): no shared copy, no hazard between wavefronts that run ahead of each other.
+//   * The dense Schur block is inverted by a blocked Gauss-Jordan (16 columns per block step, pivot block by the
+//     single-wavefront inversion the multi-workgroup path uses, rank-16 updates on the matrix cores), ping-pong between
+//     the slot's block and a scratch block of the trajectory.
+// Reference: the work this replaces is init / solve! / reinit! of the reference's stiff solver and the chunk loop around
+// it (src/solving/methods.jl:185-303, 717-865; solve_utils.jl:376-424, 435-509).
+#include "resident.hpp"
+
+#include "exp_tab.hpp"
+#include "gj_dev.hpp"
+#include "segsum_dev.hpp"
+
+#include <new>
+
+namespace kin {
+
+namespace {
+
+constexpr int RES_WG = 1024, RES_WAVES = RES_WG / 64;
+
+#define KIN_AS1 __attribute__((address_space(1)))
+typedef KIN_AS1 double gd_t;
+typedef KIN_AS1 const double gcd_t;
+typedef KIN_AS1 const int32_t gci_t;
+typedef KIN_AS1 const float gcf_t;
+template <class T> __device__ __forceinline__ KIN_AS1 T* glob(T* p) { return (KIN_AS1 T*)p; }
+
+// a gather plan with global-memory pointers
+struct SegPlanViewG {
+  gci_t *grp_off, *grp_dst, *grp_aux, *ell_a, *ell_b; gcf_t* ell_c;
+  gci_t *seg_beg, *seg_end, *seg_dst, *seg_aux, *blk_beg, *blk_end, *blk_dst, *blk_aux, *long_a, *long_b; gcf_t* long_c;
+  int32_t G, S, B, val_base, ell_total;
+  int32_t n64, n32;   // medium rows (sorted longest first): [0, n64) have more than 64 entries, [n64, n32) 33 .. 64, the rest 9 .. 32
+};
+__device__ __forceinline__ SegPlanViewG plan_g(const SegPlanView& p, int n64 = -1, int n32 = -1) {
+  SegPlanViewG g;
+  g.grp_off = glob(p.grp_off); g.grp_dst = glob(p.grp_dst); g.grp_aux = glob(p.grp_aux);
+  g.ell_a = glob(p.ell_a); g.ell_b = glob(p.ell_b); g.ell_c = glob(p.ell_c);
+  g.seg_beg = glob(p.seg_beg); g.seg_end = glob(p.seg_end); g.seg_dst = glob(p.seg_dst); g.seg_aux = glob(p.seg_aux);
+  g.blk_beg = glob(p.blk_beg); g.blk_end = glob(p.blk_end); g.blk_dst = glob(p.blk_dst); g.blk_aux = glob(p.blk_aux);
+  g.long_a = glob(p.long_a); g.long_b = glob(p.long_b); g.long_c = glob(p.long_c);
+  g.G = p.G; g.S = p.S; g.B = p.B; g.val_base = p.val_base; g.ell_total = p.ell_total;
+  g.n64 = n64 < 0 ? p.S : n64; g.n32 = n32 < 0 ? p.S : n32;   // unknown split: every medium row by a whole wavefront
+  return g;
+}
+struct SegExtraG { gcd_t* psi = nullptr; gcd_t* d = nullptr; double cscal = 0.0; };
+
+// hot gather plans kept in LDS (the per-round plans of the factorisation stay in global memory)
+enum : int { PL_RHS = 0, PL_JAC, PL_RESID, PL_LZ, PL_NVU, PL_STAGEA, PL_STAGEC, PL_FWDZ, PL_FWD_DENSE, PL_BWDT, PL_BWDV, PL_COUNT };
+
+// everything the phases need, written once by the kernel's prologue (LDS)
+struct ResCtx {
+  ResTrajDev T;
+  const ResNetDev* net;
+  SegPlanView plan[PL_COUNT];
+  int32_t split[PL_COUNT][2];   // n64, n32 of the hot plans (counted once by the kernel's prologue)
+  int32_t profile;
+  int32_t N, R, nnzJ, ns, m, m16, mpad, nrounds, n_mono_ent, solve_mode, has_kmax, n_slots, rate_mode;
+  int64_t off_diag, off_U, off_L, off_S, off_y, off_x, off_dinv, w_size;
+  double k_max, t_mult;
+};
+
+struct ResShared {
+  double red[RES_WAVES][8];
+  double ru[36];
+  double coef[8], gamma[8];
+  double drift[RES_MAX_SLOTS], slot_c[RES_MAX_SLOTS];
+  int slot_valid[RES_MAX_SLOTS];
+  double pinv[16][17];
+  long long prof[12];
+  int bad;
+  // command of the leader wavefront to the fifteen others (see resident_bdf_kernel)
+  int cmd_op, cmd_i[3];
+  long long cmd_l;
+  double cmd_d[8];
+};
+
+// LU-cache slot table (Solver's per-slot bookkeeping): only the leader wavefront touches it - its 64 lanes execute in
+// lockstep, so a shared copy has no hazards, and lane i can look at slot i when a search runs over all slots
+struct ResSlots {
+  double c_fact[RES_MAX_SLOTS], crate[RES_MAX_SLOTS];
+  long long crate_step[RES_MAX_SLOTS], crate_restart[RES_MAX_SLOTS], last_use[RES_MAX_SLOTS], jac_stamp[RES_MAX_SLOTS], step_stamp[RES_MAX_SLOTS];
+  int valid[RES_MAX_SLOTS];
+};
+
+__shared__ ResCtx g_cx;
+__shared__ ResShared g_sh;
+__shared__ ResSlots g_sl;
+__shared__ ResParams g_par;
+extern __shared__ double g_dyn[];   // row panel of the dense inverse: 16 x (m16 + 1) doubles
+
+// phase kinds of the in-kernel profile (ResResult::prof, 10 ns ticks, thread 0's clock)
+enum ProfId : int { PF_TOTAL = 0, PF_FACTOR = 1, PF_GJ = 2, PF_NEWTON = 3, PF_SOLVE = 4, PF_PREDICT = 5, PF_CHANGE_D = 6, PF_ACCEPT = 7,
+                    PF_JAC = 8, PF_RHS = 9, PF_RESID = 10, PF_UPDATE = 11 };
+struct ProfScope {   // (off unless KIN_RESIDENT_PROFILE is set: the clock reads cost ~0.3 us each)
+  int id; long long t0;
+  __device__ ProfScope(int i) : id(i), t0(g_cx.profile ? wall_clock64() : 0) {}
+  __device__ ~ProfScope() { if (g_cx.profile && threadIdx.x == 0) g_sh.prof[id] += wall_clock64() - t0; }
+};
+#define RES_PROF(id) ProfScope prof_scope_##id(id)
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ long long shfl_ll(long long v, int src) {
+  const int lo = __shfl((int)(v & 0xffffffffll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// NV sums over the workgroup, the same value in every thread (fixed order: bitwise reproducible)
+template <int NV>
+__device__ __forceinline__ void wg_reduce(double (&v)[NV]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NV; q++) v[q] = wave_sum(v[q]);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; q++) g_sh.red[wave][q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < RES_WAVES; w++) t += g_sh.red[w][q];
+    v[q] = t;
+  }
+  __syncthreads();
+}
+
+// The in-workgroup executor of a gather plan (kernels.hip: segsum_kernel spreads the same tasks over a grid): wavefront
+// tasks round robin over the 16 wavefronts - long rows first (one wavefront walks such a row 512 entries per pass: no
+// workgroup-wide reduction inside a phase), then medium rows, then the ELL groups of short rows.
+// one group of LANES lanes per medium row (4 entries per lane), 64 / LANES rows per wavefront task
+template <int OP, int LANES>
+__device__ __forceinline__ void seg_rows_grouped(const SegPlanViewG& p, gcd_t* src, gd_t* out, const SegExtraG& ex, bool impl, int row0, int row_end) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LANES, l = lane % LANES;
+  const int sidx = row0 + g;
+  const bool have = sidx < row_end;
+  const int32_t e0 = have ? p.seg_beg[sidx] : 0, e1 = have ? p.seg_end[sidx] : 0;
+  const int32_t dst = have ? p.seg_dst[sidx] : -1, aux = have ? p.seg_aux[sidx] : 0;
+  const SegPre pre = seg_pre<OP>(out, src, l == 0 ? dst : -1, aux, ex);
+  double acc = seg_gather<OP, 4, false>(p, src, ex, impl, [&](int x) { const int32_t e = e0 + l + LANES * x; return e < e1 ? e : -1; });
+#pragma unroll
+  for (int off = LANES / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (l == 0 && dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
+}
+
+template <int OP>
+__device__ __forceinline__ void seg_run(const SegPlanViewG& p, gcd_t* src, gd_t* out, const SegExtraG& ex) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool impl = p.val_base >= 0;
+  // task list: long rows, medium rows > 64 entries (a wavefront each), 33 .. 64 (four per wavefront), 9 .. 32 (eight per
+  // wavefront), ELL groups of 64 short rows - most rows of the solve's stages have 9 .. 32 entries
+  const int t1 = p.B, t2 = t1 + p.n64, t3 = t2 + ((p.n32 - p.n64 + 3) >> 2), t4 = t3 + ((p.S - p.n32 + 7) >> 3), ntask = t4 + p.G;
+  for (int task = wave; task < ntask; task += RES_WAVES) {
+    if (task < t1) {
+      const int r = task;
+      const int32_t e0 = p.blk_beg[r], e1 = p.blk_end[r], dst = p.blk_dst[r], aux = p.blk_aux[r];
+      const SegPre pre = seg_pre<OP>(out, src, lane == 0 ? dst : -1, aux, ex);
+      double acc = 0.0;
+      for (int32_t base = e0; base < e1; base += 512)
+        acc += seg_gather<OP, 8, false>(p, src, ex, impl, [&](int x) { const int32_t e = base + lane + 64 * x; return e < e1 ? e : -1; });
+      acc = wave_sum(acc);
+      if (lane == 0) seg_store<OP>(out, dst, acc, pre, ex);
+    } else if (task < t2) {
+      seg_rows_grouped<OP, 64>(p, src, out, ex, impl, task - t1, p.n64);
+    } else if (task < t3) {
+      seg_rows_grouped<OP, 16>(p, src, out, ex, impl, p.n64 + 4 * (task - t2), p.n32);
+    } else if (task < t4) {
+      seg_rows_grouped<OP, 8>(p, src, out, ex, impl, p.n32 + 8 * (task - t3), p.S);
+    } else {
+      const int g = task - t4;
+      const int32_t dst = p.grp_dst[g * 64 + lane], aux = p.grp_aux[g * 64 + lane];
+      const int32_t c0 = p.grp_off[g], c1 = p.grp_off[g + 1];
+      const SegPre pre = seg_pre<OP>(out, src, dst, aux, ex);
+      double acc = 0.0;
+      for (int32_t col = c0; col < c1; col += 8)
+        acc += seg_gather<OP, 8, true>(p, src, ex, impl, [&](int x) { return col + x < c1 ? (col + x) * 64 + lane : -1; });
+      if (dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
+    }
+  }
+}
+
+__device__ __forceinline__ SegPlanViewG hot_plan(int id) { return plan_g(g_cx.plan[id], g_cx.split[id][0], g_cx.split[id][1]); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// phases (each called by all 1 024 threads; every one ends behind a barrier)
+// ------------------------------------------------------------------------------------------------------------------
+enum VecOp : int { VO_LOAD_U0 = 0, VO_CHUNK_START_FROM_Y, VO_Y_FROM_CHUNK_START_CLIPPED, VO_Y_FROM_D0, VO_YTMP_FROM_D0, VO_YTMP_AXPY };
+__device__ __noinline__ void ph_vec(int op, double h0) {
+  const int N = g_cx.N, tid = threadIdx.x;
+  gd_t* y = glob(g_cx.T.y);
+  if (op == VO_LOAD_U0) { gcd_t* u0 = glob(g_cx.T.u0); for (int i = tid; i < N; i += RES_WG) y[i] = u0[i]; }
+  else if (op == VO_CHUNK_START_FROM_Y) { gd_t* cs = glob(g_cx.T.chunk_start); for (int i = tid; i < N; i += RES_WG) cs[i] = y[i]; }
+  else if (op == VO_Y_FROM_CHUNK_START_CLIPPED) {
+    gcd_t* cs = glob((const double*)g_cx.T.chunk_start);
+    for (int i = tid; i < N; i += RES_WG) { const double v = cs[i]; y[i] = v < 0.0 ? 0.0 : v; }
+  }
+  else if (op == VO_Y_FROM_D0) { gcd_t* D = glob((const double*)g_cx.T.D); for (int i = tid; i < N; i += RES_WG) y[i] = D[i]; }
+  else if (op == VO_YTMP_FROM_D0) { gcd_t* D = glob((const double*)g_cx.T.D); gd_t* yt = glob(g_cx.T.ytmp); for (int i = tid; i < N; i += RES_WG) yt[i] = D[i]; }
+  else { gcd_t* f0 = glob((const double*)g_cx.T.f0); gd_t* yt = glob(g_cx.T.ytmp); for (int i = tid; i < N; i += RES_WG) yt[i] = y[i] + h0 * f0[i]; }
+  __syncthreads();
+}
+
+__device__ __noinline__ void ph_save_y(long long row, double time) {
+  const int N = g_cx.N;
+  gcd_t* y = glob((const double*)g_cx.T.y);
+  gd_t* o = glob(g_cx.T.sol) + (size_t)row * N;
+  for (int i = threadIdx.x; i < N; i += RES_WG) o[i] = y[i];
+  if (threadIdx.x == 0) glob(g_cx.T.sol_t)[row] = time;
+  __syncthreads();
+}
+
+__device__ __noinline__ void ph_apply_rates(long long stop) {
+  const int R = g_cx.R;
+  gd_t* k = glob(g_cx.T.k);
+  const ResNetDev* net = g_cx.net;
+  if (g_cx.rate_mode == 1) {
+    gcd_t* src = glob(net->k_table) + (size_t)stop * R;
+    for (int r = threadIdx.x; r < R; r += RES_WG) k[r] = src[r];
+  } else if (g_cx.rate_mode == 2) {
+    const double RT = 8.314462618 * glob(net->T_stops)[stop];
+    gcd_t* Ea = glob(net->Ea); gcd_t* A = glob(net->A);
+    const int has_kmax = g_cx.has_kmax; const double k_max = g_cx.k_max, t_mult = g_cx.t_mult;
+    for (int r = threadIdx.x; r < R; r += RES_WG) k[r] = arrhenius_one(Ea[r], A[r], RT, has_kmax, k_max, t_mult);
+  }
+  __syncthreads();
+}
+
+// mass-action rates of state u into T.rate (make_rs, solve_utils.jl:318-334); no barrier inside
+__device__ __forceinline__ void rates_into(gcd_t* u) {
+  const int R = g_cx.R;
+  gci_t* x0 = glob(g_cx.net->x0); gci_t* x1 = glob(g_cx.net->x1);
+  gcd_t* k = glob((const double*)g_cx.T.k); gd_t* rate = glob(g_cx.T.rate);
+  for (int r = threadIdx.x; r < R; r += RES_WG) {
+    const int32_t a = x0[r], b = x1[r];
+    const double ub = b >= 0 ? u[b] : 1.0;
+    rate[r] = k[r] * u[a] * ub;
+  }
+}
+
+enum RhsOp : int { RO_Y_TO_F0 = 0, RO_YTMP_TO_F1, RO_YTMP_TO_F0 };
+__device__ __noinline__ void ph_rhs(int op) {
+  RES_PROF(PF_RHS);
+  gcd_t* u = glob((const double*)(op == RO_Y_TO_F0 ? g_cx.T.y : g_cx.T.ytmp));
+  gd_t* out = glob(op == RO_YTMP_TO_F1 ? g_cx.T.f1 : g_cx.T.f0);
+  rates_into(u);
+  __syncthreads();
+  seg_run<SEG_COEF_SET>(hot_plan(PL_RHS), glob((const double*)g_cx.T.rate), out, SegExtraG{});
+  __syncthreads();
+}
+
+// analytic Jacobian at y into T.jv (CSR values)
+__device__ __noinline__ void ph_jac() {
+  RES_PROF(PF_JAC);
+  const int R = g_cx.R;
+  gcd_t* u = glob((const double*)g_cx.T.y);
+  gci_t* x0 = glob(g_cx.net->x0); gci_t* x1 = glob(g_cx.net->x1);
+  gcd_t* k = glob((const double*)g_cx.T.k); gd_t* dr = glob(g_cx.T.dr);
+  for (int r = threadIdx.x; r < R; r += RES_WG) {
+    const int32_t a = x0[r], b = x1[r];
+    const double kk = k[r];
+    double d0, d1 = 0.0;
+    if (b < 0) d0 = kk;
+    else if (b == a) d0 = 2.0 * kk * u[a];
+    else { d0 = kk * u[b]; d1 = kk * u[a]; }
+    dr[2 * r] = d0; dr[2 * r + 1] = d1;
+  }
+  __syncthreads();
+  seg_run<SEG_COEF_SET>(hot_plan(PL_JAC), glob((const double*)g_cx.T.dr), glob(g_cx.T.jv), SegExtraG{});
+  __syncthreads();
+}
+
+__device__ __noinline__ ResNorms ph_norms(bool with_f1, double atol, double rtol) {
+  const int N = g_cx.N;
+  gcd_t* y = glob((const double*)g_cx.T.y); gcd_t* f0p = glob((const double*)g_cx.T.f0); gcd_t* f1p = glob((const double*)g_cx.T.f1);
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    const double y0 = y[i], f0 = f0p[i];
+    const double sc = atol + rtol * fabs(y0);
+    const double a = y0 / sc, b = f0 / sc;
+    v[0] += a * a; v[1] += b * b;
+    if (!isfinite(f0)) v[3] = 1.0;
+    if (with_f1) { const double f1 = f1p[i]; const double c = (f1 - f0) / sc; v[2] += c * c; if (!isfinite(f1)) v[3] = 1.0; }
+  }
+  wg_reduce<4>(v);
+  const double Nd = (double)N;
+  return ResNorms{sqrt(v[0] / Nd), sqrt(v[1] / Nd), sqrt(v[2] / Nd), v[3] > 0.0 ? 1 : 0};
+}
+
+__device__ __noinline__ void ph_init_D(bool from_ytmp, double h) {
+  const int N = g_cx.N;
+  gcd_t* y0 = glob((const double*)(from_ytmp ? g_cx.T.ytmp : g_cx.T.y));
+  gcd_t* f0 = glob((const double*)g_cx.T.f0);
+  gd_t* D = glob(g_cx.T.D);
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    D[i] = y0[i];
+    D[(size_t)N + i] = f0[i] * h;
+#pragma unroll
+    for (int j = 2; j < RES_D_ROWS; j++) D[(size_t)j * N + i] = 0.0;
+  }
+  __syncthreads();
+}
+
+// predictor from the backward differences (gamma in g_sh.gamma): y, psi, d = 0, scale
+__device__ __noinline__ void ph_predict(int order, double alpha_o, double atol, double rtol) {
+  RES_PROF(PF_PREDICT);
+  const int N = g_cx.N;
+  gcd_t* D = glob((const double*)g_cx.T.D);
+  gd_t* y = glob(g_cx.T.y); gd_t* psi = glob(g_cx.T.psi); gd_t* d = glob(g_cx.T.d); gd_t* scale = glob(g_cx.T.scale);
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    double yp = D[i], ps = 0.0;
+    for (int j = 1; j <= order; j++) {
+      const double dj = D[(size_t)j * N + i];
+      yp += dj;
+      ps += dj * g_sh.gamma[j];
+    }
+    y[i] = yp;
+    psi[i] = ps / alpha_o;
+    d[i] = 0.0;
+    scale[i] = atol + rtol * fabs(yp);
+  }
+  __syncthreads();
+}
+
+// D[0..ord] <- (R U)^T D[0..ord], matrix in g_sh.ru
+__device__ __noinline__ void ph_change_D(int ord) {
+  RES_PROF(PF_CHANGE_D);
+  const int N = g_cx.N;
+  gd_t* D = glob(g_cx.T.D);
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    double v[6], o[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) v[j] = j <= ord ? D[(size_t)j * N + i] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) t += (q <= ord ? g_sh.ru[q * 6 + a] : 0.0) * v[q];
+      o[a] = t;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j <= ord) D[(size_t)j * N + i] = o[j];
+  }
+  __syncthreads();
+}
+
+__device__ __noinline__ void ph_accept(int order) {
+  RES_PROF(PF_ACCEPT);
+  const int N = g_cx.N;
+  gd_t* D = glob(g_cx.T.D);
+  gcd_t* d = glob((const double*)g_cx.T.d);
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    const double di = d[i];
+    D[(size_t)(order + 2) * N + i] = di - D[(size_t)(order + 1) * N + i];
+    D[(size_t)(order + 1) * N + i] = di;
+    double carry = di;
+    for (int j = order; j >= 0; j--) {
+      carry += D[(size_t)j * N + i];
+      D[(size_t)j * N + i] = carry;
+    }
+  }
+  __syncthreads();
+}
+
+// dense output into solution row `row` (weights in g_sh.coef)
+__device__ __noinline__ void ph_interp(int order, long long row) {
+  const int N = g_cx.N;
+  gcd_t* D = glob((const double*)g_cx.T.D);
+  gd_t* o = glob(g_cx.T.sol) + (size_t)row * N;
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    double v = D[i];
+    for (int j = 1; j <= order; j++) v += g_sh.coef[j] * D[(size_t)j * N + i];
+    o[i] = v;
+  }
+  __syncthreads();
+}
+
+// drift guard of the LU cache at a restart (solver_kernels.hip: slot_drift_kernel): g_sh.drift[s] for every valid slot
+// (validity and c_fact of the slots in g_sh.slot_valid / slot_c, written by the caller)
+__device__ __noinline__ void ph_drift() {
+  const int N = g_cx.N, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  gcd_t* jv = glob((const double*)g_cx.T.jv);
+  gci_t* j_diag = glob(g_cx.net->j_diag);
+  for (int s = wave; s < g_cx.n_slots; s += RES_WAVES) {
+    if (!g_sh.slot_valid[s]) { if (lane == 0) g_sh.drift[s] = 0.0; continue; }
+    const double c = g_sh.slot_c[s];
+    gcd_t* jd = glob((const double*)g_cx.T.jd) + (size_t)s * N;
+    double worst = 1.0;
+    for (int i = lane; i < N; i += 64) {
+      const double m_old = 1.0 - c * jd[i], m_new = 1.0 - c * jv[j_diag[i]];
+      const double q = m_old / m_new;
+      const double dev = (q > 0.0) ? fmax(q, 1.0 / q) : 1e300;
+      worst = fmax(worst, dev == dev ? dev : 1e300);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_down(worst, off, 64));
+    if (lane == 0) g_sh.drift[s] = worst - 1.0;
+  }
+  __syncthreads();
+}
+
+// ---- dense inverse: blocked Gauss-Jordan, 16 columns per block step, X -> Y ping-pong (no tile reads what another wavefront
+// of the same step writes). Block step kb with K = rows / columns 16 kb .. 16 kb + 15:
+//     P = X[K,K]^-1                     (wavefront 0: gj_inv16_wave, result in g_sh.pinv)
+//     RP = P X[K,:]                     (row panel into LDS g_dyn, 16 x m16; RP[:,K] = P)
+//     Y[K,:] = RP ;  Y[i,j] = X[i,j] - X[i,K] RP[:,j]  (j not in K) ;  Y[i,K] = -X[i,K] P        (i not in K)
+// v_mfma_f64_16x16x4_f64 operand layout (tools/mfma_probe.hip): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k,
+// D[i][j] in lane 16 (i % 4) + j, register i / 4.
+typedef double res_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gj_blocked(gd_t* S, gd_t* S2, int ld, int m16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nb = m16 / 16, ldr = m16 + 1;
+  double* rp = g_dyn;
+  gd_t* X = S;
+  gd_t* Y = S2;
+  for (int kb = 0; kb < nb; kb++) {
+    const int K0 = kb * 16;
+    if (wave == 0) {
+      const int r = lane >> 2, c0 = (lane & 3) * 4;
+      double a[4];
+#pragma unroll
+      for (int x = 0; x < 4; x++) a[x] = X[(size_t)(K0 + r) * ld + K0 + c0 + x];
+      const bool vanished = gj_inv16_wave(a, lane);
+#pragma unroll
+      for (int x = 0; x < 4; x++) g_sh.pinv[r][c0 + x] = a[x];
+      if (vanished) g_sh.bad = 1;
+    }
+    __syncthreads();
+    // row panel: wavefront w forms the 16 x 16 tiles J = w, w + 16, ...
+    for (int J = wave; J < nb; J += RES_WAVES) {
+      res_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      if (J != kb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          const double ap = g_sh.pinv[li][4 * ks + lk];
+          const double bx = X[(size_t)(K0 + 4 * ks + lk) * ld + J * 16 + li];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bx, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = 4 * v + lk;
+        rp[i * ldr + J * 16 + li] = (J == kb) ? g_sh.pinv[i][li] : acc[v];
+      }
+    }
+    __syncthreads();
+    // update: wavefront w takes the row strips I = w, w + 16, ...; its column-panel tile X[I,K] is loaded once per strip
+    for (int I = wave; I < nb; I += RES_WAVES) {
+      if (I == kb) {
+        for (int J = 0; J < nb; J++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) Y[(size_t)(K0 + 4 * v + lk) * ld + J * 16 + li] = rp[(4 * v + lk) * ldr + J * 16 + li];
+        continue;
+      }
+      double a[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) a[ks] = X[(size_t)(I * 16 + li) * ld + K0 + 4 * ks + lk];
+      for (int J = 0; J < nb; J++) {
+        double xo[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) xo[v] = (J == kb) ? 0.0 : X[(size_t)(I * 16 + 4 * v + lk) * ld + J * 16 + li];
+        res_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], rp[(4 * ks + lk) * ldr + J * 16 + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; v++) Y[(size_t)(I * 16 + 4 * v + lk) * ld + J * 16 + li] = xo[v] - acc[v];
+      }
+    }
+    __syncthreads();
+    gd_t* t = X; X = Y; Y = t;
+  }
+  if (X != S) {   // odd number of block steps: the inverse sits in the scratch block
+    for (int idx = threadIdx.x; idx < m16 * m16; idx += RES_WG) { const int i = idx / m16, j = idx - i * m16; S[(size_t)i * ld + j] = X[(size_t)i * ld + j]; }
+    __syncthreads();
+  }
+}
+
+// M = I - c J factorised into slot `slot` (SparseLU::factor); returns true when a pivot vanished
+__device__ __noinline__ bool ph_factor(int slot, double c, bool keep_diag) {
+  RES_PROF(PF_FACTOR);
+  const int tid = threadIdx.x;
+  const ResNetDev* net = g_cx.net;
+  gd_t* W = glob(g_cx.T.W) + (size_t)slot * (size_t)g_cx.w_size;
+  gcd_t* Wc = (gcd_t*)W;
+  gcd_t* jv = glob((const double*)g_cx.T.jv);
+  const int m = g_cx.m, mpad = g_cx.mpad, nnzJ = g_cx.nnzJ, ns = g_cx.ns;
+  const long long off_S = g_cx.off_S, off_L = g_cx.off_L, off_diag = g_cx.off_diag, off_dinv = g_cx.off_dinv;
+  if (tid == 0) g_sh.bad = 0;
+  for (long long e = tid; e < g_cx.off_y; e += RES_WG) W[e] = 0.0;
+  __syncthreads();
+  {
+    gci_t* jmap = glob(net->jmap);
+    const int total = nnzJ + (mpad - m);
+    for (int e = tid; e < total; e += RES_WG) {
+      if (e < nnzJ) {
+        const int32_t jm = jmap[e];
+        W[jm & 0x7fffffff] = (jm < 0 ? 1.0 : 0.0) - c * jv[e];
+      } else {
+        const int d = m + (e - nnzJ);
+        W[off_S + (long long)d * mpad + d] = 1.0;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    gci_t* ent_pivot = glob(net->ent_pivot);
+    for (int r = 0; r < g_cx.nrounds; r++) {
+      const int e0 = net->round_e0[r], e1 = net->round_e0[r + 1];
+      for (int e = e0 + tid; e < e1; e += RES_WG) {
+        const double w = W[off_L + e], piv = W[off_diag + ent_pivot[e]];
+        const double l = w / piv;
+        if (!(fabs(piv) >= PIVOT_MIN) || (w != 0.0 && !(fabs(l) <= PIVOT_GROWTH_MAX))) g_sh.bad = 1;
+        W[off_L + e] = l;
+      }
+      __syncthreads();
+      seg_run<SEG_PROD_SUB>(plan_g(net->schur[r]), Wc, W, SegExtraG{});
+      __syncthreads();
+    }
+  }
+  if (g_cx.solve_mode != RES_SOLVE_PLAIN) {
+    for (int i = tid; i < ns; i += RES_WG) W[off_dinv + i] = 1.0 / W[off_diag + i];
+    __syncthreads();
+    gci_t* mep = glob(net->mono_ent_ptr); gci_t* mp = glob(net->mono_ptr); gci_t* mf = glob(net->mono_fac); gci_t* md = glob(net->mono_dst);
+    gcf_t* ms = glob(net->mono_sign);
+    for (int e = tid; e < g_cx.n_mono_ent; e += RES_WG) {
+      double acc = 0.0;
+      for (int32_t mo = mep[e]; mo < mep[e + 1]; mo++) {
+        double prod = (double)ms[mo];
+        for (int32_t f = mp[mo]; f < mp[mo + 1]; f++) prod *= W[mf[f]];
+        acc += prod;
+      }
+      W[md[e]] = acc;
+    }
+    __syncthreads();
+    if (g_cx.solve_mode == RES_SOLVE_FUSED) {
+      seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_LZ), Wc, W, SegExtraG{});
+      seg_run<SEG_PROD_NEG>(hot_plan(PL_NVU), Wc, W, SegExtraG{});
+      __syncthreads();
+    }
+  }
+  if (m > 0) { RES_PROF(PF_GJ); gj_blocked(W + off_S, glob(g_cx.T.gj_scratch), mpad, g_cx.m16); }
+  if (keep_diag) {
+    gd_t* jd = glob(g_cx.T.jd) + (size_t)slot * g_cx.N;
+    gci_t* j_diag = glob(net->j_diag);
+    for (int i = tid; i < g_cx.N; i += RES_WG) jd[i] = jv[j_diag[i]];
+  }
+  __syncthreads();
+  const bool bad = g_sh.bad != 0;
+  __syncthreads();
+  return bad;
+}
+
+// x = S^-1 y2 (one wavefront per row; solver_kernels.hip: gemv_kernel)
+__device__ __forceinline__ void gemv_wg(gcd_t* S, int ld, int m, gcd_t* y2, gd_t* x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = wave; row < m; row += RES_WAVES) {
+    gcd_t* a = S + (size_t)row * ld;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int j = lane;
+    for (; j + 192 < m; j += 256) {
+      const double a0 = a[j], a1 = a[j + 64], a2 = a[j + 128], a3 = a[j + 192];
+      const double y0 = y2[j], y1 = y2[j + 64], y2v = y2[j + 128], y3 = y2[j + 192];
+      acc0 += a0 * y0; acc1 += a1 * y1; acc2 += a2 * y2v; acc3 += a3 * y3;
+    }
+    for (; j < m; j += 64) acc0 += a[j] * y2[j];
+    const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+    if (lane == 0) x[row] = acc;
+  }
+  __syncthreads();
+}
+
+// M x = b with the factors in W: b at W[yloc], x at W[xloc] (SparseLU::solve)
+__device__ __forceinline__ void solve_wg(gd_t* W) {
+  const SegExtraG ex{};
+  gcd_t* Wc = (gcd_t*)W;
+  const ResNetDev* net = g_cx.net;
+  gcd_t* Sinv = Wc + g_cx.off_S;
+  const int m = g_cx.m, mpad = g_cx.mpad, ns = g_cx.ns;
+  if (g_cx.solve_mode == RES_SOLVE_FUSED) {
+    seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_STAGEA), Wc, W, ex); __syncthreads();
+    gemv_wg(Sinv, mpad, m, Wc + g_cx.off_y + ns, W + g_cx.off_x);
+    seg_run<SEG_PROD_SET>(hot_plan(PL_STAGEC), Wc, W, ex); __syncthreads();
+  } else if (g_cx.solve_mode == RES_SOLVE_EXPLICIT) {
+    seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_FWDZ), Wc, W, ex); __syncthreads();
+    if (m > 0) {
+      seg_run<SEG_PROD_SUB>(hot_plan(PL_FWD_DENSE), Wc, W, ex); __syncthreads();
+      gemv_wg(Sinv, mpad, m, Wc + g_cx.off_y + ns, W + g_cx.off_x);
+    }
+    seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_BWDT), Wc, W, ex); __syncthreads();
+    seg_run<SEG_PROD_SET>(hot_plan(PL_BWDV), Wc, W, ex); __syncthreads();
+  } else {
+    for (int r = 1; r < g_cx.nrounds; r++) { seg_run<SEG_PROD_SUB>(plan_g(net->fwd[r]), Wc, W, ex); __syncthreads(); }
+    if (m > 0) {
+      if (ns > 0) { seg_run<SEG_PROD_SUB>(hot_plan(PL_FWD_DENSE), Wc, W, ex); __syncthreads(); }
+      gemv_wg(Sinv, mpad, m, Wc + g_cx.off_y + ns, W + g_cx.off_x);
+    }
+    for (int r = g_cx.nrounds - 1; r >= 0; r--) { seg_run<SEG_PROD_SUB_DIV>(plan_g(net->bwd[r]), Wc, W, ex); __syncthreads(); }
+  }
+}
+
+// one corrector iteration: residual, solve, update, the five sums of the decision and the error test
+// (solver_kernels.hip: rates_skip_kernel, segsum<SEG_COEF_BDF>, the solve, bdf_newton_kernel)
+__device__ __noinline__ ResSums ph_newton(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
+  RES_PROF(PF_NEWTON);
+  gd_t* W = glob(g_cx.T.W) + (size_t)slot * (size_t)g_cx.w_size;
+  gd_t* y = glob(g_cx.T.y); gd_t* d = glob(g_cx.T.d);
+  {
+    RES_PROF(PF_RESID);
+    rates_into((gcd_t*)y);
+    __syncthreads();
+    SegExtraG ex;
+    ex.psi = glob((const double*)g_cx.T.psi); ex.d = (gcd_t*)d; ex.cscal = c;
+    seg_run<SEG_COEF_BDF>(hot_plan(PL_RESID), glob((const double*)g_cx.T.rate), W, ex);
+    __syncthreads();
+  }
+  { RES_PROF(PF_SOLVE); solve_wg(W); }
+  RES_PROF(PF_UPDATE);
+  const int N = g_cx.N;
+  gci_t* xloc = glob(g_cx.net->xloc);
+  gcd_t* scale = glob((const double*)g_cx.T.scale); gcd_t* D = glob((const double*)g_cx.T.D);
+  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < N; i += RES_WG) {
+    const double dy = upd * W[xloc[i]];
+    const double q = dy / scale[i];
+    v[0] += q * q;
+    const double yy = y[i] + dy, dd = d[i] + dy;
+    if (yy < 0.0) v[4] = 1.0;
+    const double sce = atol + rtol * fabs(yy);
+    const double e = ec * dd / sce;
+    v[1] += e * e + (isfinite(yy) ? 0.0 : INFINITY);
+    if (order > 1) { const double em = ec_m * (D[(size_t)order * N + i] + dd) / sce; v[2] += em * em; }
+    if (order < RES_MAX_ORDER) { const double ep = ec_p * (dd - D[(size_t)(order + 1) * N + i]) / sce; v[3] += ep * ep; }
+    y[i] = yy; d[i] = dd;
+  }
+  wg_reduce<5>(v);
+  return ResSums{v[0], v[1], v[2], v[3], v[4]};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the backend handed to the controller (wavefront 0): posts a phase to the other wavefronts and runs it with them; the slot
+// table of the LU cache in its registers
+// ------------------------------------------------------------------------------------------------------------------
+enum CmdOp : int { OP_EXIT = 0, OP_VEC, OP_SAVE_Y, OP_APPLY_RATES, OP_RHS, OP_JAC, OP_NORMS, OP_INIT_D, OP_PREDICT, OP_CHANGE_D, OP_ACCEPT,
+                   OP_INTERP, OP_DRIFT, OP_FACTOR, OP_NEWTON };
+struct DevBackend {
+  __device__ int lane() const { return threadIdx.x & 63; }
+  __device__ int n_species() const { return g_cx.N; }
+  __device__ void profile_out(int64_t* out) const {
+    for (int i = 0; i < 12; i++) out[i] = g_sh.prof[i];   // written by thread 0 only: this wavefront's own stores
+  }
+
+  // ---- slot table (g_sl)
+  __device__ double slot_c_fact(int i) const { return g_sl.c_fact[i]; }
+  __device__ double slot_crate(int i) const { return g_sl.crate[i]; }
+  __device__ long long slot_crate_step(int i) const { return g_sl.crate_step[i]; }
+  __device__ long long slot_crate_restart(int i) const { return g_sl.crate_restart[i]; }
+  __device__ void slot_touch(int i, long long clock) { g_sl.last_use[i] = clock; }
+  __device__ void slot_rate(int i, double crate, long long step, long long restart) { g_sl.crate[i] = crate; g_sl.crate_step[i] = step; g_sl.crate_restart[i] = restart; }
+  __device__ void slot_drop(int i) { g_sl.valid[i] = 0; }
+  __device__ void slot_made(int i, double c, long long clock, long long jac_stamp, long long step_stamp) {
+    g_sl.c_fact[i] = c; g_sl.crate[i] = 1.0; g_sl.valid[i] = 1; g_sl.last_use[i] = clock; g_sl.jac_stamp[i] = jac_stamp; g_sl.step_stamp[i] = step_stamp;
+  }
+  __device__ void slots_invalidate(bool reset) {
+    g_sl.valid[lane()] = 0;
+    if (reset) { g_sl.c_fact[lane()] = 0.0; g_sl.last_use[lane()] = 0; g_sl.crate[lane()] = 1.0; g_sl.crate_step[lane()] = 0; g_sl.crate_restart[lane()] = -1;
+                 g_sl.jac_stamp[lane()] = 0; g_sl.step_stamp[lane()] = 0; }
+  }
+  // slot whose c_fact is closest (in ratio) to c and within the band, lowest index on ties; -1: none (Solver::nearest_slot)
+  __device__ int nearest_slot(double c, double band, long long n_restarts, long long max_age) const {
+    const double cf = g_sl.c_fact[lane()];
+    const bool ok = lane() < g_cx.n_slots && g_sl.valid[lane()] && n_restarts - g_sl.jac_stamp[lane()] <= max_age && fabs(c / cf - 1.0) <= band;
+    double r = ok ? fabs(log(c / cf)) : 1e300;
+    if (!(r < 1e300)) r = 1e300;
+    int idx = lane();
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double r2 = __shfl_xor(r, off, 64);
+      const int i2 = __shfl_xor(idx, off, 64);
+      if (r2 < r || (r2 == r && i2 < idx)) { r = r2; idx = i2; }
+    }
+    return r < 1e300 ? idx : -1;
+  }
+  // a slot for a new factorisation: the first unused or expired one, else the least recently used (Solver::victim_slot)
+  __device__ int victim_slot(long long n_restarts, long long max_age, int n_slots) const {
+    const bool in = lane() < n_slots;
+    const bool free_ = in && (!g_sl.valid[lane()] || n_restarts - g_sl.jac_stamp[lane()] > max_age);
+    const unsigned long long fm = __ballot(free_);
+    if (fm) return __ffsll((long long)fm) - 1;
+    long long u = in ? g_sl.last_use[lane()] : 0x7fffffffffffffffll;
+    int idx = lane();
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const long long u2 = shfl_ll(u, lane() ^ off);
+      const int i2 = __shfl_xor(idx, off, 64);
+      if (u2 < u || (u2 == u && i2 < idx)) { u = u2; idx = i2; }
+    }
+    return idx;
+  }
+  // ---- commands: lane 0 posts the phase and its scalar arguments, the barrier releases the other wavefronts into it
+  __device__ void post(int op, int i0 = 0, int i1 = 0, int i2 = 0, long long l0 = 0, double d0 = 0.0, double d1 = 0.0, double d2 = 0.0,
+                       double d3 = 0.0, double d4 = 0.0, double d5 = 0.0, double d6 = 0.0) {
+    if (threadIdx.x == 0) {
+      g_sh.cmd_op = op; g_sh.cmd_i[0] = i0; g_sh.cmd_i[1] = i1; g_sh.cmd_i[2] = i2; g_sh.cmd_l = l0;
+      g_sh.cmd_d[0] = d0; g_sh.cmd_d[1] = d1; g_sh.cmd_d[2] = d2; g_sh.cmd_d[3] = d3; g_sh.cmd_d[4] = d4; g_sh.cmd_d[5] = d5; g_sh.cmd_d[6] = d6;
+    }
+    __syncthreads();
+  }
+  // drift guard at a restart: slots whose diag(I - c_s J) moved by more than `max_drift` are dropped; returns how many
+  __device__ int drift_check(double max_drift) {
+    g_sh.slot_valid[lane()] = g_sl.valid[lane()]; g_sh.slot_c[lane()] = g_sl.c_fact[lane()];
+    post(OP_DRIFT);
+    ph_drift();
+    const bool drop = lane() < g_cx.n_slots && g_sl.valid[lane()] && !(g_sh.drift[lane()] <= max_drift);
+    if (drop) g_sl.valid[lane()] = 0;
+    return __popcll(__ballot(drop));
+  }
+
+  // ---- vectors
+  __device__ void vec(int op, double h0) { post(OP_VEC, op, 0, 0, 0, h0); ph_vec(op, h0); }
+  __device__ void load_u0() { vec(VO_LOAD_U0, 0.0); }
+  __device__ void chunk_start_from_y() { vec(VO_CHUNK_START_FROM_Y, 0.0); }
+  __device__ void y_from_chunk_start_clipped() { vec(VO_Y_FROM_CHUNK_START_CLIPPED, 0.0); }
+  __device__ void y_from_D0() { vec(VO_Y_FROM_D0, 0.0); }
+  __device__ void ytmp_from_D0() { vec(VO_YTMP_FROM_D0, 0.0); }
+  __device__ void ytmp_axpy(double h0) { vec(VO_YTMP_AXPY, h0); }
+  __device__ void save_y(long long row, double time) { post(OP_SAVE_Y, 0, 0, 0, row, time); ph_save_y(row, time); }
+  __device__ void set_time(long long row, double time) { if (threadIdx.x == 0) glob(g_cx.T.sol_t)[row] = time; }
+  __device__ void apply_rates(long long stop) { post(OP_APPLY_RATES, 0, 0, 0, stop); ph_apply_rates(stop); }
+  __device__ void rhs_y_to_f0() { post(OP_RHS, RO_Y_TO_F0); ph_rhs(RO_Y_TO_F0); }
+  __device__ void rhs_ytmp_to_f1() { post(OP_RHS, RO_YTMP_TO_F1); ph_rhs(RO_YTMP_TO_F1); }
+  __device__ void rhs_ytmp_to_f0() { post(OP_RHS, RO_YTMP_TO_F0); ph_rhs(RO_YTMP_TO_F0); }
+  __device__ void eval_jac_y() { post(OP_JAC); ph_jac(); }
+  __device__ ResNorms norms(bool with_f1, double atol, double rtol) { post(OP_NORMS, with_f1 ? 1 : 0, 0, 0, 0, atol, rtol); return ph_norms(with_f1, atol, rtol); }
+  __device__ void init_D(bool from_ytmp, double h) { post(OP_INIT_D, from_ytmp ? 1 : 0, 0, 0, 0, h); ph_init_D(from_ytmp, h); }
+  __device__ void predict(int order, const double* gamma, double alpha_o, double atol, double rtol) {
+    (void)gamma;   // the kernel's prologue put the coefficients into g_sh.gamma
+    post(OP_PREDICT, order, 0, 0, 0, alpha_o, atol, rtol);
+    ph_predict(order, alpha_o, atol, rtol);
+  }
+  __device__ void change_D(int ord, const double (*RU)[6]) {
+    if (threadIdx.x < 36) g_sh.ru[threadIdx.x] = RU[threadIdx.x / 6][threadIdx.x % 6];
+    post(OP_CHANGE_D, ord);
+    ph_change_D(ord);
+  }
+  __device__ void accept(int order) { post(OP_ACCEPT, order); ph_accept(order); }
+  __device__ void interp(int order, const double* p, long long row) {
+    if (threadIdx.x <= RES_MAX_ORDER) g_sh.coef[threadIdx.x] = (int)threadIdx.x <= order ? p[threadIdx.x] : 0.0;
+    post(OP_INTERP, order, 0, 0, row);
+    ph_interp(order, row);
+  }
+  __device__ bool factor(int slot, double c, bool keep_diag) { post(OP_FACTOR, slot, keep_diag ? 1 : 0, 0, 0, c); return ph_factor(slot, c, keep_diag); }
+  __device__ ResSums newton_iter(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
+    post(OP_NEWTON, slot, order, 0, 0, c, upd, ec, ec_m, ec_p, atol, rtol);
+    return ph_newton(slot, c, upd, order, ec, ec_m, ec_p, atol, rtol);
+  }
+};
+
+// what the fifteen other wavefronts do: wait for a command, run its phase, until the leader posts OP_EXIT
+__device__ void worker_loop() {
+  for (;;) {
+    __syncthreads();
+    const int op = g_sh.cmd_op;
+    if (op == OP_EXIT) return;
+    const int i0 = g_sh.cmd_i[0], i1 = g_sh.cmd_i[1];
+    const long long l0 = g_sh.cmd_l;
+    const double d0 = g_sh.cmd_d[0], d1 = g_sh.cmd_d[1], d2 = g_sh.cmd_d[2], d3 = g_sh.cmd_d[3], d4 = g_sh.cmd_d[4], d5 = g_sh.cmd_d[5], d6 = g_sh.cmd_d[6];
+    switch (op) {
+      case OP_VEC: ph_vec(i0, d0); break;
+      case OP_SAVE_Y: ph_save_y(l0, d0); break;
+      case OP_APPLY_RATES: ph_apply_rates(l0); break;
+      case OP_RHS: ph_rhs(i0); break;
+      case OP_JAC: ph_jac(); break;
+      case OP_NORMS: (void)ph_norms(i0 != 0, d0, d1); break;
+      case OP_INIT_D: ph_init_D(i0 != 0, d0); break;
+      case OP_PREDICT: ph_predict(i0, d0, d1, d2); break;
+      case OP_CHANGE_D: ph_change_D(i0); break;
+      case OP_ACCEPT: ph_accept(i0); break;
+      case OP_INTERP: ph_interp(i0, l0); break;
+      case OP_DRIFT: ph_drift(); break;
+      case OP_FACTOR: (void)ph_factor(i0, d0, i1 != 0); break;
+      case OP_NEWTON: (void)ph_newton(i0, d0, d1, i1, d2, d3, d4, d5, d6); break;
+      default: break;
+    }
+  }
+}
+
+// counts of medium rows with more than 64 / more than 32 entries (the rows are sorted longest first); all threads
+__device__ __forceinline__ void count_splits(int id) {
+  const SegPlanView& p = g_cx.plan[id];
+  gci_t* sb = glob(p.seg_beg); gci_t* se = glob(p.seg_end);
+  int c64 = 0, c32 = 0;
+  for (int r = threadIdx.x; r < p.S; r += RES_WG) { const int len = se[r] - sb[r]; c64 += len > 64; c32 += len > 32; }
+  for (int off = 32; off >= 1; off >>= 1) { c64 += __shfl_down(c64, off, 64); c32 += __shfl_down(c32, off, 64); }
+  if ((threadIdx.x & 63) == 0 && (c64 | c32)) { atomicAdd(&g_cx.split[id][0], c64); atomicAdd(&g_cx.split[id][1], c32); }
+}
+
+__shared__ __attribute__((aligned(16))) unsigned char g_ctl_mem[sizeof(ResidentBdf<DevBackend>)];
+
+__global__ __launch_bounds__(RES_WG) void resident_bdf_kernel(const ResNetDev* __restrict__ net_p, const ResTrajDev* __restrict__ traj,
+                                                               const ResParams* __restrict__ par_p) {
+  if (threadIdx.x == 0) {
+    const ResNetDev& n = *net_p;
+    g_par = *par_p;
+    g_cx.T = traj[blockIdx.x];
+    g_cx.net = net_p;
+    g_cx.plan[PL_RHS] = n.rhs_plan; g_cx.plan[PL_JAC] = n.jac_plan; g_cx.plan[PL_RESID] = n.resid_plan;
+    g_cx.plan[PL_LZ] = n.lz_build; g_cx.plan[PL_NVU] = n.nvu_build; g_cx.plan[PL_STAGEA] = n.stageA; g_cx.plan[PL_STAGEC] = n.stageC;
+    g_cx.plan[PL_FWDZ] = n.fwdZ; g_cx.plan[PL_FWD_DENSE] = n.fwd_dense; g_cx.plan[PL_BWDT] = n.bwdT; g_cx.plan[PL_BWDV] = n.bwdV;
+    for (int i = 0; i < PL_COUNT; i++) { g_cx.split[i][0] = 0; g_cx.split[i][1] = 0; }
+    g_cx.profile = par_p->profile;
+    g_cx.N = n.N; g_cx.R = n.R; g_cx.nnzJ = n.nnzJ; g_cx.ns = n.ns; g_cx.m = n.m; g_cx.m16 = (n.m + 15) / 16 * 16; g_cx.mpad = n.mpad;
+    g_cx.nrounds = n.nrounds; g_cx.n_mono_ent = n.n_mono_ent; g_cx.solve_mode = n.solve_mode; g_cx.has_kmax = n.has_kmax;
+    g_cx.n_slots = par_p->n_slots; g_cx.rate_mode = par_p->rate_mode;
+    g_cx.off_diag = n.off_diag; g_cx.off_U = n.off_U; g_cx.off_L = n.off_L; g_cx.off_S = n.off_S; g_cx.off_y = n.off_y; g_cx.off_x = n.off_x;
+    g_cx.off_dinv = n.off_dinv; g_cx.w_size = n.w_size;
+    g_cx.k_max = n.k_max; g_cx.t_mult = n.t_mult;
+  }
+  if (threadIdx.x < 12) g_sh.prof[threadIdx.x] = 0;
+  __syncthreads();
+  for (int id = 0; id < PL_COUNT; id++) count_splits(id);
+  __syncthreads();
+  if (threadIdx.x >= 64) { worker_loop(); return; }
+  // the leader wavefront: controller state and parameters live in LDS (one wavefront in lockstep: no hazards), not in
+  // registers that would be spilled around every phase call
+  const long long t_begin = wall_clock64();
+  DevBackend b;
+  ResidentBdf<DevBackend>* ctl = new (g_ctl_mem) ResidentBdf<DevBackend>(b, g_par);
+  if (threadIdx.x <= RES_MAX_ORDER) g_sh.gamma[threadIdx.x] = ctl->gamma[threadIdx.x];   // (ordered by the first command's barrier)
+  ResResult r = ctl->run();
+  b.post(OP_EXIT);
+  r.prof[PF_TOTAL] = wall_clock64() - t_begin;
+  if (threadIdx.x == 0) *g_cx.T.result = r;
+}
+
+}  // namespace
+
+size_t resident_dyn_lds(int m) { const int m16 = (m + 15) / 16 * 16; return (size_t)16 * (m16 + 1) * sizeof(double); }
+
+void launch_resident(int K, int m, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s) {
+  if (K <= 0) return;
+  hipLaunchKernelGGL(resident_bdf_kernel, dim3((unsigned)K), dim3(RES_WG), resident_dyn_lds(m), s, d_net, d_traj, d_par);
+  KIN_HIP(hipGetLastError());
+}
+
+}  // namespace kin

@@ -11,9 +11,12 @@ namespace kin {
 // (blind-enqueued Newton iterations): it is loaded together with the row descriptors and tested when those
 // are back - a skipped launch (47 % of the second iterations at C3) ends after ONE round of loads instead of
 // three, an active one does not wait for the flag any longer than it waits for its descriptors anyway.
+// (The pointer and plan-view types are template parameters: the grid kernels pass plain pointers and SegPlanView, the resident
+// integrator address-space-qualified ones - pointers read from a context block are generic to the compiler and would turn
+// every access into a flat instruction.)
 struct SegPre { double o, a, b; };
-template <int OP>
-__device__ __forceinline__ SegPre seg_pre(const double* out, const double* src, int32_t dst, int32_t aux, const SegExtra& ex) {
+template <int OP, class OutP, class SrcP, class EX>
+__device__ __forceinline__ SegPre seg_pre(OutP out, SrcP src, int32_t dst, int32_t aux, const EX& ex) {
   SegPre q{0.0, 0.0, 0.0};
   if (dst < 0) return q;
   if (OP == SEG_PROD_SUB) q.o = out[dst];
@@ -22,8 +25,8 @@ __device__ __forceinline__ SegPre seg_pre(const double* out, const double* src, 
   else if (OP == SEG_COEF_BDF) { q.a = ex.psi[aux]; q.b = ex.d[aux]; }
   return q;
 }
-template <int OP>
-__device__ __forceinline__ void seg_store(double* out, int32_t dst, double acc, const SegPre& q, const SegExtra& ex) {
+template <int OP, class OutP, class EX>
+__device__ __forceinline__ void seg_store(OutP out, int32_t dst, double acc, const SegPre& q, const EX& ex) {
   if (OP == SEG_COEF_SET) out[dst] = acc;
   else if (OP == SEG_PROD_SUB) out[dst] = q.o - acc;
   else if (OP == SEG_PROD_SUB_DIV) out[dst] = (q.o - acc) / q.a;
@@ -44,12 +47,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // One round of NX entries per lane: all index loads, then all gathers, then the sum in slot order (two dependent loads on
 // the critical path). `idx_of(x)` = payload index of this lane's x-th entry, or -1. ELL = entries of an ELL group (padding
 // inside the group is marked in the payload), else the contiguous payload of medium / long rows.
-template <int OP, int NX, bool ELL, class F>
-__device__ __forceinline__ double seg_gather(const SegPlanView& p, const double* src, const SegExtra& ex, bool impl, F idx_of) {
+template <int OP, int NX, bool ELL, class View, class SrcP, class EX, class F>
+__device__ __forceinline__ double seg_gather(const View& p, SrcP src, const EX& ex, bool impl, F idx_of) {
   constexpr bool PROD = seg_is_prod<OP>::v;
-  const int32_t* A = ELL ? p.ell_a : p.long_a;
-  const int32_t* Bp = ELL ? p.ell_b : p.long_b;
-  const float* C = ELL ? p.ell_c : p.long_c;
+  const auto A = ELL ? p.ell_a : p.long_a;
+  const auto Bp = ELL ? p.ell_b : p.long_b;
+  const auto C = ELL ? p.ell_c : p.long_c;
   const int32_t vbase = ELL ? p.val_base : p.val_base + p.ell_total;
   float c[NX]; int32_t ia[NX], ib[NX]; double va[NX], vb[NX];
 #pragma unroll

@@ -916,22 +916,17 @@ void apply_rates(kin_network* h, const double* T_stops, bool have_table, int64_t
 
 }  // namespace
 
-int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
-                const double* k_table, int64_t n_stops, kin_stats* stats, const double* t_nodes, const double* T_nodes,
-                int64_t n_nodes, bool explicit_solver) {
-  auto wall0 = std::chrono::steady_clock::now();
-  const int64_t N = h->host.N, R = h->host.R;
+void validate_solve(kin_network* h, const kin_params& p, const double* tstops, const double* T_stops, const double* k_table,
+                    int64_t n_stops, const double* t_nodes, const double* T_nodes, int64_t n_nodes, bool need_handle_rates) {
   // ---- validation (ODESimulationParams constructor, params.jl:77-104)
   if (!(p.tspan0 < p.tspan1)) throw KinError(ERR_INVALID_ARG, "Invalid time span");
   if (!(p.abstol > 0) || !(p.reltol > 0)) throw KinError(ERR_INVALID_ARG, "tolerances must be positive");
-  int64_t n_chunks = 1;
   const bool chunks = p.solve_chunks != 0;
   const bool has_save = p.save_interval >= 0;
   if (chunks) {
     if (!(p.solve_chunkstep > 0)) throw KinError(ERR_INVALID_ARG, "solve_chunkstep must be positive");
     const double q = p.tspan1 / p.solve_chunkstep;   // Int(tspan[2] / solve_chunkstep) must be exact (params.jl:89-99)
     if (q != std::floor(q) || q < 1) throw KinError(ERR_INVALID_ARG, "Simulation timespan is not divisible by requested chunkwise simulation step size");
-    n_chunks = (int64_t)q;
     if (has_save && p.save_interval > p.solve_chunkstep) throw KinError(ERR_INVALID_ARG, "Solution save interval must be less than chunkwise simulation step size");
     if (has_save && !(p.save_interval > 0)) throw KinError(ERR_INVALID_ARG, "save_interval must be positive");
   }
@@ -950,8 +945,27 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
     if (!k_table && !h->has_arrhenius) throw KinError(ERR_STATE, "T_stops given but Arrhenius parameters were never set");
     for (int64_t i = 1; i < n_stops; i++)
       if (!(tstops[i] > tstops[i - 1])) throw KinError(ERR_INVALID_ARG, "tstops must be strictly increasing");
-  } else if (!continuous && !h->has_rates) {
+  } else if (!continuous && need_handle_rates && !h->has_rates) {
     throw KinError(ERR_STATE, "rates were never set");
+  }
+}
+
+int solve_entry(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
+                const double* k_table, int64_t n_stops, kin_stats* stats, const double* t_nodes, const double* T_nodes,
+                int64_t n_nodes, bool explicit_solver) {
+  auto wall0 = std::chrono::steady_clock::now();
+  const int64_t N = h->host.N, R = h->host.R;
+  validate_solve(h, p, tstops, T_stops, k_table, n_stops, t_nodes, T_nodes, n_nodes, true);
+  int64_t n_chunks = 1;
+  const bool chunks = p.solve_chunks != 0;
+  const bool has_save = p.save_interval >= 0;
+  if (chunks) n_chunks = (int64_t)(p.tspan1 / p.solve_chunkstep);
+  const bool continuous = n_nodes > 0;
+  const bool variable = n_stops > 0;
+  // small networks: the whole solve in one launch, one workgroup owns the trajectory (resident.cpp)
+  if (resident_eligible(h, p, continuous, explicit_solver)) {
+    if (h->k_pending) h->flush_pending_T(h->stream);
+    return resident_solve(h, p, u0, tstops, T_stops, k_table, n_stops, stats);
   }
   if (!h->solver) h->solver.reset(new Solver(h));
   Solver& S = *h->solver;
