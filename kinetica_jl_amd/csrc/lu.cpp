@@ -152,7 +152,12 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   off_S = align(off_L + nnzU);
   off_y = align(off_S + (int64_t)mpad * mpad);
   off_x = align(off_y + n);
-  int64_t w_end = align(off_x + mpad + 8);
+  // the vectors of a solve - right-hand side / solution y, x and (explicit triangular inverses) y1, t - sit in ONE
+  // contiguous window [off_y, off_vec_end): the resident integrator keeps that window in LDS
+  off_y1 = align(off_x + mpad + 8);
+  off_t = align(off_y1 + ns);
+  off_vec_end = align(off_t + ns + 8);
+  int64_t w_end = off_vec_end;
 
   // ---- explicit inverses of the sparse triangular blocks (symbolic): monomials along the elimination DAG
   struct Mono { float sign; std::vector<int32_t> fac; };
@@ -211,9 +216,7 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
       off_dinv = w_end;
       off_Z = align(off_dinv + ns);
       off_V = align(off_Z + nnzZ);
-      off_y1 = align(off_V + nnzV);
-      off_t = align(off_y1 + ns);
-      w_end = align(off_t + ns + 8);
+      w_end = align(off_V + nnzV + 8);
       int64_t ez = 0, ev = 0;
       auto emit = [&](int64_t dst_pos, const std::vector<Mono>& monos, float flip, int32_t extra) {
         for (const Mono& mo : monos) {

@@ -45,7 +45,7 @@ struct SparseLU {
   int64_t schur_macs = 0;
   std::vector<int32_t> perm, iperm, round_ptr;
   // layout of the single value array W (so every gather indexes one base pointer)
-  int64_t off_diag = 0, off_U = 0, off_L = 0, off_S = 0, off_y = 0, off_x = 0, w_size = 0;
+  int64_t off_diag = 0, off_U = 0, off_L = 0, off_S = 0, off_y = 0, off_x = 0, off_vec_end = 0, w_size = 0;
 
   // Factor values live in SLOTS: one value array W = [diag | U | L | dense Schur block | solve vectors] plus the
   // ping-pong copy of the Schur block per slot. The symbolic structure (plans, maps) is shared. Several slots = the LU

@@ -25,6 +25,7 @@ struct ResidentSolver {
   DevBuf<ResNetDev> d_net;
   bool ok = false;
   std::string why;
+  size_t dyn_lds = 0;
   // workspaces (grown on demand)
   int K_cap = 0, n_slots = 0;
   size_t per_traj = 0;
@@ -47,6 +48,8 @@ struct ResidentSolver {
     lu.analyze((int32_t)H.N, H.j_ptr, H.j_col, opt, s);
     if (lu.m > RES_MAX_DENSE) { why = "dense Schur block beyond the resident integrator's limit"; return; }
     if (lu.nrounds > RES_MAX_ROUNDS) { why = "too many elimination rounds"; return; }
+    dyn_lds = resident_dyn_lds((int)H.N, (int)H.R, lu.m, lu.off_vec_end - lu.off_y);
+    if (dyn_lds > RES_LDS_BUDGET) { why = "state, rates and solve vectors do not fit one compute unit's LDS"; return; }
     std::vector<int32_t> yl(H.N), ident(H.N);
     lu.yloc.download(yl.data(), H.N, s);
     KIN_HIP(hipStreamSynchronize(s));
@@ -57,7 +60,7 @@ struct ResidentSolver {
     hn.ns = lu.ns; hn.m = lu.m; hn.mpad = lu.mpad; hn.nrounds = lu.nrounds; hn.n_mono_ent = lu.n_mono_ent;
     hn.solve_mode = lu.fused_tri ? RES_SOLVE_FUSED : (lu.explicit_tri ? RES_SOLVE_EXPLICIT : RES_SOLVE_PLAIN);
     hn.off_diag = lu.off_diag; hn.off_U = lu.off_U; hn.off_L = lu.off_L; hn.off_S = lu.off_S; hn.off_y = lu.off_y; hn.off_x = lu.off_x;
-    hn.off_dinv = lu.off_dinv; hn.w_size = lu.w_size;
+    hn.off_dinv = lu.off_dinv; hn.off_vec_end = lu.off_vec_end; hn.w_size = lu.w_size;
     hn.x0 = h->x0.p; hn.x1 = h->x1.p; hn.jmap = lu.jmap.p; hn.ent_pivot = lu.ent_pivot.p; hn.yloc = lu.yloc.p; hn.xloc = lu.xloc.p;
     hn.j_diag = d_jdiag.p;
     hn.mono_ent_ptr = lu.mono_ent_ptr.p; hn.mono_ptr = lu.mono_ptr.p; hn.mono_fac = lu.mono_fac.p; hn.mono_dst = lu.mono_dst.p;
@@ -165,7 +168,7 @@ void run_resident(kin_network* h, ResidentSolver& RS, const kin_params& p, const
   RS.d_net.upload(&RS.hn, 1, s);
   RS.d_par.upload(&P, 1, s);
   RS.d_traj.upload(RS.h_traj.data(), (size_t)K, s);
-  launch_resident(K, RS.lu.m, RS.d_net.p, RS.d_traj.p, RS.d_par.p, s);
+  launch_resident(K, RS.dyn_lds, RS.d_net.p, RS.d_traj.p, RS.d_par.p, s);
   res.resize(K);
   RS.d_res.download(res.data(), (size_t)K, s);
   KIN_HIP(hipStreamSynchronize(s));
@@ -219,12 +222,13 @@ int resident_solve(kin_network* h, const kin_params& p, const double* u0, const 
   KIN_HIP(hipStreamSynchronize(s));
   stats_from(RS, r, slots, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(), stats);
   if (getenv("KIN_RESIDENT_PROFILE")) {
-    static const char* names[12] = {"kernel", "factor", "(of which dense inverse)", "corrector iterations", "(solve)", "predict", "change_D",
-                                    "accept", "jacobian", "rhs", "(rates + residual)", "(update + sums)"};
+    static const char* names[20] = {"kernel", "factor", "(of which dense inverse)", "corrector attempts", "(solve)", "predict", "change_D",
+                                    "accept", "jacobian", "rhs", "(rates + residual)", "(update + sums)", "((rates))", "((stage A))", "((gemv))",
+                                    "((stage C))", "((reduce))", "(((reduce: lane sums)))", "(((reduce: first barrier)))", "(((reduce: reads + second barrier)))"};
     fprintf(stderr, "[resident] N=%lld m=%d slots=%d steps=%lld factor=%lld linsolve=%lld wall %.4f s\n", (long long)N, RS.lu.m, slots,
             (long long)r.st.n_steps, (long long)r.st.n_factor, (long long)r.st.n_linsolve,
             std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
-    for (int i = 0; i < 12; i++) fprintf(stderr, "[resident]   %-26s %9.3f ms\n", names[i], (double)r.prof[i] * 1e-5);
+    for (int i = 0; i < 20; i++) fprintf(stderr, "[resident]   %-26s %9.3f ms\n", names[i], (double)r.prof[i] * 1e-5);
   }
   return r.retcode;
 }

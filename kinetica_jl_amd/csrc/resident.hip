@@ -12,6 +12,13 @@
 //     the compiler, and generic accesses (flat_load / flat_store) cost this kernel a factor of ten in its first version.
 //   * The LU cache's slot table lives in registers, slot i in lane i of every wavefront (reads = lane broadcasts, writes =
 //     one predicated move): no shared copy, no hazard between wavefronts that run ahead of each other.
+//   * The vectors every corrector iteration touches - y, d, psi, the error weights, the reaction rates and the window of
+//     the Newton-matrix workspace that holds right-hand side, intermediate and solution of a solve (lu.cpp lays them out
+//     contiguously) - live in LDS for the whole solve: a gather from them costs an LDS access instead of an L2 round trip,
+//     and a stage's stores need no write acknowledgement before the barrier behind it. Factor values, index lists and the
+//     difference history stay in global memory (L2).
+//   * A whole corrector attempt (predictor, up to four iterations, their decisions) is ONE phase: between its iterations
+//     nothing goes back to the controller.
 //   * The dense Schur block is inverted by a blocked Gauss-Jordan (16 columns per block step, pivot block by the
 //     single-wavefront inversion the multi-workgroup path uses, rank-16 updates on the matrix cores), ping-pong between
 //     the slot's block and a scratch block of the trajectory.
@@ -23,20 +30,29 @@
 #include "gj_dev.hpp"
 #include "segsum_dev.hpp"
 
+#include <algorithm>
 #include <new>
 
 namespace kin {
 
 namespace {
 
-constexpr int RES_WG = 1024, RES_WAVES = RES_WG / 64;
+constexpr int RES_WG = 512, RES_WAVES = RES_WG / 64;
 
 #define KIN_AS1 __attribute__((address_space(1)))
 typedef KIN_AS1 double gd_t;
 typedef KIN_AS1 const double gcd_t;
 typedef KIN_AS1 const int32_t gci_t;
 typedef KIN_AS1 const float gcf_t;
-template <class T> __device__ __forceinline__ KIN_AS1 T* glob(T* p) { return (KIN_AS1 T*)p; }
+// Values read from the context block in LDS are the same in every lane, but the compiler keeps them in vector registers (a
+// pointer = 2 VGPRs in each of 64 lanes; a gather plan = 34): readfirstlane moves them to scalar registers, where the global
+// loads take them as a scalar base address - without it the gather loops of the solve spilled their pointers to scratch.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni(long long v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+template <class T> __device__ __forceinline__ KIN_AS1 T* glob(T* p) { return (KIN_AS1 T*)(unsigned long long)uni((long long)(unsigned long long)p); }
 
 // a gather plan with global-memory pointers
 struct SegPlanViewG {
@@ -52,11 +68,11 @@ __device__ __forceinline__ SegPlanViewG plan_g(const SegPlanView& p, int n64 = -
   g.seg_beg = glob(p.seg_beg); g.seg_end = glob(p.seg_end); g.seg_dst = glob(p.seg_dst); g.seg_aux = glob(p.seg_aux);
   g.blk_beg = glob(p.blk_beg); g.blk_end = glob(p.blk_end); g.blk_dst = glob(p.blk_dst); g.blk_aux = glob(p.blk_aux);
   g.long_a = glob(p.long_a); g.long_b = glob(p.long_b); g.long_c = glob(p.long_c);
-  g.G = p.G; g.S = p.S; g.B = p.B; g.val_base = p.val_base; g.ell_total = p.ell_total;
-  g.n64 = n64 < 0 ? p.S : n64; g.n32 = n32 < 0 ? p.S : n32;   // unknown split: every medium row by a whole wavefront
+  g.G = uni(p.G); g.S = uni(p.S); g.B = uni(p.B); g.val_base = uni(p.val_base); g.ell_total = uni(p.ell_total);
+  g.n64 = n64 < 0 ? g.S : uni(n64); g.n32 = n32 < 0 ? g.S : uni(n32);   // unknown split: every medium row by a whole wavefront
   return g;
 }
-struct SegExtraG { gcd_t* psi = nullptr; gcd_t* d = nullptr; double cscal = 0.0; };
+struct SegExtraG { const double* psi = nullptr; const double* d = nullptr; double cscal = 0.0; };   // (LDS vectors)
 
 // hot gather plans kept in LDS (the per-round plans of the factorisation stay in global memory)
 enum : int { PL_RHS = 0, PL_JAC, PL_RESID, PL_LZ, PL_NVU, PL_STAGEA, PL_STAGEC, PL_FWDZ, PL_FWD_DENSE, PL_BWDT, PL_BWDV, PL_COUNT };
@@ -68,6 +84,8 @@ struct ResCtx {
   SegPlanView plan[PL_COUNT];
   int32_t split[PL_COUNT][2];   // n64, n32 of the hot plans (counted once by the kernel's prologue)
   int32_t profile;
+  int32_t l_y, l_d, l_psi, l_scale, l_win, l_rate;   // offsets (doubles) of the LDS-resident vectors in g_dyn
+  int64_t off_vec_end;
   int32_t N, R, nnzJ, ns, m, m16, mpad, nrounds, n_mono_ent, solve_mode, has_kmax, n_slots, rate_mode;
   int64_t off_diag, off_U, off_L, off_S, off_y, off_x, off_dinv, w_size;
   double k_max, t_mult;
@@ -80,12 +98,13 @@ struct ResShared {
   double drift[RES_MAX_SLOTS], slot_c[RES_MAX_SLOTS];
   int slot_valid[RES_MAX_SLOTS];
   double pinv[16][17];
-  long long prof[12];
+  long long prof[20];
   int bad;
   // command of the leader wavefront to the fifteen others (see resident_bdf_kernel)
   int cmd_op, cmd_i[3];
   long long cmd_l;
   double cmd_d[8];
+  ResCorrIn corr;   // the corrector attempt being run (OP_CORRECTOR)
 };
 
 // LU-cache slot table (Solver's per-slot bookkeeping): only the leader wavefront touches it - its 64 lanes execute in
@@ -100,35 +119,66 @@ __shared__ ResCtx g_cx;
 __shared__ ResShared g_sh;
 __shared__ ResSlots g_sl;
 __shared__ ResParams g_par;
-extern __shared__ double g_dyn[];   // row panel of the dense inverse: 16 x (m16 + 1) doubles
+// dynamic LDS: y | d | psi | scale | solve-vector window of W | rates (the dense inverse's row panel, 16 x (m16 + 1), reuses
+// the rates' place: no rates are live during a factorisation)
+extern __shared__ double g_dyn[];
+__device__ __forceinline__ double* L_y() { return g_dyn + uni(g_cx.l_y); }
+__device__ __forceinline__ double* L_d() { return g_dyn + uni(g_cx.l_d); }
+__device__ __forceinline__ double* L_psi() { return g_dyn + uni(g_cx.l_psi); }
+__device__ __forceinline__ double* L_scale() { return g_dyn + uni(g_cx.l_scale); }
+__device__ __forceinline__ double* L_rate() { return g_dyn + uni(g_cx.l_rate); }
+// the window, addressed with positions of the workspace W: L_win()[p] for off_y <= p < off_vec_end
+__device__ __forceinline__ double* L_win() { return g_dyn + uni(g_cx.l_win) - uni((long long)g_cx.off_y); }
 
 // phase kinds of the in-kernel profile (ResResult::prof, 10 ns ticks, thread 0's clock)
 enum ProfId : int { PF_TOTAL = 0, PF_FACTOR = 1, PF_GJ = 2, PF_NEWTON = 3, PF_SOLVE = 4, PF_PREDICT = 5, PF_CHANGE_D = 6, PF_ACCEPT = 7,
-                    PF_JAC = 8, PF_RHS = 9, PF_RESID = 10, PF_UPDATE = 11 };
+                    PF_JAC = 8, PF_RHS = 9, PF_RESID = 10, PF_UPDATE = 11, PF_RATES = 12, PF_STAGEA = 13, PF_GEMV = 14, PF_STAGEC = 15,
+                    PF_REDUCE = 16, PF_CTL_CORR = 17 };
 struct ProfScope {   // (off unless KIN_RESIDENT_PROFILE is set: the clock reads cost ~0.3 us each)
   int id; long long t0;
-  __device__ ProfScope(int i) : id(i), t0(g_cx.profile ? wall_clock64() : 0) {}
-  __device__ ~ProfScope() { if (g_cx.profile && threadIdx.x == 0) g_sh.prof[id] += wall_clock64() - t0; }
+  __device__ __forceinline__ ProfScope(int i) : id(i), t0(g_cx.profile ? wall_clock64() : 0) {}
+  __device__ __forceinline__ ~ProfScope() { if (g_cx.profile && threadIdx.x == 0) g_sh.prof[id] += wall_clock64() - t0; }
 };
 #define RES_PROF(id) ProfScope prof_scope_##id(id)
 
-__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ long long shfl_ll(long long v, int src) {
   const int lo = __shfl((int)(v & 0xffffffffll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+// Sums over lanes by DPP row shifts and row broadcasts (tools/wg_latency_probe.hip: five sums 0.26 us, by ds_bpermute
+// 0.72 us - the LDS crossbar is shared by the CU's sixteen wavefronts). dpp_sum<64>: total in lane 63; <16> / <8>: the total of
+// every group of 16 / 8 lanes in the group's last lane. Fixed order: bitwise reproducible.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int LANES>
+__device__ __forceinline__ double dpp_sum(double v) {
+  v += dpp_mov<0x111>(v);                    // row_shr:1
+  v += dpp_mov<0x112>(v);                    // row_shr:2
+  v += dpp_mov<0x114>(v);                    // row_shr:4
+  if (LANES >= 16) v += dpp_mov<0x118>(v);   // row_shr:8
+  if (LANES >= 64) { v += dpp_mov<0x142>(v); v += dpp_mov<0x143>(v); }   // row_bcast:15, row_bcast:31
+  return v;
+}
 // NV sums over the workgroup, the same value in every thread (fixed order: bitwise reproducible)
 template <int NV>
 __device__ __forceinline__ void wg_reduce(double (&v)[NV]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool pf = NV == 5 && g_cx.profile && threadIdx.x == 0;
+  long long c0 = pf ? wall_clock64() : 0;
 #pragma unroll
-  for (int q = 0; q < NV; q++) v[q] = wave_sum(v[q]);
-  if (lane == 0) {
+  for (int q = 0; q < NV; q++) v[q] = dpp_sum<64>(v[q]);
+  if (lane == 63) {
 #pragma unroll
     for (int q = 0; q < NV; q++) g_sh.red[wave][q] = v[q];
   }
+  long long c1 = pf ? wall_clock64() : 0;
   __syncthreads();
+  long long c2 = pf ? wall_clock64() : 0;
 #pragma unroll
   for (int q = 0; q < NV; q++) {
     double t = 0.0;
@@ -137,29 +187,30 @@ __device__ __forceinline__ void wg_reduce(double (&v)[NV]) {
     v[q] = t;
   }
   __syncthreads();
+  if (pf) { const long long c3 = wall_clock64(); g_sh.prof[17] += c1 - c0; g_sh.prof[18] += c2 - c1; g_sh.prof[19] += c3 - c2; }
 }
 
 // The in-workgroup executor of a gather plan (kernels.hip: segsum_kernel spreads the same tasks over a grid): wavefront
 // tasks round robin over the 16 wavefronts - long rows first (one wavefront walks such a row 512 entries per pass: no
 // workgroup-wide reduction inside a phase), then medium rows, then the ELL groups of short rows.
 // one group of LANES lanes per medium row (4 entries per lane), 64 / LANES rows per wavefront task
-template <int OP, int LANES>
-__device__ __forceinline__ void seg_rows_grouped(const SegPlanViewG& p, gcd_t* src, gd_t* out, const SegExtraG& ex, bool impl, int row0, int row_end) {
+// srcA / srcB: arrays of the first / second factor (segsum_dev.hpp: seg_gather2), auxp: array of the `aux` operand
+template <int OP, int LANES, class SA, class SB, class OP_, class AP>
+__device__ __forceinline__ void seg_rows_grouped(const SegPlanViewG& p, SA srcA, SB srcB, OP_ out, AP auxp, const SegExtraG& ex, bool impl, int row0, int row_end) {
   const int lane = threadIdx.x & 63;
   const int g = lane / LANES, l = lane % LANES;
   const int sidx = row0 + g;
   const bool have = sidx < row_end;
   const int32_t e0 = have ? p.seg_beg[sidx] : 0, e1 = have ? p.seg_end[sidx] : 0;
   const int32_t dst = have ? p.seg_dst[sidx] : -1, aux = have ? p.seg_aux[sidx] : 0;
-  const SegPre pre = seg_pre<OP>(out, src, l == 0 ? dst : -1, aux, ex);
-  double acc = seg_gather<OP, 4, false>(p, src, ex, impl, [&](int x) { const int32_t e = e0 + l + LANES * x; return e < e1 ? e : -1; });
-#pragma unroll
-  for (int off = LANES / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (l == 0 && dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
+  const SegPre pre = seg_pre<OP>(out, auxp, l == LANES - 1 ? dst : -1, aux, ex);
+  double acc = seg_gather2<OP, 4, false>(p, srcA, srcB, ex, impl, [&](int x) { const int32_t e = e0 + l + LANES * x; return e < e1 ? e : -1; });
+  acc = dpp_sum<LANES>(acc);
+  if (l == LANES - 1 && dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
 }
 
-template <int OP>
-__device__ __forceinline__ void seg_run(const SegPlanViewG& p, gcd_t* src, gd_t* out, const SegExtraG& ex) {
+template <int OP, class SA, class SB, class OP_, class AP>
+__device__ __forceinline__ void seg_run(const SegPlanViewG& p, SA srcA, SB srcB, OP_ out, AP auxp, const SegExtraG& ex) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool impl = p.val_base >= 0;
   // task list: long rows, medium rows > 64 entries (a wavefront each), 33 .. 64 (four per wavefront), 9 .. 32 (eight per
@@ -169,40 +220,44 @@ __device__ __forceinline__ void seg_run(const SegPlanViewG& p, gcd_t* src, gd_t*
     if (task < t1) {
       const int r = task;
       const int32_t e0 = p.blk_beg[r], e1 = p.blk_end[r], dst = p.blk_dst[r], aux = p.blk_aux[r];
-      const SegPre pre = seg_pre<OP>(out, src, lane == 0 ? dst : -1, aux, ex);
+      const SegPre pre = seg_pre<OP>(out, auxp, lane == 63 ? dst : -1, aux, ex);
       double acc = 0.0;
       for (int32_t base = e0; base < e1; base += 512)
-        acc += seg_gather<OP, 8, false>(p, src, ex, impl, [&](int x) { const int32_t e = base + lane + 64 * x; return e < e1 ? e : -1; });
-      acc = wave_sum(acc);
-      if (lane == 0) seg_store<OP>(out, dst, acc, pre, ex);
+        acc += seg_gather2<OP, 8, false>(p, srcA, srcB, ex, impl, [&](int x) { const int32_t e = base + lane + 64 * x; return e < e1 ? e : -1; });
+      acc = dpp_sum<64>(acc);
+      if (lane == 63) seg_store<OP>(out, dst, acc, pre, ex);
     } else if (task < t2) {
-      seg_rows_grouped<OP, 64>(p, src, out, ex, impl, task - t1, p.n64);
+      seg_rows_grouped<OP, 64>(p, srcA, srcB, out, auxp, ex, impl, task - t1, p.n64);
     } else if (task < t3) {
-      seg_rows_grouped<OP, 16>(p, src, out, ex, impl, p.n64 + 4 * (task - t2), p.n32);
+      seg_rows_grouped<OP, 16>(p, srcA, srcB, out, auxp, ex, impl, p.n64 + 4 * (task - t2), p.n32);
     } else if (task < t4) {
-      seg_rows_grouped<OP, 8>(p, src, out, ex, impl, p.n32 + 8 * (task - t3), p.S);
+      seg_rows_grouped<OP, 8>(p, srcA, srcB, out, auxp, ex, impl, p.n32 + 8 * (task - t3), p.S);
     } else {
       const int g = task - t4;
       const int32_t dst = p.grp_dst[g * 64 + lane], aux = p.grp_aux[g * 64 + lane];
       const int32_t c0 = p.grp_off[g], c1 = p.grp_off[g + 1];
-      const SegPre pre = seg_pre<OP>(out, src, dst, aux, ex);
+      const SegPre pre = seg_pre<OP>(out, auxp, dst, aux, ex);
       double acc = 0.0;
       for (int32_t col = c0; col < c1; col += 8)
-        acc += seg_gather<OP, 8, true>(p, src, ex, impl, [&](int x) { return col + x < c1 ? (col + x) * 64 + lane : -1; });
+        acc += seg_gather2<OP, 8, true>(p, srcA, srcB, ex, impl, [&](int x) { return col + x < c1 ? (col + x) * 64 + lane : -1; });
       if (dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
     }
   }
 }
+// everything in one array (the factorisation's updates, the right-hand side, the Jacobian)
+template <int OP, class SP, class OP_>
+__device__ __forceinline__ void seg_run1(const SegPlanViewG& p, SP src, OP_ out, const SegExtraG& ex) { seg_run<OP>(p, src, src, out, src, ex); }
 
 __device__ __forceinline__ SegPlanViewG hot_plan(int id) { return plan_g(g_cx.plan[id], g_cx.split[id][0], g_cx.split[id][1]); }
 
 // ------------------------------------------------------------------------------------------------------------------
-// phases (each called by all 1 024 threads; every one ends behind a barrier)
+// phases (each called by all 1 024 threads; every one ends behind a barrier). y, d, psi, scale, the rates and the solve
+// window are LDS arrays (L_y() ...), everything else global
 // ------------------------------------------------------------------------------------------------------------------
 enum VecOp : int { VO_LOAD_U0 = 0, VO_CHUNK_START_FROM_Y, VO_Y_FROM_CHUNK_START_CLIPPED, VO_Y_FROM_D0, VO_YTMP_FROM_D0, VO_YTMP_AXPY };
 __device__ __noinline__ void ph_vec(int op, double h0) {
-  const int N = g_cx.N, tid = threadIdx.x;
-  gd_t* y = glob(g_cx.T.y);
+  const int N = uni(g_cx.N), tid = threadIdx.x;
+  double* y = L_y();
   if (op == VO_LOAD_U0) { gcd_t* u0 = glob(g_cx.T.u0); for (int i = tid; i < N; i += RES_WG) y[i] = u0[i]; }
   else if (op == VO_CHUNK_START_FROM_Y) { gd_t* cs = glob(g_cx.T.chunk_start); for (int i = tid; i < N; i += RES_WG) cs[i] = y[i]; }
   else if (op == VO_Y_FROM_CHUNK_START_CLIPPED) {
@@ -216,8 +271,8 @@ __device__ __noinline__ void ph_vec(int op, double h0) {
 }
 
 __device__ __noinline__ void ph_save_y(long long row, double time) {
-  const int N = g_cx.N;
-  gcd_t* y = glob((const double*)g_cx.T.y);
+  const int N = uni(g_cx.N);
+  const double* y = L_y();
   gd_t* o = glob(g_cx.T.sol) + (size_t)row * N;
   for (int i = threadIdx.x; i < N; i += RES_WG) o[i] = y[i];
   if (threadIdx.x == 0) glob(g_cx.T.sol_t)[row] = time;
@@ -225,7 +280,7 @@ __device__ __noinline__ void ph_save_y(long long row, double time) {
 }
 
 __device__ __noinline__ void ph_apply_rates(long long stop) {
-  const int R = g_cx.R;
+  const int R = uni(g_cx.R);
   gd_t* k = glob(g_cx.T.k);
   const ResNetDev* net = g_cx.net;
   if (g_cx.rate_mode == 1) {
@@ -240,11 +295,13 @@ __device__ __noinline__ void ph_apply_rates(long long stop) {
   __syncthreads();
 }
 
-// mass-action rates of state u into T.rate (make_rs, solve_utils.jl:318-334); no barrier inside
-__device__ __forceinline__ void rates_into(gcd_t* u) {
-  const int R = g_cx.R;
+// mass-action rates of state u into the LDS rate array (make_rs, solve_utils.jl:318-334); no barrier inside
+template <class UP>
+__device__ __forceinline__ void rates_into(UP u) {
+  const int R = uni(g_cx.R);
   gci_t* x0 = glob(g_cx.net->x0); gci_t* x1 = glob(g_cx.net->x1);
-  gcd_t* k = glob((const double*)g_cx.T.k); gd_t* rate = glob(g_cx.T.rate);
+  gcd_t* k = glob((const double*)g_cx.T.k);
+  double* rate = L_rate();
   for (int r = threadIdx.x; r < R; r += RES_WG) {
     const int32_t a = x0[r], b = x1[r];
     const double ub = b >= 0 ? u[b] : 1.0;
@@ -255,19 +312,20 @@ __device__ __forceinline__ void rates_into(gcd_t* u) {
 enum RhsOp : int { RO_Y_TO_F0 = 0, RO_YTMP_TO_F1, RO_YTMP_TO_F0 };
 __device__ __noinline__ void ph_rhs(int op) {
   RES_PROF(PF_RHS);
-  gcd_t* u = glob((const double*)(op == RO_Y_TO_F0 ? g_cx.T.y : g_cx.T.ytmp));
   gd_t* out = glob(op == RO_YTMP_TO_F1 ? g_cx.T.f1 : g_cx.T.f0);
-  rates_into(u);
+  if (op == RO_Y_TO_F0) rates_into((const double*)L_y());
+  else rates_into(glob((const double*)g_cx.T.ytmp));
   __syncthreads();
-  seg_run<SEG_COEF_SET>(hot_plan(PL_RHS), glob((const double*)g_cx.T.rate), out, SegExtraG{});
+  const double* rate = L_rate();
+  seg_run<SEG_COEF_SET>(hot_plan(PL_RHS), rate, rate, out, rate, SegExtraG{});
   __syncthreads();
 }
 
 // analytic Jacobian at y into T.jv (CSR values)
 __device__ __noinline__ void ph_jac() {
   RES_PROF(PF_JAC);
-  const int R = g_cx.R;
-  gcd_t* u = glob((const double*)g_cx.T.y);
+  const int R = uni(g_cx.R);
+  const double* u = L_y();
   gci_t* x0 = glob(g_cx.net->x0); gci_t* x1 = glob(g_cx.net->x1);
   gcd_t* k = glob((const double*)g_cx.T.k); gd_t* dr = glob(g_cx.T.dr);
   for (int r = threadIdx.x; r < R; r += RES_WG) {
@@ -280,13 +338,14 @@ __device__ __noinline__ void ph_jac() {
     dr[2 * r] = d0; dr[2 * r + 1] = d1;
   }
   __syncthreads();
-  seg_run<SEG_COEF_SET>(hot_plan(PL_JAC), glob((const double*)g_cx.T.dr), glob(g_cx.T.jv), SegExtraG{});
+  seg_run1<SEG_COEF_SET>(hot_plan(PL_JAC), glob((const double*)g_cx.T.dr), glob(g_cx.T.jv), SegExtraG{});
   __syncthreads();
 }
 
 __device__ __noinline__ ResNorms ph_norms(bool with_f1, double atol, double rtol) {
-  const int N = g_cx.N;
-  gcd_t* y = glob((const double*)g_cx.T.y); gcd_t* f0p = glob((const double*)g_cx.T.f0); gcd_t* f1p = glob((const double*)g_cx.T.f1);
+  const int N = uni(g_cx.N);
+  const double* y = L_y();
+  gcd_t* f0p = glob((const double*)g_cx.T.f0); gcd_t* f1p = glob((const double*)g_cx.T.f1);
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < N; i += RES_WG) {
     const double y0 = y[i], f0 = f0p[i];
@@ -302,12 +361,13 @@ __device__ __noinline__ ResNorms ph_norms(bool with_f1, double atol, double rtol
 }
 
 __device__ __noinline__ void ph_init_D(bool from_ytmp, double h) {
-  const int N = g_cx.N;
-  gcd_t* y0 = glob((const double*)(from_ytmp ? g_cx.T.ytmp : g_cx.T.y));
+  const int N = uni(g_cx.N);
+  gcd_t* yt = glob((const double*)g_cx.T.ytmp);
+  const double* y = L_y();
   gcd_t* f0 = glob((const double*)g_cx.T.f0);
   gd_t* D = glob(g_cx.T.D);
   for (int i = threadIdx.x; i < N; i += RES_WG) {
-    D[i] = y0[i];
+    D[i] = from_ytmp ? yt[i] : y[i];
     D[(size_t)N + i] = f0[i] * h;
 #pragma unroll
     for (int j = 2; j < RES_D_ROWS; j++) D[(size_t)j * N + i] = 0.0;
@@ -315,12 +375,11 @@ __device__ __noinline__ void ph_init_D(bool from_ytmp, double h) {
   __syncthreads();
 }
 
-// predictor from the backward differences (gamma in g_sh.gamma): y, psi, d = 0, scale
-__device__ __noinline__ void ph_predict(int order, double alpha_o, double atol, double rtol) {
-  RES_PROF(PF_PREDICT);
-  const int N = g_cx.N;
+// predictor from the backward differences (gamma in g_sh.gamma): y, psi, d = 0, scale; barrier behind it
+__device__ __forceinline__ void predict_body(int order, double alpha_o, double atol, double rtol) {
+  const int N = uni(g_cx.N);
   gcd_t* D = glob((const double*)g_cx.T.D);
-  gd_t* y = glob(g_cx.T.y); gd_t* psi = glob(g_cx.T.psi); gd_t* d = glob(g_cx.T.d); gd_t* scale = glob(g_cx.T.scale);
+  double* y = L_y(); double* psi = L_psi(); double* d = L_d(); double* scale = L_scale();
   for (int i = threadIdx.x; i < N; i += RES_WG) {
     double yp = D[i], ps = 0.0;
     for (int j = 1; j <= order; j++) {
@@ -335,11 +394,15 @@ __device__ __noinline__ void ph_predict(int order, double alpha_o, double atol, 
   }
   __syncthreads();
 }
+__device__ __noinline__ void ph_predict(int order, double alpha_o, double atol, double rtol) {
+  RES_PROF(PF_PREDICT);
+  predict_body(order, alpha_o, atol, rtol);
+}
 
 // D[0..ord] <- (R U)^T D[0..ord], matrix in g_sh.ru
 __device__ __noinline__ void ph_change_D(int ord) {
   RES_PROF(PF_CHANGE_D);
-  const int N = g_cx.N;
+  const int N = uni(g_cx.N);
   gd_t* D = glob(g_cx.T.D);
   for (int i = threadIdx.x; i < N; i += RES_WG) {
     double v[6], o[6];
@@ -360,9 +423,9 @@ __device__ __noinline__ void ph_change_D(int ord) {
 
 __device__ __noinline__ void ph_accept(int order) {
   RES_PROF(PF_ACCEPT);
-  const int N = g_cx.N;
+  const int N = uni(g_cx.N);
   gd_t* D = glob(g_cx.T.D);
-  gcd_t* d = glob((const double*)g_cx.T.d);
+  const double* d = L_d();
   for (int i = threadIdx.x; i < N; i += RES_WG) {
     const double di = d[i];
     D[(size_t)(order + 2) * N + i] = di - D[(size_t)(order + 1) * N + i];
@@ -378,7 +441,7 @@ __device__ __noinline__ void ph_accept(int order) {
 
 // dense output into solution row `row` (weights in g_sh.coef)
 __device__ __noinline__ void ph_interp(int order, long long row) {
-  const int N = g_cx.N;
+  const int N = uni(g_cx.N);
   gcd_t* D = glob((const double*)g_cx.T.D);
   gd_t* o = glob(g_cx.T.sol) + (size_t)row * N;
   for (int i = threadIdx.x; i < N; i += RES_WG) {
@@ -392,7 +455,7 @@ __device__ __noinline__ void ph_interp(int order, long long row) {
 // drift guard of the LU cache at a restart (solver_kernels.hip: slot_drift_kernel): g_sh.drift[s] for every valid slot
 // (validity and c_fact of the slots in g_sh.slot_valid / slot_c, written by the caller)
 __device__ __noinline__ void ph_drift() {
-  const int N = g_cx.N, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int N = uni(g_cx.N), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   gcd_t* jv = glob((const double*)g_cx.T.jv);
   gci_t* j_diag = glob(g_cx.net->j_diag);
   for (int s = wave; s < g_cx.n_slots; s += RES_WAVES) {
@@ -425,7 +488,7 @@ __device__ __forceinline__ void gj_blocked(gd_t* S, gd_t* S2, int ld, int m16) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int nb = m16 / 16, ldr = m16 + 1;
-  double* rp = g_dyn;
+  double* rp = L_rate();   // (no rates are live during a factorisation)
   gd_t* X = S;
   gd_t* Y = S2;
   for (int kb = 0; kb < nb; kb++) {
@@ -528,7 +591,7 @@ __device__ __noinline__ bool ph_factor(int slot, double c, bool keep_diag) {
         W[off_L + e] = l;
       }
       __syncthreads();
-      seg_run<SEG_PROD_SUB>(plan_g(net->schur[r]), Wc, W, SegExtraG{});
+      seg_run1<SEG_PROD_SUB>(plan_g(net->schur[r]), Wc, W, SegExtraG{});
       __syncthreads();
     }
   }
@@ -548,8 +611,8 @@ __device__ __noinline__ bool ph_factor(int slot, double c, bool keep_diag) {
     }
     __syncthreads();
     if (g_cx.solve_mode == RES_SOLVE_FUSED) {
-      seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_LZ), Wc, W, SegExtraG{});
-      seg_run<SEG_PROD_NEG>(hot_plan(PL_NVU), Wc, W, SegExtraG{});
+      seg_run1<SEG_PROD_AUXSUB>(hot_plan(PL_LZ), Wc, W, SegExtraG{});
+      seg_run1<SEG_PROD_NEG>(hot_plan(PL_NVU), Wc, W, SegExtraG{});
       __syncthreads();
     }
   }
@@ -565,77 +628,102 @@ __device__ __noinline__ bool ph_factor(int slot, double c, bool keep_diag) {
   return bad;
 }
 
-// x = S^-1 y2 (one wavefront per row; solver_kernels.hip: gemv_kernel)
-__device__ __forceinline__ void gemv_wg(gcd_t* S, int ld, int m, gcd_t* y2, gd_t* x) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int row = wave; row < m; row += RES_WAVES) {
-    gcd_t* a = S + (size_t)row * ld;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int j = lane;
-    for (; j + 192 < m; j += 256) {
-      const double a0 = a[j], a1 = a[j + 64], a2 = a[j + 128], a3 = a[j + 192];
-      const double y0 = y2[j], y1 = y2[j + 64], y2v = y2[j + 128], y3 = y2[j + 192];
-      acc0 += a0 * y0; acc1 += a1 * y1; acc2 += a2 * y2v; acc3 += a3 * y3;
+// x = S^-1 y2; y2 and x in the LDS window. A group of 16 lanes takes a row (64 rows per pass of the workgroup, a row's
+// loads all in flight): one wavefront per row (solver_kernels.hip: gemv_kernel) is seven dependent rounds at m = 108
+__device__ __forceinline__ void gemv_wg(gcd_t* S, int ld, int m, const double* y2, double* x) {
+  const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;   // RES_WG / 16 groups
+  for (int row0 = 0; row0 < m; row0 += RES_WG / 16) {
+    const int row = row0 + grp;
+    double acc = 0.0;
+    if (row < m) {
+      gcd_t* a = S + (size_t)row * ld;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int j = l;
+      for (; j + 48 < m; j += 64) {
+        const double p0 = a[j], p1 = a[j + 16], p2 = a[j + 32], p3 = a[j + 48];
+        a0 += p0 * y2[j]; a1 += p1 * y2[j + 16]; a2 += p2 * y2[j + 32]; a3 += p3 * y2[j + 48];
+      }
+      for (; j < m; j += 16) a0 += a[j] * y2[j];
+      acc = (a0 + a1) + (a2 + a3);
     }
-    for (; j < m; j += 64) acc0 += a[j] * y2[j];
-    const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
-    if (lane == 0) x[row] = acc;
+    acc = dpp_sum<16>(acc);
+    if (l == 15 && row < m) x[row] = acc;
   }
   __syncthreads();
 }
 
-// M x = b with the factors in W: b at W[yloc], x at W[xloc] (SparseLU::solve)
-__device__ __forceinline__ void solve_wg(gd_t* W) {
+// M x = b with the factors in W (global) and the vectors in the LDS window: b at win[yloc], x at win[xloc] (SparseLU::solve).
+// One function per solve form: an iteration only ever fetches the code of the form its network uses.
+__device__ __noinline__ void solve_fused(gcd_t* Wc) {
   const SegExtraG ex{};
-  gcd_t* Wc = (gcd_t*)W;
-  const ResNetDev* net = g_cx.net;
-  gcd_t* Sinv = Wc + g_cx.off_S;
-  const int m = g_cx.m, mpad = g_cx.mpad, ns = g_cx.ns;
-  if (g_cx.solve_mode == RES_SOLVE_FUSED) {
-    seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_STAGEA), Wc, W, ex); __syncthreads();
-    gemv_wg(Sinv, mpad, m, Wc + g_cx.off_y + ns, W + g_cx.off_x);
-    seg_run<SEG_PROD_SET>(hot_plan(PL_STAGEC), Wc, W, ex); __syncthreads();
-  } else if (g_cx.solve_mode == RES_SOLVE_EXPLICIT) {
-    seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_FWDZ), Wc, W, ex); __syncthreads();
-    if (m > 0) {
-      seg_run<SEG_PROD_SUB>(hot_plan(PL_FWD_DENSE), Wc, W, ex); __syncthreads();
-      gemv_wg(Sinv, mpad, m, Wc + g_cx.off_y + ns, W + g_cx.off_x);
-    }
-    seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_BWDT), Wc, W, ex); __syncthreads();
-    seg_run<SEG_PROD_SET>(hot_plan(PL_BWDV), Wc, W, ex); __syncthreads();
-  } else {
-    for (int r = 1; r < g_cx.nrounds; r++) { seg_run<SEG_PROD_SUB>(plan_g(net->fwd[r]), Wc, W, ex); __syncthreads(); }
-    if (m > 0) {
-      if (ns > 0) { seg_run<SEG_PROD_SUB>(hot_plan(PL_FWD_DENSE), Wc, W, ex); __syncthreads(); }
-      gemv_wg(Sinv, mpad, m, Wc + g_cx.off_y + ns, W + g_cx.off_x);
-    }
-    for (int r = g_cx.nrounds - 1; r >= 0; r--) { seg_run<SEG_PROD_SUB_DIV>(plan_g(net->bwd[r]), Wc, W, ex); __syncthreads(); }
+  double* win = L_win();
+  const double* winc = win;
+  const int m = uni(g_cx.m), mpad = uni(g_cx.mpad), ns = uni(g_cx.ns);
+  const long long off_y = uni((long long)g_cx.off_y), off_x = uni((long long)g_cx.off_x);
+  { RES_PROF(PF_STAGEA); seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_STAGEA), Wc, winc, win, winc, ex); __syncthreads(); }
+  { RES_PROF(PF_GEMV); gemv_wg(Wc + uni((long long)g_cx.off_S), mpad, m, winc + off_y + ns, win + off_x); }
+  { RES_PROF(PF_STAGEC); seg_run<SEG_PROD_SET>(hot_plan(PL_STAGEC), Wc, winc, win, winc, ex); __syncthreads(); }
+}
+__device__ __noinline__ void solve_explicit(gcd_t* Wc) {
+  const SegExtraG ex{};
+  double* win = L_win();
+  const double* winc = win;
+  const int m = uni(g_cx.m), mpad = uni(g_cx.mpad), ns = uni(g_cx.ns);
+  const long long off_y = uni((long long)g_cx.off_y), off_x = uni((long long)g_cx.off_x);
+  seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_FWDZ), Wc, winc, win, winc, ex); __syncthreads();
+  if (m > 0) {
+    seg_run<SEG_PROD_SUB>(hot_plan(PL_FWD_DENSE), Wc, winc, win, winc, ex); __syncthreads();
+    gemv_wg(Wc + uni((long long)g_cx.off_S), mpad, m, winc + off_y + ns, win + off_x);
   }
+  seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_BWDT), Wc, winc, win, winc, ex); __syncthreads();
+  seg_run<SEG_PROD_SET>(hot_plan(PL_BWDV), Wc, winc, win, winc, ex); __syncthreads();
+}
+__device__ __noinline__ void solve_plain(gcd_t* Wc) {
+  // plain substitution: the divisor of a backward row (aux) is a factor value, i.e. in global memory
+  const SegExtraG ex{};
+  const ResNetDev* net = g_cx.net;
+  double* win = L_win();
+  const double* winc = win;
+  const int m = uni(g_cx.m), mpad = uni(g_cx.mpad), ns = uni(g_cx.ns), nrounds = uni(g_cx.nrounds);
+  const long long off_y = uni((long long)g_cx.off_y), off_x = uni((long long)g_cx.off_x);
+  for (int r = 1; r < nrounds; r++) { seg_run<SEG_PROD_SUB>(plan_g(net->fwd[r]), Wc, winc, win, winc, ex); __syncthreads(); }
+  if (m > 0) {
+    if (ns > 0) { seg_run<SEG_PROD_SUB>(hot_plan(PL_FWD_DENSE), Wc, winc, win, winc, ex); __syncthreads(); }
+    gemv_wg(Wc + uni((long long)g_cx.off_S), mpad, m, winc + off_y + ns, win + off_x);
+  }
+  for (int r = nrounds - 1; r >= 0; r--) { seg_run<SEG_PROD_SUB_DIV>(plan_g(net->bwd[r]), Wc, winc, win, Wc, ex); __syncthreads(); }
+}
+__device__ __forceinline__ void solve_wg(gcd_t* Wc) {
+  const int mode = uni(g_cx.solve_mode);
+  if (mode == RES_SOLVE_FUSED) solve_fused(Wc);
+  else if (mode == RES_SOLVE_EXPLICIT) solve_explicit(Wc);
+  else solve_plain(Wc);
 }
 
 // one corrector iteration: residual, solve, update, the five sums of the decision and the error test
 // (solver_kernels.hip: rates_skip_kernel, segsum<SEG_COEF_BDF>, the solve, bdf_newton_kernel)
-__device__ __noinline__ ResSums ph_newton(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
-  RES_PROF(PF_NEWTON);
-  gd_t* W = glob(g_cx.T.W) + (size_t)slot * (size_t)g_cx.w_size;
-  gd_t* y = glob(g_cx.T.y); gd_t* d = glob(g_cx.T.d);
+__device__ __forceinline__ ResSums newton_body(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
+  gcd_t* Wc = glob((const double*)g_cx.T.W) + (size_t)slot * (size_t)g_cx.w_size;
+  double* y = L_y(); double* d = L_d();
+  double* win = L_win();
   {
     RES_PROF(PF_RESID);
-    rates_into((gcd_t*)y);
-    __syncthreads();
+    { RES_PROF(PF_RATES); rates_into((const double*)y); __syncthreads(); }
     SegExtraG ex;
-    ex.psi = glob((const double*)g_cx.T.psi); ex.d = (gcd_t*)d; ex.cscal = c;
-    seg_run<SEG_COEF_BDF>(hot_plan(PL_RESID), glob((const double*)g_cx.T.rate), W, ex);
+    ex.psi = L_psi(); ex.d = d; ex.cscal = c;
+    const double* rate = L_rate();
+    seg_run<SEG_COEF_BDF>(hot_plan(PL_RESID), rate, rate, win, rate, ex);
     __syncthreads();
   }
-  { RES_PROF(PF_SOLVE); solve_wg(W); }
+  { RES_PROF(PF_SOLVE); solve_wg(Wc); }
   RES_PROF(PF_UPDATE);
-  const int N = g_cx.N;
+  const int N = uni(g_cx.N);
   gci_t* xloc = glob(g_cx.net->xloc);
-  gcd_t* scale = glob((const double*)g_cx.T.scale); gcd_t* D = glob((const double*)g_cx.T.D);
+  const double* scale = L_scale();
+  gcd_t* D = glob((const double*)g_cx.T.D);
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < N; i += RES_WG) {
-    const double dy = upd * W[xloc[i]];
+    const double dy = upd * win[xloc[i]];
     const double q = dy / scale[i];
     v[0] += q * q;
     const double yy = y[i] + dy, dd = d[i] + dy;
@@ -647,8 +735,25 @@ __device__ __noinline__ ResSums ph_newton(int slot, double c, double upd, int or
     if (order < RES_MAX_ORDER) { const double ep = ec_p * (dd - D[(size_t)(order + 1) * N + i]) / sce; v[3] += ep * ep; }
     y[i] = yy; d[i] = dd;
   }
-  wg_reduce<5>(v);
+  { RES_PROF(PF_REDUCE); wg_reduce<5>(v); }
   return ResSums{v[0], v[1], v[2], v[3], v[4]};
+}
+
+// a whole corrector attempt: predictor + iterations + their decisions (resident_core.hpp: res_corrector_loop), by all wavefronts
+struct InnerOps {
+  __device__ void predict_inner(int order, const double*, double alpha_o, double atol, double rtol) {
+    RES_PROF(PF_PREDICT);
+    predict_body(order, alpha_o, atol, rtol);
+  }
+  __device__ ResSums newton_iter_inner(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
+    return newton_body(slot, c, upd, order, ec, ec_m, ec_p, atol, rtol);
+  }
+};
+__device__ __noinline__ ResAttempt ph_corrector() {
+  RES_PROF(PF_NEWTON);
+  const ResCorrIn in = g_sh.corr;
+  InnerOps ops;
+  return res_corrector_loop(ops, in, g_sh.gamma, g_cx.N);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -656,12 +761,12 @@ __device__ __noinline__ ResSums ph_newton(int slot, double c, double upd, int or
 // table of the LU cache in its registers
 // ------------------------------------------------------------------------------------------------------------------
 enum CmdOp : int { OP_EXIT = 0, OP_VEC, OP_SAVE_Y, OP_APPLY_RATES, OP_RHS, OP_JAC, OP_NORMS, OP_INIT_D, OP_PREDICT, OP_CHANGE_D, OP_ACCEPT,
-                   OP_INTERP, OP_DRIFT, OP_FACTOR, OP_NEWTON };
+                   OP_INTERP, OP_DRIFT, OP_FACTOR, OP_CORRECTOR };
 struct DevBackend {
   __device__ int lane() const { return threadIdx.x & 63; }
   __device__ int n_species() const { return g_cx.N; }
   __device__ void profile_out(int64_t* out) const {
-    for (int i = 0; i < 12; i++) out[i] = g_sh.prof[i];   // written by thread 0 only: this wavefront's own stores
+    for (int i = 0; i < 20; i++) out[i] = g_sh.prof[i];   // written by thread 0 only: this wavefront's own stores
   }
 
   // ---- slot table (g_sl)
@@ -764,9 +869,10 @@ struct DevBackend {
     ph_interp(order, row);
   }
   __device__ bool factor(int slot, double c, bool keep_diag) { post(OP_FACTOR, slot, keep_diag ? 1 : 0, 0, 0, c); return ph_factor(slot, c, keep_diag); }
-  __device__ ResSums newton_iter(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
-    post(OP_NEWTON, slot, order, 0, 0, c, upd, ec, ec_m, ec_p, atol, rtol);
-    return ph_newton(slot, c, upd, order, ec, ec_m, ec_p, atol, rtol);
+  __device__ ResAttempt corrector(const ResCorrIn& in, const double*) {
+    if (threadIdx.x == 0) g_sh.corr = in;
+    post(OP_CORRECTOR);
+    return ph_corrector();
   }
 };
 
@@ -778,7 +884,7 @@ __device__ void worker_loop() {
     if (op == OP_EXIT) return;
     const int i0 = g_sh.cmd_i[0], i1 = g_sh.cmd_i[1];
     const long long l0 = g_sh.cmd_l;
-    const double d0 = g_sh.cmd_d[0], d1 = g_sh.cmd_d[1], d2 = g_sh.cmd_d[2], d3 = g_sh.cmd_d[3], d4 = g_sh.cmd_d[4], d5 = g_sh.cmd_d[5], d6 = g_sh.cmd_d[6];
+    const double d0 = g_sh.cmd_d[0], d1 = g_sh.cmd_d[1], d2 = g_sh.cmd_d[2];
     switch (op) {
       case OP_VEC: ph_vec(i0, d0); break;
       case OP_SAVE_Y: ph_save_y(l0, d0); break;
@@ -793,7 +899,7 @@ __device__ void worker_loop() {
       case OP_INTERP: ph_interp(i0, l0); break;
       case OP_DRIFT: ph_drift(); break;
       case OP_FACTOR: (void)ph_factor(i0, d0, i1 != 0); break;
-      case OP_NEWTON: (void)ph_newton(i0, d0, d1, i1, d2, d3, d4, d5, d6); break;
+      case OP_CORRECTOR: (void)ph_corrector(); break;
       default: break;
     }
   }
@@ -829,8 +935,11 @@ __global__ __launch_bounds__(RES_WG) void resident_bdf_kernel(const ResNetDev* _
     g_cx.off_diag = n.off_diag; g_cx.off_U = n.off_U; g_cx.off_L = n.off_L; g_cx.off_S = n.off_S; g_cx.off_y = n.off_y; g_cx.off_x = n.off_x;
     g_cx.off_dinv = n.off_dinv; g_cx.w_size = n.w_size;
     g_cx.k_max = n.k_max; g_cx.t_mult = n.t_mult;
+    g_cx.off_vec_end = n.off_vec_end;
+    const int win = (int)(n.off_vec_end - n.off_y);
+    g_cx.l_y = 0; g_cx.l_d = n.N; g_cx.l_psi = 2 * n.N; g_cx.l_scale = 3 * n.N; g_cx.l_win = 4 * n.N; g_cx.l_rate = 4 * n.N + win;
   }
-  if (threadIdx.x < 12) g_sh.prof[threadIdx.x] = 0;
+  if (threadIdx.x < 20) g_sh.prof[threadIdx.x] = 0;
   __syncthreads();
   for (int id = 0; id < PL_COUNT; id++) count_splits(id);
   __syncthreads();
@@ -838,22 +947,29 @@ __global__ __launch_bounds__(RES_WG) void resident_bdf_kernel(const ResNetDev* _
   // the leader wavefront: controller state and parameters live in LDS (one wavefront in lockstep: no hazards), not in
   // registers that would be spilled around every phase call
   const long long t_begin = wall_clock64();
+  const long long c_begin = clock64();
   DevBackend b;
   ResidentBdf<DevBackend>* ctl = new (g_ctl_mem) ResidentBdf<DevBackend>(b, g_par);
   if (threadIdx.x <= RES_MAX_ORDER) g_sh.gamma[threadIdx.x] = ctl->gamma[threadIdx.x];   // (ordered by the first command's barrier)
   ResResult r = ctl->run();
   b.post(OP_EXIT);
   r.prof[PF_TOTAL] = wall_clock64() - t_begin;
+  (void)c_begin;
   if (threadIdx.x == 0) *g_cx.T.result = r;
 }
 
 }  // namespace
 
-size_t resident_dyn_lds(int m) { const int m16 = (m + 15) / 16 * 16; return (size_t)16 * (m16 + 1) * sizeof(double); }
+size_t resident_dyn_lds(int N, int R, int m, int64_t window) {
+  const int m16 = (m + 15) / 16 * 16;
+  return ((size_t)4 * N + (size_t)window + (size_t)std::max(R, 16 * (m16 + 1))) * sizeof(double);
+}
 
-void launch_resident(int K, int m, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s) {
+void launch_resident(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s) {
   if (K <= 0) return;
-  hipLaunchKernelGGL(resident_bdf_kernel, dim3((unsigned)K), dim3(RES_WG), resident_dyn_lds(m), s, d_net, d_traj, d_par);
+  static bool attr_set = false;
+  if (!attr_set) { KIN_HIP(hipFuncSetAttribute((const void*)resident_bdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BUDGET)); attr_set = true; }
+  hipLaunchKernelGGL(resident_bdf_kernel, dim3((unsigned)K), dim3(RES_WG), dyn_lds, s, d_net, d_traj, d_par);
   KIN_HIP(hipGetLastError());
 }
 

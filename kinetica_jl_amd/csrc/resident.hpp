@@ -15,7 +15,7 @@ enum : int { RES_SOLVE_FUSED = 0, RES_SOLVE_EXPLICIT = 1, RES_SOLVE_PLAIN = 2 };
 // immutable per network: reaction tables, gather plans, symbolic LU (device pointers)
 struct ResNetDev {
   int32_t N, R, nnzJ, ns, m, mpad, nrounds, n_mono_ent, solve_mode, has_kmax;
-  int64_t off_diag, off_U, off_L, off_S, off_y, off_x, off_dinv, w_size;
+  int64_t off_diag, off_U, off_L, off_S, off_y, off_x, off_dinv, off_vec_end, w_size;
   double k_max, t_mult;
   const int32_t *x0, *x1, *jmap, *ent_pivot, *yloc, *xloc, *j_diag;
   const int32_t *mono_ent_ptr, *mono_ptr, *mono_fac, *mono_dst;
@@ -41,6 +41,9 @@ struct ResTrajDev {
 // enqueues the solve of K trajectories (grid = K workgroups of 1024 threads)
 // `m`: dimension of the dense Schur block (sizes the dynamic LDS of its row panel; at most RES_MAX_DENSE)
 constexpr int RES_MAX_DENSE = 512;
-void launch_resident(int K, int m, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
+// dynamic LDS of the kernel: y, d, psi, scale (4 N), the solve-vector window of W, max(R, row panel of the dense inverse)
+size_t resident_dyn_lds(int N, int R, int m, int64_t window);
+constexpr size_t RES_LDS_BUDGET = 160 * 1024 - 14 * 1024;   // what is left of a CU's LDS next to the kernel's static blocks
+void launch_resident(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
 
 }  // namespace kin

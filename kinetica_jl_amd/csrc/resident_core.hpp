@@ -56,7 +56,7 @@ struct ResResult {
   int64_t n_saved;
   double final_abstol, final_reltol;
   ResStats st;
-  int64_t prof[12];   // device only: 10 ns ticks per phase kind (resident.hip: ProfId), 0 in the CPU replay
+  int64_t prof[20];   // device only: 10 ns ticks per phase kind (resident.hip: ProfId), 0 in the CPU replay
 };
 
 struct ResNorms { double d0, d1, d2; int nonfinite; };
@@ -65,6 +65,56 @@ struct ResSums { double s, se, sm, sp, neg; };   // update, error test of order 
 KIN_HD inline double res_inf() { return HUGE_VAL; }
 // spacing of the doubles above x (x >= 0, finite): what std::nextafter(x, inf) - x gives on the host
 KIN_HD inline double res_ulp_above(double x) { return nextafter(x, res_inf()) - x; }
+
+// one corrector attempt: what the controller hands to the backend, and what it gets back
+struct ResCorrIn {
+  int32_t slot, order;
+  double c, upd, rate_max, crate0, tol_first, newton_tol, dy_first_max, ec, ec_m, ec_p, atol, rtol, alpha_o;
+};
+struct ResAttempt { bool done, converged, nonfinite, any_negative; int n_iter; double err, err_m, err_p, crate; };
+
+// Predictor + corrector iterations until decided: the decisions of newton_decide (solver_kernels.hip), taken in sequence.
+// `I` supplies predict_inner / newton_iter_inner (the CPU replay: the backend itself; the device: the phase's own inlined
+// operations, run by all wavefronts).
+template <class I>
+KIN_HD ResAttempt res_corrector_loop(I& b, const ResCorrIn& in, const double* gamma, int n_species) {
+  ResAttempt a{false, false, false, false, 0, 0.0, 0.0, 0.0, 1.0};
+  b.predict_inner(in.order, gamma, in.alpha_o, in.atol, in.rtol);
+  const double N = (double)n_species;
+  double crate = in.crate0, dy_old = 0.0;
+  for (int it = 0; it < RES_NEWTON_MAXITER && !a.done; it++) {
+    const ResSums q = b.newton_iter_inner(in.slot, in.c, in.upd, in.order, in.ec, in.ec_m, in.ec_p, in.atol, in.rtol);
+    const double dy_norm = sqrt(q.s / N);
+    const bool nonfinite = !(fabs(q.s) <= 1.79769313486231570815e308);   // !isfinite
+    const bool have_rate = it > 0;
+    const double rate = have_rate ? dy_norm / dy_old : 0.0;
+    if (have_rate && !nonfinite) crate = (0.3 * crate > rate) ? 0.3 * crate : rate;
+    bool diverged = nonfinite;
+    if (!diverged && have_rate) {
+      double rp = rate;
+      for (int e = 1; e < RES_NEWTON_MAXITER - it; e++) rp *= rate;
+      if (rate >= in.rate_max || rp / (1.0 - rate) * dy_norm > in.newton_tol) diverged = true;
+    }
+    a.n_iter = it + 1;
+    a.done = true;
+    if (diverged) { a.nonfinite = nonfinite; }
+    else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < in.newton_tol) ||
+             (!have_rate && (dy_norm < in.newton_tol || (in.crate0 < 1.0 && dy_norm <= in.dy_first_max &&
+                                                         in.crate0 / (1.0 - in.crate0) * dy_norm < in.tol_first)))) {
+      a.converged = true;
+    } else {
+      dy_old = dy_norm;
+      a.done = it == RES_NEWTON_MAXITER - 1;
+    }
+    if (a.converged) {
+      a.err = sqrt(q.se / N); a.err_m = sqrt(q.sm / N); a.err_p = sqrt(q.sp / N);
+      a.any_negative = q.neg > 0.0;
+      if (!(fabs(q.se) <= 1.79769313486231570815e308)) a.nonfinite = true;
+    }
+  }
+  a.crate = crate;
+  return a;
+}
 
 template <class B>
 struct ResidentBdf {
@@ -181,50 +231,20 @@ struct ResidentBdf {
     return bad;
   }
 
-  struct Attempt { bool done, converged, nonfinite, any_negative; int n_iter; double err, err_m, err_p, crate; };
-
-  // predictor + corrector iterations until decided: the decisions of newton_decide (solver_kernels.hip), taken in sequence
-  KIN_HD Attempt corrector(double c) {
-    Attempt a{false, false, false, false, 0, 0.0, 0.0, 0.0, 1.0};
-    predict();
+  // predictor + corrector iterations until decided (one backend operation: on the device one phase, no round trip through
+  // the controller between the iterations)
+  KIN_HD ResAttempt corrector(double c) {
+    ResCorrIn in;
     const double cf = b.slot_c_fact(cur_slot);
-    const double upd = cf != c ? 2.0 / (1.0 + c / cf) : 1.0;
-    const double rate_max = (P.lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? P.reuse_rate_max : 1.0;
-    const double crate0 = P.carry_rate ? b.slot_crate(cur_slot) : 1.0;
-    const double tol_first = crate_fresh(cur_slot) ? newton_tol : -1.0;
-    const double N = (double)b.n_species();
-    double crate = crate0, dy_old = 0.0;
-    for (int it = 0; it < RES_NEWTON_MAXITER && !a.done; it++) {
-      const ResSums q = b.newton_iter(cur_slot, c, upd, order, errc[order], order > 1 ? errc[order - 1] : 0.0, errc[order + 1], atol, rtol);
-      const double dy_norm = sqrt(q.s / N);
-      const bool nonfinite = !(fabs(q.s) <= 1.79769313486231570815e308);   // !isfinite
-      const bool have_rate = it > 0;
-      const double rate = have_rate ? dy_norm / dy_old : 0.0;
-      if (have_rate && !nonfinite) crate = (0.3 * crate > rate) ? 0.3 * crate : rate;
-      bool diverged = nonfinite;
-      if (!diverged && have_rate) {
-        double rp = rate;
-        for (int e = 1; e < RES_NEWTON_MAXITER - it; e++) rp *= rate;
-        if (rate >= rate_max || rp / (1.0 - rate) * dy_norm > newton_tol) diverged = true;
-      }
-      a.n_iter = it + 1;
-      a.done = true;
-      if (diverged) { a.nonfinite = nonfinite; }
-      else if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < newton_tol) ||
-               (!have_rate && (dy_norm < newton_tol || (crate0 < 1.0 && dy_norm <= P.crate_dy_max && crate0 / (1.0 - crate0) * dy_norm < tol_first)))) {
-        a.converged = true;
-      } else {
-        dy_old = dy_norm;
-        a.done = it == RES_NEWTON_MAXITER - 1;
-      }
-      if (a.converged) {
-        a.err = sqrt(q.se / N); a.err_m = sqrt(q.sm / N); a.err_p = sqrt(q.sp / N);
-        a.any_negative = q.neg > 0.0;
-        if (!(fabs(q.se) <= 1.79769313486231570815e308)) a.nonfinite = true;
-      }
-    }
-    a.crate = crate;
-    return a;
+    in.slot = cur_slot; in.order = order; in.c = c;
+    in.upd = cf != c ? 2.0 / (1.0 + c / cf) : 1.0;
+    in.rate_max = (P.lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? P.reuse_rate_max : 1.0;
+    in.crate0 = P.carry_rate ? b.slot_crate(cur_slot) : 1.0;
+    in.tol_first = crate_fresh(cur_slot) ? newton_tol : -1.0;
+    in.newton_tol = newton_tol; in.dy_first_max = P.crate_dy_max;
+    in.ec = errc[order]; in.ec_m = order > 1 ? errc[order - 1] : 0.0; in.ec_p = errc[order + 1];
+    in.atol = atol; in.rtol = rtol; in.alpha_o = alpha[order];
+    return b.corrector(in, gamma);
   }
 
   enum StepStatus { STEP_OK = 0, STEP_DT_MIN = 1 };
@@ -233,7 +253,7 @@ struct ResidentBdf {
   KIN_HD StepStatus step(double t_bound) {
     bool accepted = false, first_attempt = true;
     double safety = 0.9, err_norm = 0.0, t_new = t;
-    Attempt a{};
+    ResAttempt a{};
     while (!accepted) {
       if (iters_left-- <= 0) return STEP_OK;   // caller checks iters_left < 0 -> MaxIters
       const double ulp10 = 10.0 * res_ulp_above(t);
@@ -469,7 +489,7 @@ struct ResidentBdf {
     }
     ResResult r;
     r.retcode = retcode; r.pad = 0; r.n_saved = n_saved; r.final_abstol = abstol; r.final_reltol = reltol; r.st = st;
-    for (int i = 0; i < 12; i++) r.prof[i] = 0;
+    for (int i = 0; i < 20; i++) r.prof[i] = 0;
     b.profile_out(r.prof);
     return r;
   }

@@ -47,8 +47,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // One round of NX entries per lane: all index loads, then all gathers, then the sum in slot order (two dependent loads on
 // the critical path). `idx_of(x)` = payload index of this lane's x-th entry, or -1. ELL = entries of an ELL group (padding
 // inside the group is marked in the payload), else the contiguous payload of medium / long rows.
-template <int OP, int NX, bool ELL, class View, class SrcP, class EX, class F>
-__device__ __forceinline__ double seg_gather(const View& p, SrcP src, const EX& ex, bool impl, F idx_of) {
+// srcA: the array the first factor (or the coefficient plans' operand) is read from, srcB: the second factor's - the same
+// array in the grid kernels; in the resident integrator the factor values are in global memory and the solve vectors in LDS
+template <int OP, int NX, bool ELL, class View, class SrcA, class SrcB, class EX, class F>
+__device__ __forceinline__ double seg_gather2(const View& p, SrcA srcA, SrcB srcB, const EX& ex, bool impl, F idx_of) {
   constexpr bool PROD = seg_is_prod<OP>::v;
   const auto A = ELL ? p.ell_a : p.long_a;
   const auto Bp = ELL ? p.ell_b : p.long_b;
@@ -66,8 +68,8 @@ __device__ __forceinline__ double seg_gather(const View& p, SrcP src, const EX& 
 #pragma unroll
   for (int x = 0; x < NX; x++) {
     const bool on = c[x] != 0.0f;
-    va[x] = on ? src[ia[x]] : 0.0;
-    vb[x] = (PROD && on) ? src[ib[x]] : 0.0;
+    va[x] = on ? srcA[ia[x]] : 0.0;
+    vb[x] = (PROD && on) ? srcB[ib[x]] : 0.0;
   }
   double acc = 0.0;
 #pragma unroll
@@ -76,6 +78,11 @@ __device__ __forceinline__ double seg_gather(const View& p, SrcP src, const EX& 
     else acc += (double)c[x] * va[x];
   }
   return acc;
+}
+
+template <int OP, int NX, bool ELL, class View, class SrcP, class EX, class F>
+__device__ __forceinline__ double seg_gather(const View& p, SrcP src, const EX& ex, bool impl, F idx_of) {
+  return seg_gather2<OP, NX, ELL>(p, src, src, ex, impl, idx_of);
 }
 
 }  // namespace kin

@@ -317,7 +317,9 @@ struct HostBackend {
       for (int r = lu.nrounds - 1; r >= 0; r--) seg_run_host(SEG_PROD_SUB_DIV, net.Pl(lu.bwd[r]), Wp, Wp, ex);
     }
   }
-  ResSums newton_iter(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
+  ResAttempt corrector(const ResCorrIn& in, const double* gamma) { return res_corrector_loop(*this, in, gamma, N); }
+  void predict_inner(int order, const double* gamma, double alpha_o, double atol, double rtol) { predict(order, gamma, alpha_o, atol, rtol); }
+  ResSums newton_iter_inner(int slot, double c, double upd, int order, double ec, double ec_m, double ec_p, double atol, double rtol) {
     double* Wp = slot_W(slot);
     rates(y.data());
     Ex ex; ex.psi = psi.data(); ex.d = d.data(); ex.cscal = c;

@@ -17,7 +17,7 @@ _lib = None
 class ResResult(ctypes.Structure):
     _fields_ = [("retcode", c_int32), ("pad", c_int32), ("n_saved", c_int64), ("final_abstol", c_double), ("final_reltol", c_double)] + \
                [(n, c_int64) for n in ("n_steps", "n_rejected", "n_rhs", "n_jac", "n_factor", "n_linsolve", "n_newton_fail", "n_chunks",
-                                        "n_restarts", "n_retries", "n_lu_reused", "n_bad_pivot", "n_lu_dropped")] + [("prof", c_int64 * 12)]
+                                        "n_restarts", "n_retries", "n_lu_reused", "n_bad_pivot", "n_lu_dropped")] + [("prof", c_int64 * 20)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "prof"}
