@@ -52,6 +52,9 @@ def parse():
                     help="back-to-back sweeps BEFORE the warm-up steps, untimed: the clocks settle (0 = cold-clock number)")
     ap.add_argument("--replicas", default="1,2,4,8", help="concurrent replicas on one GPU to time (comma list, '' = skip)")
     ap.add_argument("--no-tiled", dest="tiled", action="store_false", help="skip the library-order sweep legs (C3 + C5)")
+    ap.add_argument("--no-configs", dest="configs", action="store_false",
+                    help="skip the BASELINE configurations as SURVEY 8(d) states them (C3 whole span both ways, C4 20-chunk prefix, C5 5 chunks)")
+    ap.add_argument("--no-crossover", dest="crossover", action="store_false", help="skip the network-size crossover table and the ensemble launch")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (traffic = null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -218,19 +221,30 @@ def replica_worker(args):
 def run_replica_workers(args, P, T, nck):
     """Starts P worker processes with T threads each, releases them together, returns the ensemble's throughput."""
     cmd = [sys.executable, os.path.abspath(__file__), "--species", str(args.species), "--reactions", str(args.reactions)]
+    logdir = tempfile.mkdtemp(prefix="kin_bench_workers_", dir="/tmp")
+    logs = [open(os.path.join(logdir, f"worker{p}.stderr"), "w") for p in range(P)]
     procs = [subprocess.Popen(cmd + ["--replica-worker", str(T), str(nck), str(p * T)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                              stderr=subprocess.DEVNULL, text=True, env=clean_child_env()) for p in range(P)]
+                              stderr=logs[p], text=True, env=clean_child_env()) for p in range(P)]
+
+    def tail(p):
+        logs[p].flush()
+        return open(logs[p].name).read()[-1500:]
     try:
         for pr in procs:
             line = pr.stdout.readline()
             while line and line.strip() != "READY":
                 line = pr.stdout.readline()
             if not line:
-                raise RuntimeError("a replica worker ended before it was ready")
+                raise RuntimeError("a replica worker ended before it was ready: " + tail(procs.index(pr)))
         t0 = time.perf_counter()
         for pr in procs:
             pr.stdin.write("GO\n"); pr.stdin.flush()
-        reps = [json.loads(pr.stdout.readline()) for pr in procs]
+        reps = []
+        for i, pr in enumerate(procs):
+            line = pr.stdout.readline()
+            if not line.strip():
+                raise RuntimeError("a replica worker ended without a result: " + tail(i))
+            reps.append(json.loads(line))
         wall = time.perf_counter() - t0
     finally:
         for pr in procs:
@@ -238,9 +252,21 @@ def run_replica_workers(args, P, T, nck):
                 pr.wait(timeout=60)
             except subprocess.TimeoutExpired:
                 pr.kill()
+        for f in logs:
+            f.close()
+        shutil.rmtree(logdir, ignore_errors=True)
     K = P * T
     return {"processes": P, "threads_per_process": T, "wall_s": wall, "solves_per_s": K / wall, "all_success": all(r["ok"] for r in reps),
             "replica0_steps": reps[0]["steps"][0], "replica0_checksum": [reps[0]["sum0"], reps[0]["max0"]]}
+
+
+def guarded(out, key, fn):
+    """Optional legs never take the headline numbers with them: an exception becomes {'error': ...} under `key`."""
+    try:
+        out[key] = fn()
+    except Exception as e:        # noqa: BLE001 - whatever an optional leg throws is recorded, not raised
+        import traceback
+        out[key] = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().splitlines()[-3:]}
 
 
 def main():
@@ -359,6 +385,16 @@ def main():
         torch.cuda.synchronize()
         sustained_ms = e0.elapsed_time(e1) / n_sus
 
+    # who took part (so that the driver can see that RCCL had N ranks on N devices): backend, world size, device of every rank
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+          "pci_bus_id": getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "pci_bus_id", None)}
+    if dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        rank_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "members": gathered,
+                     "scaling_note": "weak scaling: every rank sweeps its own B states; no scaling curve has been measured before round 4"}
+    else:
+        rank_info = {"backend": None, "world_size": 1, "members": [me]}
     out = None
     if rank == 0:
         alg_bytes = 20 * R + B * (8 * R + 16 * N)
@@ -368,6 +404,7 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "RHS evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "ranks": rank_info,
             "config": {"workload": f"synthetic CRN {N} species / {R} reactions (seed 12345), batched RHS sweep, "
                                    f"B={B} states per GPU with per-state Arrhenius k (500-1200 K)",
                        "states_per_gpu": B, "parallelism": f"replicas x{world} (no data-path collective)"},
@@ -410,17 +447,22 @@ def main():
                                  "GBps": alg_k / (ms_k * 1e-3) / 1e9, "frac_of_8TBps": alg_k / (ms_k * 1e-3) / 8e12, "bound": "hbm / LDS atomics"},
                     "temperature_form": {"ms": ms_T, "evals_per_s": Bb / (ms_T * 1e-3), "algorithmic_bytes_M1prime": alg_T,
                                          "GBps": alg_T / (ms_T * 1e-3) / 1e9, "bound": "FP64 VALU (2 exp per record) + LDS atomics"}}
-        out["tiled_sweep"] = {"kernel": "kin::tiled_sweep_kernel (library order: kin_lib_layout / kin_rate_table_lib_dev / kin_rhs_tiled_dev)",
-                              "C3": tiled_leg(h, N, R, B, d_u, T)}
-        net5, Ea5, A5 = synthetic_crn(50000, 250000)
-        h5 = capi.HipNetwork.from_flat(net5)
-        h5.set_arrhenius(Ea5, A5, k_max=1e12)
-        B5 = 1024
-        u5 = torch.pow(10.0, torch.rand((B5, 50000), dtype=torch.float64, device=dev, generator=g) * 12.0 - 12.0)
-        out["tiled_sweep"]["C5"] = tiled_leg(h5, 50000, 250000, B5, u5, torch.linspace(500.0, 1200.0, B5, dtype=torch.float64, device=dev))
-        out["tiled_sweep"]["C5"]["traffic_note"] = "PMC counters of this kernel: profiles/r03_c5_tiled_pmc.json (tools/pmc_tiled.sh)"
-        h5.close()
-        del u5
+        def tiled_all():
+            res = {"kernel": "kin::tiled_sweep_kernel (library order: kin_lib_layout / kin_rate_table_lib_dev / kin_rhs_tiled_dev)",
+                   "C3": tiled_leg(h, N, R, B, d_u, T)}
+            net5, Ea5, A5 = synthetic_crn(50000, 250000)
+            h5 = capi.HipNetwork.from_flat(net5)
+            try:
+                h5.set_arrhenius(Ea5, A5, k_max=1e12)
+                B5 = 1024
+                u5 = torch.pow(10.0, torch.rand((B5, 50000), dtype=torch.float64, device=dev, generator=g) * 12.0 - 12.0)
+                res["C5"] = tiled_leg(h5, 50000, 250000, B5, u5, torch.linspace(500.0, 1200.0, B5, dtype=torch.float64, device=dev))
+                res["C5"]["traffic_note"] = "PMC counters of this kernel: profiles/r03_c5_tiled_pmc.json (tools/pmc_tiled.sh)"
+                del u5
+            finally:
+                h5.close()
+            return res
+        guarded(out, "tiled_sweep", tiled_all)
 
     # ---- ONE trajectory's RHS with the reactions split over the ranks and an all-reduce of du (N doubles):
     # measured at N > 1 so that the cost of the single-trajectory decomposition is a number, not an argument
@@ -560,18 +602,175 @@ def main():
     # fill the rest. Measured limits (tools/ensemble_scaling.py): the throughput saturates at
     # ~4 replicas (the runtime's 4 hardware queues, each a serial chain of small dependent dispatches); more hardware
     # queues (GPU_MAX_HW_QUEUES = 8 ... 24) or several worker PROCESSES (2 x 4, 4 x 4 threads) were slower, not faster.
-    if rank == 0 and world == 1 and args.solve_chunks > 0 and args.replicas:
-        nck = max(1, args.cpu_solve_chunks)
-        res = {}
-        for K in [int(x) for x in args.replicas.split(",")]:
-            res[str(K)] = run_replica_workers(args, 1, K, nck)
-        best = max(res.values(), key=lambda q: q["solves_per_s"])
-        out["solve_network"]["concurrent_replicas"] = dict(res, chunks=nck, note="K host threads of one worker process, one handle per thread, "
-                                                           f"each solving the first {nck} chunks of its own replica (1000 + 10 i K); "
-                                                           "timed between a common start signal and the last worker's report")
-        cac = out["solve_network"].get("cpu_all_cores")
-        if cac:
-            cac["gpu_over_all_cores_best_K"] = best["solves_per_s"] / cac["solves_per_s"]
+    if rank == 0 and world == 1 and args.solve_chunks > 0 and args.replicas and "solve_network" in out:
+        def replicas_leg():
+            nck = max(1, args.cpu_solve_chunks)
+            res = {}
+            for K in [int(x) for x in args.replicas.split(",")]:
+                res[str(K)] = run_replica_workers(args, 1, K, nck)
+            best = max(res.values(), key=lambda q: q["solves_per_s"])
+            cac = out["solve_network"].get("cpu_all_cores")
+            if cac:
+                cac["gpu_over_all_cores_best_K"] = best["solves_per_s"] / cac["solves_per_s"]
+            return dict(res, chunks=nck, note="K host threads of one worker process, one handle per thread, each solving the first "
+                        f"{nck} chunks of its own replica (1000 + 10 i K); timed between a common start signal and the last worker's report")
+        guarded(out["solve_network"], "concurrent_replicas", replicas_leg)
+
+    # ---- the BASELINE configurations as SURVEY 8(d) states them (rank 0, N = 1): C3 over its whole span (0, 1) s chunkwise
+    # (1 000 default chunks) AND as one integration (solve_chunks = false, methods.jl:132-183); the first 20 chunks of the C4
+    # ramp (200 rate updates / restarts) against the committed tight-tolerance truth; a 5-chunk solve of the C5 network
+    # (50k species). The ramp and the complete-timespan solve need dtmin below the reference's hard-coded eps(.) on this
+    # synthetic CRN: kin_params.dtmin = 1e-30, what INTEGRATION.md's shim passes as HIPBDF(dtmin).
+    if rank == 0 and world == 1 and args.configs and args.solve_chunks > 0:
+        RAMP_DTMIN = 1e-30
+
+        def kpc(t1, chunk, save=-1.0, chunks=1, dtmin=0.0):
+            return capi.KinParams(tspan0=0.0, tspan1=t1, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=chunks,
+                                  ban_negatives=0, solve_chunkstep=chunk, maxiters=100000, save_interval=save, dtmin=dtmin)
+
+        def brief(st):
+            return {q: st[q] for q in ("n_steps", "n_rejected", "n_factor", "n_newton_fail", "n_restarts", "n_retries", "n_lu_reused")}
+
+        def c3_full():
+            h.rates_at(1000.0)
+            res = {}
+            t1 = time.perf_counter()
+            tt, uu, rc1, st1, _ = h.solve(kpc(1.0, 1e-3), u0)
+            res["chunkwise_1000_chunks"] = {"wall_s": time.perf_counter() - t1, "retcode": rc1, "n_saved": len(tt), "stats": brief(st1)}
+            fin = uu[-1].copy()
+            mass = h.solution_dot(net.mass.astype(float))
+            res["chunkwise_1000_chunks"]["mass_invariant_max_rel_drift"] = float(np.max(np.abs(mass / mass[0] - 1.0)))
+            t1 = time.perf_counter()
+            tt, uu, rc2, st2, _ = h.solve(kpc(1.0, 1e-3, save=1e-3, chunks=0, dtmin=RAMP_DTMIN), u0)
+            res["complete_timespan"] = {"wall_s": time.perf_counter() - t1, "retcode": rc2, "n_saved": len(tt), "stats": brief(st2),
+                                        "dtmin": RAMP_DTMIN}
+            e = np.abs(fin - uu[-1]) / (1e-10 + 1e-8 * np.abs(uu[-1]))
+            res["final_states_apart_in_tolerance_units"] = {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean()))}
+            return res
+
+        def c4_prefix():
+            tst = np.arange(201) * 1e-3
+            Tst = 500.0 + 50.0 * tst
+            pr = kpc(0.2, 1e-2, save=5e-3, dtmin=RAMP_DTMIN)
+            h.solve(kpc(0.02, 1e-2, save=5e-3, dtmin=RAMP_DTMIN), u0, tstops=tst[:21], T_stops=Tst[:21])      # warm-up
+            t1 = time.perf_counter()
+            tt, uu, rc4, st4, _ = h.solve(pr, u0, tstops=tst, T_stops=Tst)
+            res = {"workload": "ramp 500 -> 1200 K at 50 K/s, ts_update 1 ms, chunk 10 ms, save 5 ms: first 20 chunks (200 restarts)",
+                   "wall_s": time.perf_counter() - t1, "retcode": rc4, "n_saved": len(tt), "dtmin": RAMP_DTMIN, "stats": brief(st4)}
+            tp = os.path.join(ROOT, "tests", "golden", "truth_c4_long.npz")
+            if os.path.exists(tp):
+                z = np.load(tp)
+                sel = np.searchsorted(tt, z["t"])
+                e = np.abs(uu[sel] - z["u"]) / (1e-10 + 1e-8 * np.abs(z["u"]))
+                res["vs_truth_in_tolerance_units"] = {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean(axis=1)).max()),
+                                                      "p99.9": float(np.percentile(e, 99.9)), "truth_self_check": float(z["self_check"]),
+                                                      "truth": "tests/golden/truth_c4_long.npz (CPU port at 1000x tighter tolerances)"}
+            return res
+
+        def c5_solve():
+            net5, Ea5, A5 = synthetic_crn(50000, 250000)
+            t1 = time.perf_counter()
+            h5 = capi.HipNetwork.from_flat(net5)
+            try:
+                h5.set_arrhenius(Ea5, A5, k_max=1e12)
+                h5.rates_at(1000.0)
+                u05 = np.zeros(50000); u05[0] = 1.0
+                tt, uu, rc5, st5, _ = h5.solve(kpc(5e-3, 1e-3, dtmin=RAMP_DTMIN), u05)
+                cold = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                tt, uu, rc5, st5, _ = h5.solve(kpc(5e-3, 1e-3, dtmin=RAMP_DTMIN), u05)
+                warm = time.perf_counter() - t1
+                m5 = h5.solution_dot(net5.mass.astype(float))
+            finally:
+                h5.close()
+            return {"workload": "50k species / 250k reactions, static 1000 K, 5 default chunks", "cold_wall_s_incl_create_and_analysis": cold,
+                    "wall_s": warm, "retcode": rc5, "dense_block": st5["lu_dense_dim"], "stats": brief(st5),
+                    "mass_invariant_max_rel_drift": float(np.max(np.abs(m5 / m5[0] - 1.0)))}
+
+        cfg = {}
+        guarded(cfg, "C3_whole_span", c3_full)
+        guarded(cfg, "C4_prefix", c4_prefix)
+        guarded(cfg, "C5_static", c5_solve)
+        out.setdefault("solve_network", {})["configs"] = cfg
+
+    # ---- where a GPU pays: 20-chunk static solves over network sizes - GPU warm, GPU cold (handle creation + symbolic analysis
+    # + solve, what an exploration level pays), the CPU port on one core; and one LAUNCH that integrates an ensemble of
+    # trajectories (kin_solve_ensemble: one workgroup per member, resident on the GPU)
+    if rank == 0 and world == 1 and args.crossover and args.solve_chunks > 0:
+        def crossover():
+            rows = []
+            for n in (100, 300, 1000, 3000, 10000):
+                netn, Ean, An = (net, Ea, A) if n == N else synthetic_crn(n, 5 * n)
+                u0n = np.zeros(n); u0n[0] = 1.0
+                kn = None
+                t1 = time.perf_counter()
+                hn = capi.HipNetwork.from_flat(netn)
+                try:
+                    hn.set_arrhenius(Ean, An, k_max=1e12)
+                    kn = hn.rates_at(1000.0)
+                    pr = kparams(20)
+                    _, _, rcn, stn, _ = hn.solve(pr, u0n)
+                    cold = time.perf_counter() - t1
+                    best = 1e9
+                    for _ in range(3):
+                        t1 = time.perf_counter()
+                        _, un, rcn, stn, _ = hn.solve(pr, u0n)
+                        best = min(best, time.perf_counter() - t1)
+                    row = {"species": n, "reactions": 5 * n, "gpu_warm_s": best, "gpu_cold_s": cold, "retcode": rcn, "steps": stn["n_steps"],
+                           "factorisations": stn["n_factor"], "dense_block": stn["lu_dense_dim"],
+                           "integrator": "resident (one workgroup owns the trajectory)" if stn["lu_slots"] <= 64 else "host-driven (one launch per stage)"}
+                    if n <= 400:   # the other integrator on the same network
+                        os.environ["KIN_RESIDENT"] = "0"
+                        try:
+                            hn.solve(pr, u0n)
+                            t1 = time.perf_counter(); hn.solve(pr, u0n); row["gpu_warm_host_driven_s"] = time.perf_counter() - t1
+                        finally:
+                            os.environ.pop("KIN_RESIDENT")
+                finally:
+                    hn.close()
+                prev = out.get("solve_network", {})
+                if n == N and "cpu_wall_same_chunks_s" in prev:      # measured above on this very network: not repeated
+                    row["cpu_port_1core_s"] = prev["cpu_wall_same_chunks_s"]
+                    row["cpu_chunks"] = prev["same_chunks"]
+                    row["gpu_same_chunks_s"] = prev["gpu_wall_same_chunks_s"]
+                elif not args.no_cpu:
+                    from oracle import cpu_bdf
+                    nck = 20 if n <= 3000 else 2
+                    cs = cpu_bdf.CpuSolver(netn)
+                    cp = dict(tspan=(0.0, 1e-3 * nck), solve_chunks=True, solve_chunkstep=1e-3)
+                    cs.solve(cp, u0n, k0=kn)
+                    t1 = time.perf_counter(); cs.solve(cp, u0n, k0=kn); cw = time.perf_counter() - t1
+                    row["cpu_port_1core_s"] = cw
+                    row["cpu_chunks"] = nck
+                    if nck == 20:
+                        row["gpu_over_cpu_1core"] = cw / best
+                rows.append(row)
+            return {"workload": "static 1000 K, 20 default chunks of 1 ms from u0 = delta on species 0, default tolerances", "rows": rows,
+                    "note": "cpu_port_1core_s at 10 000 species is for 2 chunks (cpu_chunks); the like-for-like 2-chunk pair is speedup_same_chunks_1core"}
+
+        def ensemble_launch():
+            res = {}
+            for n, Ks in ((300, (16, 256)), (1000, (16, 256))):
+                netn, Ean, An = synthetic_crn(n, 5 * n)
+                hn = capi.HipNetwork.from_flat(netn)
+                try:
+                    hn.set_arrhenius(Ean, An, k_max=1e12)
+                    U0 = np.zeros((max(Ks), n)); U0[:, 0] = 1.0
+                    for K in Ks:
+                        Tm = np.linspace(900.0, 1300.0, K)
+                        hn.solve_ensemble(kparams(2), U0[:K], T=Tm)
+                        t1 = time.perf_counter()
+                        _, ue, nsv, rcs, sts = hn.solve_ensemble(kparams(2), U0[:K], T=Tm)
+                        w = time.perf_counter() - t1
+                        res[f"{n}_species_K{K}"] = {"wall_s": w, "solves_per_s": K / w, "members_ok": int((rcs == 0).sum()), "members": K,
+                                                    "steps_per_member": float(np.mean([q["n_steps"] for q in sts]))}
+                finally:
+                    hn.close()
+            return dict(res, workload="kin_solve_ensemble: K members (900-1300 K) of one network, first 2 default chunks each, ONE launch, "
+                                      "host buffers in and out", kernel="kin::resident_bdf_kernel")
+        sn = out.setdefault("solve_network", {})
+        guarded(sn, "crossover", crossover)
+        guarded(sn, "ensemble_one_launch", ensemble_launch)
 
     # ---- CPU baseline for the headline metric: oracle RHS, 1 core, bounded sample
     if rank == 0 and not args.no_cpu and world == 1:

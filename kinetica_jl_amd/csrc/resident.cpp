@@ -124,7 +124,7 @@ void ResidentDeleter::operator()(ResidentSolver* p) const { delete p; }
 namespace {
 
 int resident_max_n() {
-  static const int v = getenv("KIN_RESIDENT_MAX_N") ? atoi(getenv("KIN_RESIDENT_MAX_N")) : 1500;   // (plus RES_MAX_DENSE on the Schur block)
+  static const int v = getenv("KIN_RESIDENT_MAX_N") ? atoi(getenv("KIN_RESIDENT_MAX_N")) : 400;   // (plus RES_MAX_DENSE on the Schur block)
   return v;
 }
 

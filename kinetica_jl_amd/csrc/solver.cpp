@@ -1390,10 +1390,11 @@ void integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, ki
 }
 
 void solution_max(kin_network* h, double* out_umax) {
-  if (!h->solver) throw KinError(ERR_STATE, "no solution stored");
-  Solver& S = *h->solver;
-  launch_colmax((int)h->host.N, h->n_saved, h->d_sol_u.p, S.umax.p, h->stream);
-  S.umax.download(out_umax, h->host.N, h->stream);
+  if (h->n_saved <= 0) throw KinError(ERR_STATE, "no solution stored");
+  // (the stored solution may come from the resident integrator: no Solver object then; the scratch vector is the handle's)
+  h->du.alloc(h->host.N);
+  launch_colmax((int)h->host.N, h->n_saved, h->d_sol_u.p, h->du.p, h->stream);
+  h->du.download(out_umax, h->host.N, h->stream);
   KIN_HIP(hipStreamSynchronize(h->stream));
 }
 

@@ -18,7 +18,7 @@ void integrator_init(kin_network* h, const kin_params& p, const double* u0, cons
 int64_t integrator_step(kin_network* h, int64_t max_steps);
 void integrator_state(kin_network* h, double* t, double* u, int32_t* retcode, kin_stats* stats);
 // Resident integrator (resident.cpp): the whole solve in one launch, one workgroup per trajectory. `resident_eligible`:
-// the network is small enough (KIN_RESIDENT_MAX_N, default 1500 species), the call has a save grid and uses none of the
+// the network is small enough (KIN_RESIDENT_MAX_N, default 400 species: measured crossover against the host-driven path), the call has a save grid and uses none of the
 // features that stay on the host-driven path (continuous rates, explicit solver, manual stepping, traces, fault injection);
 // KIN_RESIDENT=0 switches the path off.
 bool resident_eligible(kin_network* h, const kin_params& p, bool continuous, bool explicit_solver);

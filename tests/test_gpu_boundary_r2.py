@@ -63,9 +63,11 @@ def test_dtmin_ends_in_dtlessthanmin_and_the_retry_loop_answers():
     h.close()
 
 
-def test_synchronising_hand_over_gives_the_same_trajectory():
+def test_synchronising_hand_over_gives_the_same_trajectory(monkeypatch):
     """KIN_NO_FAST_SYNC=1 forces the copy + hipStreamSynchronize hand-over at the end of every step attempt (the
-    fallback of the pinned-memory sequence number): same kernels, same numbers."""
+    fallback of the pinned-memory sequence number): same kernels, same numbers. (Host-driven integrator forced: the
+    resident kernel that otherwise takes a network of this size has no hand-over.)"""
+    monkeypatch.setenv("KIN_RESIDENT", "0")
     net, Ea, A = synthetic_crn(300, 1500)
     k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
     u0 = np.zeros(300); u0[0] = 1.0

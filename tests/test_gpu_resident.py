@@ -1,0 +1,197 @@
+"""GPU parity tests of the resident integrator (kinetica_jl_amd/csrc/resident.hip: one workgroup owns one trajectory for the
+whole solve) through the C ABI: kin_solve on small networks (routed there automatically), kin_solve_ensemble. References: the
+committed Radau truths, the compiled CPU port at tight tolerances, the host-driven multi-kernel integrator (KIN_RESIDENT=0),
+and the CPU replay of the very controller the kernel runs (tests/res_host.py). Reference semantics: solve_network's chunk
+loop, discrete rate updates and adaptive_solve! retries (methods.jl:185-303, 717-865; solve_utils.jl:376-424, 435-509)."""
+import numpy as np
+import pytest
+
+from kinetica_jl_amd import capi
+from kinetica_jl_amd.synth import from_lists, synthetic_crn
+from oracle import cpu_bdf
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def kp(t1, chunk=1e-3, save=None, chunks=True, **kw):
+    d = dict(tspan0=0.0, tspan1=t1, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=1 if chunks else 0,
+             ban_negatives=0, solve_chunkstep=chunk, maxiters=100000, save_interval=-1.0 if save is None else save, dtmin=0.0)
+    d.update(kw)
+    return capi.KinParams(**d)
+
+
+def units(u, ref, atol=1e-10, rtol=1e-8):
+    return float((np.abs(u - ref) / (atol + rtol * np.abs(ref))).max())
+
+
+ROB = from_lists(3, [[(0, 1)], [(1, 2)], [(1, 1), (2, 1)]], [[(1, 1)], [(1, 1), (2, 1)], [(0, 1), (2, 1)]])
+ROB_K = np.array([0.04, 3e7, 1e4])
+
+
+def host_path(monkeypatch, on):
+    if on:
+        monkeypatch.setenv("KIN_RESIDENT", "0")
+    else:
+        monkeypatch.delenv("KIN_RESIDENT", raising=False)
+
+
+def test_small_network_against_tight_truth_host_path_and_replay(monkeypatch):
+    """300 species, 4 default chunks: the resident kernel, the host-driven path and the CPU replay of the kernel's controller
+    against a 1000x tighter integration of the CPU port. Resident kernel and replay run the SAME controller: same step counts up
+    to rounding of the linear algebra."""
+    from tests.res_host import HostResident
+    net, Ea, A = synthetic_crn(300, 1500)
+    k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
+    u0 = np.zeros(300); u0[0] = 1.0
+    tt, ut, rct, _ = cpu_bdf.CpuSolver(net).solve(dict(tspan=(0.0, 4e-3), abstol=1e-13, reltol=1e-11, dtmin=1e-300, adaptive_tols=False), u0, k0=k)
+    assert rct == 0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates(k)
+    host_path(monkeypatch, False)
+    t, u, rc, st, status = h.solve(kp(4e-3), u0)
+    assert status == capi.KIN_OK and rc == 0 and st["n_chunks"] == 4 and st["n_restarts"] == 4
+    assert st["lu_slots"] <= 64 and st["n_lu_reused"] > 0.8 * st["n_steps"]          # the resident path's cache has 64 slots at most
+    np.testing.assert_array_equal(t, tt)
+    assert units(u, ut) < 100
+    host_path(monkeypatch, True)
+    th, uh, rch, sth, _ = h.solve(kp(4e-3), u0)
+    assert rch == 0 and sth["lu_slots"] > 64 and units(uh, ut) < 100
+    assert abs(st["n_steps"] - sth["n_steps"]) <= 0.05 * sth["n_steps"] + 5
+    hr = HostResident(net)
+    tr, ur, rcr, sr = hr.solve(kp(4e-3), u0, k0=k)
+    assert rcr == 0 and abs(st["n_steps"] - sr["n_steps"]) <= 0.03 * sr["n_steps"] + 3
+    assert abs(st["n_factor"] - sr["n_factor"]) <= 0.15 * sr["n_factor"] + 5
+    assert units(u, ur) < 100
+    hr.close(); h.close()
+
+
+def test_known_answers_ramp_and_grids(golden_dir, monkeypatch):
+    host_path(monkeypatch, False)
+    z = np.load(golden_dir + "/truth_small.npz")
+    h = capi.HipNetwork.from_flat(ROB)
+    h.set_rates(ROB_K)
+    t, u, rc, st, _ = h.solve(kp(40.0, chunks=False, save=4.0), [1.0, 0.0, 0.0])
+    assert rc == 0 and st["lu_slots"] <= 64
+    np.testing.assert_allclose(t, z["rober_t"])
+    assert units(u, z["rober_u"]) < 100
+    # a save interval that does not divide the chunk (the chunk end is a save point on the last chunk only)
+    t2, u2, rc2, _, _ = h.solve(kp(8.0, chunk=4.0, save=1.5), [1.0, 0.0, 0.0])
+    tc, uc, rcc, _ = cpu_bdf.CpuSolver(ROB).solve(dict(tspan=(0.0, 8.0), solve_chunkstep=4.0, save_interval=1.5), [1.0, 0.0, 0.0], k0=ROB_K)
+    assert rc2 == 0
+    np.testing.assert_allclose(t2, tc, rtol=0, atol=1e-15)
+    assert units(u2, uc) < 10
+    h.close()
+    # 60 species under a temperature ramp: rates from T_stops on the device, and from a table; complete and chunkwise
+    net, Ea, A = synthetic_crn(60, 300, seed=11)
+    u0 = np.zeros(60); u0[0] = 1.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e3)
+    tst = np.arange(8) * 0.125
+    t, u, rc, st, _ = h.solve(kp(1.0, chunks=False, save=0.0625), u0, tstops=tst, T_stops=z["ramp_T"])
+    assert rc == 0 and st["n_restarts"] == 8
+    np.testing.assert_allclose(t, z["ramp_t"], rtol=0, atol=1e-15)
+    assert units(u, z["ramp_u"]) < 100
+    ks = orc.rate_table(Ea, A, z["ramp_T"], k_max=1e3)
+    t2, u2, rc2, st2, _ = h.solve(kp(1.0, chunk=0.25, save=0.0625), u0, tstops=tst, k_table=ks)
+    assert rc2 == 0 and st2["n_chunks"] == 4 and st2["n_restarts"] == 8
+    assert units(u2, z["ramp_u"]) < 100
+    # the rates in force at the end of the solve are what the handle holds afterwards
+    np.testing.assert_allclose(h.get_rates(), ks[-1], rtol=1e-14)
+    h.rates_at(1000.0)
+    t3, u3, rc3, _, _ = h.solve(kp(1.0, chunks=False, save=0.0625), u0)
+    assert rc3 == 0 and units(u3, z["syn_u"]) < 100
+    h.close()
+
+
+def test_failure_semantics_match_the_host_path(monkeypatch):
+    h = capi.HipNetwork.from_flat(ROB)
+    h.set_rates(ROB_K)
+    for bad, want in ((dict(dtmin=1.0), 2), (dict(maxiters=5), 1)):
+        res = {}
+        for on in (False, True):
+            host_path(monkeypatch, on)
+            t, u, rc, st, status = h.solve(kp(40.0, chunks=False, save=4.0, **bad), [1.0, 0.0, 0.0])
+            res[on] = (len(t), rc, st["n_retries"], status, st["final_abstol"])
+            assert status == capi.KIN_ERR_SOLVE_FAILED and rc == want and st["n_retries"] == 4
+        assert res[False] == res[True]
+    host_path(monkeypatch, False)
+    t, u, rc, st, status = h.solve(kp(40.0, chunks=False, save=4.0, dtmin=1.0, adaptive_tols=0), [1.0, 0.0, 0.0])
+    assert rc == 2 and st["n_retries"] == 0
+    # ban_negatives: no negative concentration in any saved state
+    net, Ea, A = synthetic_crn(200, 1000)
+    hh = capi.HipNetwork.from_flat(net)
+    hh.set_arrhenius(Ea, A, k_max=1e12)
+    hh.rates_at(1400.0)
+    u0 = np.zeros(200); u0[0] = 1.0
+    t, u, rc, st, _ = hh.solve(kp(2e-3, ban_negatives=1), u0)
+    assert rc == 0 and u.min() >= 0.0
+    hh.close(); h.close()
+
+
+def test_ensemble_members_are_bit_identical_to_solo_solves():
+    net, Ea, A = synthetic_crn(300, 1500)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    rng = np.random.default_rng(7)
+    K = 12
+    U0 = np.zeros((K, 300)); U0[:, 0] = 1.0
+    U0[:, 1:4] = rng.uniform(0.0, 0.1, (K, 3))
+    T = np.linspace(900.0, 1400.0, K)
+    # per-member temperatures
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(2e-3), U0, T=T)
+    assert (rcs == 0).all() and (ns == 3).all() and len(t) == 3
+    for i in (0, 5, K - 1):
+        h.rates_at(float(T[i]))
+        ts, us, rc, st, _ = h.solve(kp(2e-3), U0[i])
+        assert rc == 0 and np.array_equal(ts, t) and np.array_equal(us, u[i]) and st["n_steps"] == sts[i]["n_steps"]
+    # per-member rate constants (any calculator), and the handle's own rates for every member
+    ks = np.array([h.rates_at(float(Ti)) for Ti in T])     # the device's own Arrhenius values: bit-identical inputs
+    t2, u2, ns2, rcs2, _ = h.solve_ensemble(kp(2e-3), U0, k=ks)
+    assert np.array_equal(u2, u)
+    h.set_rates(ks[3])
+    t3, u3, _, rcs3, _ = h.solve_ensemble(kp(2e-3), U0[:4])
+    assert (rcs3 == 0).all() and np.array_equal(u3[3], u[3])
+    # shared discrete rate updates (zero-order hold at tstops)
+    tst = np.arange(4) * 0.5e-3
+    Ts = np.array([900.0, 1000.0, 1100.0, 1200.0])
+    t4, u4, ns4, rcs4, sts4 = h.solve_ensemble(kp(2e-3, save=2.5e-4), U0[:5], tstops=tst, T_stops=Ts)
+    assert (rcs4 == 0).all() and sts4[0]["n_restarts"] == 4
+    ts, us, rc, _, _ = h.solve(kp(2e-3, save=2.5e-4), U0[2], tstops=tst, T_stops=Ts)
+    assert np.array_equal(ts, t4) and np.array_equal(us, u4[2])
+    # argument errors
+    with pytest.raises(capi.KineticaHipError):
+        h.solve_ensemble(kp(2e-3), U0, k=ks, T=T)
+    with pytest.raises(capi.KineticaHipError):
+        h.solve_ensemble(kp(2e-3, chunks=False), U0, T=T)          # no save grid
+    h.close()
+
+
+def test_a_member_that_fails_does_not_disturb_the_others():
+    h = capi.HipNetwork.from_flat(ROB)
+    ks = np.array([ROB_K, ROB_K * np.array([1.0, 1e30, 1.0]), ROB_K])      # member 1: rates that overflow the state
+    U0 = np.tile([1.0, 0.0, 0.0], (3, 1))
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(40.0, chunks=False, save=4.0, maxiters=2000), U0, k=ks)
+    assert rcs[0] == 0 and rcs[2] == 0 and np.array_equal(u[0], u[2]) and ns[0] == 11
+    h.set_rates(ROB_K)
+    ts, us, rc, _, _ = h.solve(kp(40.0, chunks=False, save=4.0, maxiters=2000), [1.0, 0.0, 0.0])
+    assert np.array_equal(us, u[0])
+    h.close()
+
+
+def test_mid_size_network_through_the_ensemble_entry_point():
+    """1 000 species: beyond the single-solve routing threshold (the host-driven path is faster for ONE trajectory there) but
+    inside the resident kernel's LDS budget: kin_solve_ensemble integrates it, members against the host-driven kin_solve."""
+    net, Ea, A = synthetic_crn(1000, 5000)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    u0 = np.zeros(1000); u0[0] = 1.0
+    T = np.array([1000.0, 1100.0])
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(2e-3), np.tile(u0, (2, 1)), T=T)
+    assert (rcs == 0).all() and sts[0]["lu_dense_dim"] > 100
+    for i in range(2):
+        h.rates_at(float(T[i]))
+        ts, us, rc, st, _ = h.solve(kp(2e-3), u0)
+        assert rc == 0 and st["lu_slots"] > 64                    # host-driven path
+        assert units(u[i], us) < 150                              # two integrators, each within ~50 units of the truth
+    h.close()

@@ -198,7 +198,10 @@ def test_speculative_enqueue_of_the_next_step_changes_nothing(monkeypatch):
     """The next step's predictor and first corrector batch are enqueued behind the current step's batch, before the host
     knows how it ended (solver.cpp: enqueue_speculative; KIN_SPECULATE=0 switches it off): same arithmetic on the device,
     so every mode of the driver must return bit-identical results and counters - chunkwise on a save grid, every step
-    saved, one integration over the whole span, rate updates at tstops, negative states banned, manual stepping."""
+    saved, one integration over the whole span, rate updates at tstops, negative states banned, manual stepping.
+    (The host-driven integrator is forced: networks of this size are otherwise integrated by the resident kernel, which has
+    no host in its step chain to speculate for.)"""
+    monkeypatch.setenv("KIN_RESIDENT", "0")
     net, Ea, A = synthetic_crn(300, 1500)
     u0 = np.zeros(300); u0[0] = 1.0
     tst = np.arange(0, 9) * 1e-3
@@ -498,10 +501,13 @@ def test_continuous_rate_updates_n3():
     h.close()
 
 
-def test_return_integrator_n1(golden_dir):
+def test_return_integrator_n1(golden_dir, monkeypatch):
     """return_integrator=true (methods.jl:175-178, 242-246, 706-709): the initialised integrator is
-    stepped by the caller. Same kernels and step logic as kin_solve, so manual stepping reproduces
-    kin_solve's every-step output exactly."""
+    stepped by the caller. Same kernels and step logic as the host-driven kin_solve, so manual stepping reproduces
+    that kin_solve's every-step output exactly (a network of this size would otherwise be integrated by the resident
+    kernel - same algorithm, results within the tolerance, tests/test_gpu_resident.py - and manual stepping is a
+    host-driven feature)."""
+    monkeypatch.setenv("KIN_RESIDENT", "0")
     from kinetica_jl_amd import conditions as C
     from kinetica_jl_amd import solving as S
     net, Ea, A = synthetic_crn(60, 300, seed=11)
