@@ -320,11 +320,15 @@ struct ResidentBdf {
         lu_valid = true;
       }
       if (!converged || (P.ban_negatives && a.any_negative)) {
-        h_abs *= 0.5;
-        change_D(order, 0.5);
+        // a failed corrector cuts the step to a quarter and does not count towards the history reset (CVODE: ETACF = 0.25,
+        // history rebuilt only after repeated error-test failures - solver.cpp: cf_eta / cf_resets); a banned negative state
+        // (isoutofdomain, methods.jl:169-171) halves it and counts
+        const double eta = !converged ? 0.25 : 0.5;
+        h_abs *= eta;
+        change_D(order, eta);
         n_equal = 0; lu_valid = false;
         st.n_rejected++;
-        fail_score += 1.0;
+        if (converged) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
       }

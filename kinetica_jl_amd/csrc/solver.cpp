@@ -115,6 +115,11 @@ struct Solver {
       if (const char* e = getenv("KIN_SPECULATE")) speculate = atoi(e) != 0;
       fuse_newton = lu.fused_tri && lu.m > 0 && lu.newton_grid() <= 10;
       if (const char* e = getenv("KIN_FUSE_NEWTON")) fuse_newton = atoi(e) != 0 && lu.fused_tri && lu.m > 0;
+      if (const char* e = getenv("KIN_ETACF")) cf_eta = atof(e);
+      if (const char* e = getenv("KIN_CF_RESET")) cf_resets = atoi(e) != 0;
+      if (const char* e = getenv("KIN_CF_GROWTH_CAP")) cf_growth_cap = atof(e);
+      if (const char* e = getenv("KIN_CF_SOFTCAP")) cf_softcap = atof(e);
+      if (const char* e = getenv("KIN_CF_RELAX")) cf_relax = atof(e);
       if (const char* e = getenv("KIN_CRATE_AGE")) crate_max_age = atoll(e);
       if (const char* e = getenv("KIN_CRATE_DYMAX")) crate_dy_max = atof(e);
       if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
@@ -320,6 +325,8 @@ struct Solver {
     order = 1;
     n_equal = 0;
     fail_score = 0.0;
+    cf_recent = false;
+    h_ceiling = INF;
     return true;
   }
 
@@ -515,6 +522,20 @@ struct Solver {
     for (int i = 1; i < (int)lu.slots.size(); i++) if (lu.slots[i].last_use < lu.slots[v].last_use) v = i;
     return v;
   }
+  // ---- memory of a convergence failure (CVODE: cvHandleNFlag / cvSetEta). A failed corrector cuts the step by `cf_eta`
+  // (CVODE's ETACF = 0.25; 0.5 until round 3), does not count towards the history reset unless `cf_resets` (CVODE rebuilds its
+  // history only after repeated ERROR-TEST failures: after a reset the order-1 predictor is explicit Euler, which at the step
+  // sizes of a late, slowly varying solution is far outside the corrector's convergence region - the complete-timespan C3
+  // solve then halved its step ten more times, each with a factorisation of its own), and the first step-size
+  // selection after it may grow the step by `cf_growth_cap` at most (CVODE: no growth on the step after a failure).
+  double cf_eta = 0.25, cf_growth_cap = 0.0;
+  bool cf_resets = false, cf_recent = false;
+  // ... and a soft ceiling on the step size: a corrector that fails with a matrix made for this very step from a current
+  // Jacobian says the STEP is too long (late in a solve the error test allows steps at which the corrector stalls on the
+  // rounding floor of f). The ceiling is set to cf_softcap x that step, every later step-size selection stays below
+  // it, and each selection relaxes it by cf_relax - the step size then hovers below the corrector's limit instead of
+  // overshooting it by the error test's factor of 10 and falling back by orders of magnitude. Cleared by a restart.
+  double cf_softcap = 0.0, cf_relax = 1.3, h_ceiling = INF;   // (off by default: measured WORSE on the run it was built for - the failing step size is not a stable threshold: 3 400 - 4 900 steps against 1 930)
   bool force_jac_refresh = false;   // a vanished pivot: the next attempt starts from a Jacobian at its own predictor
   // After an error-test rejection the retry gets a factorisation made for its own c (CVODE's rule: a failed error test
   // forces a linear-solver setup): a converged corrector whose matrix was reused carries an iteration error that the
@@ -758,13 +779,18 @@ struct Solver {
         lu_valid = true;
       }
       if (!converged || (ban_negatives && hc->any_negative)) {
-        // isoutofdomain (methods.jl:169-171) is treated like a failed corrector: halve the step
-        h_abs *= 0.5;
-        change_D(order, 0.5);
+        // a failed corrector cuts the step by cf_eta; isoutofdomain (methods.jl:169-171) halves it and counts like an
+        // error-test failure
+        const bool conv_failure = !converged;
+        const double eta = conv_failure ? cf_eta : 0.5;
+        if (conv_failure && cf_softcap > 0.0 && !hc->lu_bad) h_ceiling = std::min(h_ceiling, cf_softcap * h_abs);
+        h_abs *= eta;
+        change_D(order, eta);
         n_equal = 0;
         lu_valid = false;
         st.n_rejected++;
-        fail_score += 1.0;
+        cf_recent = cf_recent || conv_failure;
+        if (!conv_failure || cf_resets) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
       }
@@ -828,7 +854,11 @@ struct Solver {
       if (f > best) { best = f; arg = i; }
     }
     order += arg - 1;
-    const double factor = std::min(MAX_FACTOR, safety_o * best);
+    double factor = std::min(MAX_FACTOR, safety_o * best);
+    if (cf_recent && cf_growth_cap > 0.0) factor = std::min(factor, cf_growth_cap);
+    cf_recent = false;
+    if (h_abs * factor > h_ceiling) factor = std::max(h_ceiling / h_abs, MIN_FACTOR);   // (never a cut below what a rejection would make)
+    h_ceiling *= cf_relax;
     h_abs *= factor;
     change_D(order, factor);
     n_equal = 0;

@@ -351,12 +351,16 @@ class OracleBDF:
                 self.LU = None
                 self.jac_current = True
             if not converged or (self.ban_negatives and np.any(y_new < 0)):
-                self.h_abs *= 0.5
-                change_D(D, order, 0.5)
+                # a failed corrector cuts the step to a quarter and does NOT count towards the history reset (CVODE: ETACF = 0.25;
+                # its history is rebuilt only after repeated error-test failures); a banned negative state halves it and counts
+                eta = 0.25 if not converged else 0.5
+                self.h_abs *= eta
+                change_D(D, order, eta)
                 self.n_equal = 0
                 self.LU = None
                 self.stats["n_rejected"] += 1
-                self.fail_score += 1.0
+                if converged:
+                    self.fail_score += 1.0
                 if self.fail_score >= 3.0 and order > 1:
                     self._reset_history()
                     order = self.order

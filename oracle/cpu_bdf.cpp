@@ -748,11 +748,14 @@ struct Bdf {
       if (converged && ban_negatives)
         for (int64_t i = 0; i < N; i++) if (y[i] < 0.0) { negative = true; break; }
       if (!converged || negative) {
-        h_abs *= 0.5;
-        change_D(order, 0.5);
+        // a failed corrector cuts the step to a quarter and does not count towards the history reset (CVODE: ETACF = 0.25,
+        // history rebuilt only after repeated error-test failures); a banned negative state halves it and counts
+        const double eta = !converged ? 0.25 : 0.5;
+        h_abs *= eta;
+        change_D(order, eta);
         n_equal = 0; lu_valid = false;
         st.n_rejected++;
-        fail_score += 1.0;
+        if (converged) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
       }
