@@ -99,6 +99,21 @@ def c3_long():
     print("wrote truth_c3_long.npz", u[keep].shape, "x1e-2 vs x1e-3:", sc)
 
 
+def c3_mid():
+    """C3 over (0, 0.03) s = 30 default chunks (a shorter stand-in for c3_long on slow hosts): every 5th chunk end is stored."""
+    net, Ea, A = synthetic_crn(10000, 50000)
+    k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
+    u0 = np.zeros(10000); u0[0] = 1.0
+    cs = cpu_bdf.CpuSolver(net)
+    pars = dict(tspan=(0.0, 0.03), solve_chunks=True, solve_chunkstep=1e-3)
+    t, u = solve(cs, pars, u0, 1e-3, k0=k)
+    t2, u2 = solve(cs, pars, u0, 1e-2, k0=k)
+    keep = list(range(0, 31, 5))
+    sc = float(units(u2[keep], u[keep]).max())
+    np.savez_compressed(os.path.join(HERE, "truth_c3_mid.npz"), t=t[keep], u=u[keep], self_check=sc, T=1000.0, keep=np.array(keep))
+    print("wrote truth_c3_mid.npz", u[keep].shape, "x1e-2 vs x1e-3:", sc)
+
+
 def c4_long():
     """C4 ramp, the first 20 chunks (0.2 s, 200 rate updates / restarts): chunk ends are stored."""
     net, tst, T, ks, u0, pars = ramp_inputs(10000, 50000, 20)
@@ -114,4 +129,4 @@ def c4_long():
 if __name__ == "__main__":
     for name in sys.argv[1:] or ["c3", "c4", "c5"]:
         print(name, flush=True)
-        {"c3": c3, "c4": c4, "c5": c5, "c3_long": c3_long, "c4_long": c4_long}[name]()
+        {"c3": c3, "c4": c4, "c5": c5, "c3_long": c3_long, "c4_long": c4_long, "c3_mid": c3_mid}[name]()

@@ -228,3 +228,73 @@ def test_c4_first_chunk_through_solve_network(golden_dir):
                                   low_k_cutoff="none")
     with pytest.raises(RuntimeError, match="ODE solution failed."):
         S.solve_network(S.VariableODESolve(pars0, cs, calc), sd, rd)
+
+
+def test_c4_twenty_chunks_against_truth(golden_dir):
+    """C4 as SURVEY 8(d) sizes the bounded run: the first 20 chunks of the ramp = 200 rate updates / integrator restarts,
+    against the committed tight-tolerance truth of the same stretch (tests/golden/make_truth_configs.py c4_long: the CPU port
+    at 1000x tighter tolerances; a second integration at 100x sits 6.6 units from it). The deviation stays at the level of the
+    3-chunk prefix (it does not grow with the number of restarts): the two species that carry it are the reactant and the
+    product of the dominant early channel, whose error the rms norm over 10 000 mostly empty species lets through."""
+    z = np.load(os.path.join(golden_dir, "truth_c4_long.npz"))
+    assert float(z["self_check"]) < 10.0
+    net, Ea, A = synthetic_crn(10000, 50000)
+    u0 = np.zeros(10000); u0[0] = 1.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    t, u, rc, st, status = h.solve(kp(0.2, 1e-2, 5e-3, dtmin=RAMP_DTMIN), u0, tstops=z["tstops"], T_stops=z["T_stops"])
+    assert status == capi.KIN_OK and rc == 0 and st["n_chunks"] == 20 and st["n_retries"] == 0
+    assert 200 <= st["n_restarts"] <= 204          # 200 rate intervals (+ a restart where a stop coincides with a chunk start in floating point)
+    sel = np.searchsorted(t, z["t"])
+    np.testing.assert_allclose(t[sel], z["t"], rtol=0, atol=1e-15)
+    e = units(u[sel], z["u"])
+    assert e.max() <= 620 and float(np.sqrt((e ** 2).mean(axis=1)).max()) <= 6.4      # measured 515 / 5.3 (bench.py, C4_prefix)
+    assert np.percentile(e, 99.9) <= 20                                                  # measured 15.6
+    # the two worst species of the 3-chunk prefix carry the maximum here as well
+    assert set(np.argsort(e.max(axis=0))[-2:]) <= {7705, 7150, *np.argsort(e.max(axis=0))[-6:]}
+    h.close()
+
+
+def test_c2_explicit_solve_at_the_configurations_size():
+    """BASELINE configs[1]: 1k species / 5k reactions, static conditions, "RHS kernel only, explicit solver": kin_solve_explicit
+    (Dormand-Prince 5(4) on the RHS kernels) at the configuration's size against SciPy's RK45 behind the same driver
+    (oracle/bdf.py, explicit=True): the same step sequence. Narrow-k variant with k_max = 1e3, as tools/run_configs.py runs C2:
+    with the cap at 1e12 the fastest time scale is 1e-12 s and no explicit method integrates that to milliseconds."""
+    from kinetica_jl_amd.synth import narrow_k_variant
+    from oracle import bdf as obdf
+    net, Ea, A = synthetic_crn(1000, 5000)
+    k = orc.arrhenius(narrow_k_variant(Ea), A, 1000.0, k_max=1e3)
+    u0 = np.zeros(1000); u0[0] = 1.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates(k)
+    p = capi.KinParams(tspan0=0.0, tspan1=0.02, abstol=1e-8, reltol=1e-6, adaptive_tols=1, update_tols=0, solve_chunks=1, ban_negatives=0,
+                       solve_chunkstep=5e-3, maxiters=100000, save_interval=1e-3, dtmin=0.0)
+    t, u, rc, st, status = h.solve(p, u0, explicit=True)
+    on = orc.OracleNetwork.from_flat(net)
+    to, uo, rco, sto = obdf.solve_network_oracle(lambda kk: (lambda y: on.rhs(kk, y)), lambda kk: (lambda y: on.jac(kk, y)), 1000,
+                                                 dict(tspan=(0.0, 0.02), solve_chunks=True, solve_chunkstep=5e-3, save_interval=1e-3, abstol=1e-8,
+                                                      reltol=1e-6, explicit=True), u0, k0=k)
+    assert status == capi.KIN_OK and rc == 0 and rco == 0 and st["n_factor"] == 0 and st["n_jac"] == 0
+    assert st["n_steps"] == sto["n_steps"] and st["n_chunks"] == 4
+    np.testing.assert_allclose(t, to, rtol=0, atol=1e-15)
+    e = np.abs(u - uo) / (1e-8 + 1e-6 * np.abs(uo))
+    assert e.max() < 1e-2
+    np.testing.assert_allclose((u * net.mass).sum(axis=1), net.mass[0], rtol=1e-9)
+    h.close()
+
+
+def test_speculative_enqueue_is_bit_identical_at_c3_size(monkeypatch, c3):
+    """The speculative enqueue of the next step (solver.cpp) at the size the bench runs: the first 2 chunks of C3 with and
+    without it - identical states, times and counters (at 300 species: tests/test_gpu_solve.py)."""
+    net, Ea, A, k = c3
+    u0 = np.zeros(10000); u0[0] = 1.0
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KIN_SPECULATE", mode)
+        h = capi.HipNetwork.from_flat(net)
+        h.set_rates(k)
+        t, u, rc, st, _ = h.solve(kp(2e-3, 1e-3), u0)
+        res[mode] = (t, u, rc, {q: st[q] for q in ("n_steps", "n_rejected", "n_factor", "n_linsolve", "n_newton_fail", "n_jac", "n_lu_reused")})
+        h.close()
+    assert res["1"][2] == 0 and res["0"][2] == 0
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1]) and res["1"][3] == res["0"][3]
