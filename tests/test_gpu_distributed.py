@@ -113,3 +113,25 @@ def test_bench_two_ranks_on_one_card_end_to_end():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-pmc"],
                          env=dict(os.environ, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_bench_four_ranks_rehearsal_reports_who_took_part():
+    """The N > 2 case of the driver's scaling run, rehearsed with FOUR ranks on the one card (gloo; the box allows at most
+    six GPU processes, so the N = 8 case itself is the driver's): the JSON line names backend, world size and the device of
+    every rank, value is the whole-job aggregate, every rank solved its own replica."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--species", "1000", "--reactions", "5000",
+                        "--batch", "128", "--steps", "3", "--warmup", "1", "--solve-chunks", "2", "--no-cpu", "--no-pmc",
+                        "--sustain-seconds", "0", "--spinup-seconds", "0", "--replicas", ""], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 4 and rec["scaling"] == "weak" and rec["value"] > 0
+    who = rec["ranks"]
+    assert who["backend"] == "gloo" and who["world_size"] == 4 and sorted(m["rank"] for m in who["members"]) == [0, 1, 2, 3]
+    assert rec["solve_network"]["replicas"] == 4 and rec["solve_network"]["retcode"] == 0
+    assert rec["single_trajectory_rhs_allreduce"]["ranks"] == 4
