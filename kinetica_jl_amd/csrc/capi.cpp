@@ -355,7 +355,13 @@ int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, cons
   if (n_rows && !out_u && !n_saved) { *n_rows = make_res_grid(*params).cap; }   // size query
   else {
     if (h->k_pending) h->flush_pending_T(h->stream);
-    resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
+    // networks whose trajectory fits one compute unit: one workgroup per member, one launch (resident.cpp); larger ones:
+    // lockstep rounds of batched launches (ensemble.cpp). KIN_ENSEMBLE_BATCHED=1 forces the second form.
+    const bool force_batched = getenv("KIN_ENSEMBLE_BATCHED") && atoi(getenv("KIN_ENSEMBLE_BATCHED")) != 0;
+    if (!force_batched && resident_fits(h))
+      resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
+    else
+      batched_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
   }
   KIN_CATCH(h)
 }

@@ -9,8 +9,9 @@
 #include "tiled.hpp"
 
 namespace kin {
-struct Solver; struct IntegratorState; struct ResidentSolver;
+struct Solver; struct IntegratorState; struct ResidentSolver; struct EnsembleSolver;
 struct ResidentDeleter { void operator()(ResidentSolver* p) const; };   // resident.cpp (the type is complete there only)
+struct EnsembleDeleter { void operator()(EnsembleSolver* p) const; };   // ensemble.cpp
 }
 
 struct kin_network {
@@ -68,6 +69,7 @@ struct kin_network {
   std::unique_ptr<kin::Solver> solver;
   std::unique_ptr<kin::IntegratorState> integ;   // return_integrator=true stepping state
   std::unique_ptr<kin::ResidentSolver, kin::ResidentDeleter> resident;   // one-workgroup-per-trajectory integrator (resident.cpp)
+  std::unique_ptr<kin::EnsembleSolver, kin::EnsembleDeleter> ensemble;   // lockstep ensemble of large networks (ensemble.cpp)
   std::vector<double> sol_t, sol_u;
   kin::DevBuf<double> d_sol_u;   // saved states on the device, [n_saved][N]
   int64_t n_saved = 0;

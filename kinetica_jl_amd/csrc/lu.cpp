@@ -568,18 +568,20 @@ void SparseLU::analyze(int32_t n_, const std::vector<int32_t>& j_ptr, const std:
   lap("backward plans + first slot");
 }
 
+void SparseLU::alloc_slot(Slot& q, hipStream_t s) const {
+  q.W.alloc((size_t)w_size);
+  KIN_HIP(hipMemsetAsync(q.W.p, 0, (size_t)w_size * sizeof(double), s));
+  q.S2.alloc((size_t)std::max(mpad, 64) * std::max(mpad, 64));
+}
+
 void SparseLU::ensure_slots(int nslots, hipStream_t s) {
   while ((int)slots.size() < nslots) {
     slots.emplace_back();
-    Slot& q = slots.back();
-    q.W.alloc((size_t)w_size);
-    KIN_HIP(hipMemsetAsync(q.W.p, 0, (size_t)w_size * sizeof(double), s));
-    q.S2.alloc((size_t)std::max(mpad, 64) * std::max(mpad, 64));
+    alloc_slot(slots.back(), s);
   }
 }
 
-void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipStream_t s) {
-  Slot& q = slots[slot];
+void SparseLU::factor_into(double c, const double* d_jvals, Slot& q, double* pinv_scratch, int* bad, hipStream_t s) {
   double* W = q.W.p;
   // zero everything up to the solve vectors, then scatter I - c*J
   KIN_HIP(hipMemsetAsync(W, 0, (size_t)off_y * sizeof(double), s));
@@ -596,7 +598,7 @@ void SparseLU::factor(double c, const double* d_jvals, int slot, int* bad, hipSt
       launch_segsum(nvu_build.view(), SEG_PROD_NEG, W, W, SegExtra{}, s);
     }
   }
-  if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv.p, bad, s);
+  if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv_scratch, bad, s);
   q.c_fact = c;
   q.crate = 1.0;
   q.valid = true;

@@ -117,7 +117,11 @@ struct SparseLU {
   // M = I - c*J, factorised into slot `slot`
   // `bad`: device flag raised when a pivot vanishes (a multiplier exceeds 1e8 in magnitude or is not finite): pivoting
   // is static (diagonal), so the caller answers with a fresh Jacobian and a shorter step
-  void factor(double c, const double* d_jvals, int slot, int* bad, hipStream_t s);
+  void factor(double c, const double* d_jvals, int slot, int* bad, hipStream_t s) { factor_into(c, d_jvals, slots[slot], pinv.p, bad, s); }
+  // the same into a slot that lives outside this object (ensemble.cpp: every member of an ensemble has slots of its own, the
+  // symbolic tables are shared); `pinv_scratch`: 2 x 32 x 32 doubles, one per stream that factorises concurrently
+  void factor_into(double c, const double* d_jvals, Slot& q, double* pinv_scratch, int* bad, hipStream_t s);
+  void alloc_slot(Slot& q, hipStream_t s) const;   // value arrays of one slot, zeroed
   // solves M x = b in place with the factors of `slot`: b was written to W[yloc[v]], x is read from W[xloc[v]]
   // (W = that slot's array). `skip`: optional device flag making every kernel of the solve a no-op.
   void solve(const int* skip, int slot, hipStream_t s);

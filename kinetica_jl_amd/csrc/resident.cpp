@@ -197,6 +197,8 @@ bool resident_eligible(kin_network* h, const kin_params& p, bool continuous, boo
   return RS->ok;
 }
 
+bool resident_fits(kin_network* h) { return get_resident(h)->ok; }
+
 int resident_solve(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
                    const double* k_table, int64_t n_stops, kin_stats* stats) {
   auto wall0 = std::chrono::steady_clock::now();

@@ -27,6 +27,12 @@ int resident_solve(kin_network* h, const kin_params& p, const double* u0, const 
 void resident_ensemble(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
                        const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* out_rows,
                        double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats);
+// does the network fit the resident kernel (its state, rates and solve vectors in one compute unit's LDS)?
+bool resident_fits(kin_network* h);
+// K members of a network beyond that, advanced in lockstep rounds of batched launches (ensemble.cpp); same arguments
+void batched_ensemble(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
+                      const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* out_rows,
+                      double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats);
 // validation of a solve's arguments (ODESimulationParams constructor, params.jl:77-104, and the rate inputs); throws
 void validate_solve(kin_network* h, const kin_params& p, const double* tstops, const double* T_stops, const double* k_table,
                     int64_t n_stops, const double* t_nodes, const double* T_nodes, int64_t n_nodes, bool need_handle_rates);

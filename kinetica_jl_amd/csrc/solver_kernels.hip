@@ -5,6 +5,7 @@
 // (one host synchronisation per step attempt instead of one per Newton iteration).
 #include "lu.hpp"
 #include "solver_kernels.hpp"
+#include "ensemble.hpp"
 
 #include "exp_tab.hpp"
 #include "gj_dev.hpp"
@@ -1126,5 +1127,7 @@ void launch_rates_skip_T(int64_t R, const ArrheniusAt& at, double* k, const doub
   if (R == 0) return;
   hipLaunchKernelGGL(rates_skip_T_kernel, GRID1(R), 0, s, (int)R, at, k, u, x0, x1, rate, skip);
 }
+
+#include "ensemble_kernels.inc"
 
 }  // namespace kin

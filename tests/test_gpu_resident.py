@@ -195,3 +195,42 @@ def test_mid_size_network_through_the_ensemble_entry_point():
         assert rc == 0 and st["lu_slots"] > 64                    # host-driven path
         assert units(u[i], us) < 150                              # two integrators, each within ~50 units of the truth
     h.close()
+
+
+def test_lockstep_ensemble_of_a_large_network(monkeypatch):
+    """kin_solve_ensemble beyond the resident kernel's size (ensemble.cpp): members advance in lockstep rounds of batched
+    launches, each with the controller the resident kernel runs. At C3 size against solo kin_solve runs of the same inputs
+    (the host-driven integrator: same kernels' arithmetic, an independent controller implementation), and - forced at 1 000
+    species - against the resident kernel's ensemble of the same members."""
+    net, Ea, A = synthetic_crn(10000, 50000)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    u0 = np.zeros(10000); u0[0] = 1.0
+    T = np.array([1000.0, 1040.0, 1080.0])
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(2e-3), np.tile(u0, (3, 1)), T=T)
+    assert (rcs == 0).all() and (ns == 3).all() and sts[0]["lu_dense_dim"] > 900
+    for i in range(3):
+        h.rates_at(float(T[i]))
+        ts, us, rc, st, _ = h.solve(kp(2e-3), u0)
+        assert rc == 0 and np.array_equal(ts, t)
+        assert units(u[i], us) < 50                                              # measured 0 - 8
+        assert abs(sts[i]["n_steps"] - st["n_steps"]) <= 0.02 * st["n_steps"] + 2
+    # shared discrete rate updates through the lockstep path
+    tst = np.arange(4) * 0.5e-3
+    Ts = np.array([900.0, 1000.0, 1100.0, 1200.0])
+    t2, u2, ns2, rcs2, sts2 = h.solve_ensemble(kp(2e-3, save=5e-4), np.tile(u0, (2, 1)), tstops=tst, T_stops=Ts)
+    ts, us, rc, st, _ = h.solve(kp(2e-3, save=5e-4), u0, tstops=tst, T_stops=Ts)
+    assert (rcs2 == 0).all() and rc == 0 and np.array_equal(ts, t2) and sts2[0]["n_restarts"] == 4
+    assert units(u2[0], us) < 50 and np.array_equal(u2[0], u2[1])
+    h.close()
+    net, Ea, A = synthetic_crn(1000, 5000)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    u0 = np.zeros(1000); u0[0] = 1.0
+    T = np.array([950.0, 1050.0, 1150.0, 1250.0])
+    tr, ur, _, rcr, _ = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
+    monkeypatch.setenv("KIN_ENSEMBLE_BATCHED", "1")
+    tb, ub, _, rcb, stb = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
+    assert (rcr == 0).all() and (rcb == 0).all() and np.array_equal(tr, tb)
+    assert units(ub, ur) < 100
+    h.close()
