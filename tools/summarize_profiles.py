@@ -95,3 +95,18 @@ if sol:
     rec = [l for l in open(os.path.join(out, "solve_stats.log")) if l.startswith("{")]
     if rec:
         open(os.path.join(dst, f"{tag}_solve_stats.json"), "w").write(rec[-1])
+
+
+# ---- round 4: resident integrator (300 species, 20 chunks) and lockstep ensemble (10k species, K = 16)
+for sub, log, name in (("resident_stats", "resident_stats.log", "resident"), ("ensemble_stats", "ensemble_stats.log", "ensemble_lockstep")):
+    st = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not st:
+        continue
+    srows = list(csv.DictReader(open(st[0])))
+    with open(os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=srows[0].keys())
+        w.writeheader()
+        w.writerows([r for r in srows if "kin::" in r["Name"]])
+    rec = [l for l in open(os.path.join(out, log)) if l.startswith("{")]
+    if rec:
+        open(os.path.join(dst, f"{tag}_{name}_stats.json"), "w").write(rec[-1])
