@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <deque>
 #include <thread>
 
 #include "handle.hpp"
@@ -86,6 +87,25 @@ struct EnsembleSolver {
   std::vector<hipEvent_t> evs;          // per member: end of its factorisation chain
   int pool = 8;
   int n_parked = 0;
+  // The dense inverses of members that factorise at the same time run as ONE chain of launches (launch_gauss_jordan_batched:
+  // 157 us per matrix at 8 matrices against 460 us alone, tools/gj_probe.hip): a member's thread enqueues the sparse part of its
+  // factorisation on its pool stream and hands the dense block to this server; the server takes what has queued up while its
+  // previous batch was running (that wait IS the batching window; plus a short hold-off), at most GJ_BMAX. Measured at C3 size
+  // (tools/ens_gj_matrix.sh, best of 4): K = 16: 18.1 solves/s against 16.6-17.6 with every member's own chain, K = 32: 20.4-20.7
+  // against 18.4-18.9; 2.6-3.1 matrices per chain. The device is throughput-bound on the members' summed kernel time by then.
+  struct GjReq { int t; SparseLU::Slot* q; hipEvent_t ready; };
+  std::mutex gmu;
+  std::condition_variable gcv, gcv_members;
+  std::deque<GjReq> gq;
+  std::vector<char> g_enqueued;         // per member: its batch is in the stream and evs[t] recorded behind it
+  std::string g_error;
+  bool g_stop = false, g_batched = true;
+  std::thread g_thread;
+  hipStream_t gs = nullptr;
+  DevBuf<double> gpinv;
+  std::vector<hipEvent_t> pre_evs;      // per member: end of the sparse part
+  int64_t g_batches = 0, g_matrices = 0;
+  int g_min = 4, g_wait_us = 200;       // hold-off: a batch starts with 4 requests or 200 us after its first (KIN_ENSEMBLE_GJ_MIN / _WAIT_US)
   double t_enqueue = 0.0, t_sync = 0.0, t_round = 0.0;   // host seconds inside the rounds (KIN_TIMING=1)
   int64_t n_ops[16] = {};
 
@@ -116,6 +136,9 @@ struct EnsembleSolver {
     ok = true;
   }
   ~EnsembleSolver() {
+    stop_gj_server();
+    if (gs) (void)hipStreamDestroy(gs);
+    for (auto& e : pre_evs) if (e) (void)hipEventDestroy(e);
     for (auto& m_ : ms) if (m_) (void)hipStreamDestroy(m_);
     for (auto& e : evs) if (e) (void)hipEventDestroy(e);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -170,6 +193,15 @@ struct EnsembleSolver {
     ctrl_of.assign(K, BdfCtrl{});
     if (const char* e = getenv("KIN_ENSEMBLE_STREAMS")) pool = std::max(1, atoi(e));
     while ((int)evs.size() < K) { hipEvent_t e; KIN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); }
+    while ((int)pre_evs.size() < K) { hipEvent_t e; KIN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); pre_evs.push_back(e); }
+    if (!gs) KIN_HIP(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+    gpinv.alloc((size_t)GJ_BMAX * 2 * 32 * 32);
+    g_enqueued.assign(K, 0);
+    g_batched = !(getenv("KIN_ENSEMBLE_GJ_BATCHED") && atoi(getenv("KIN_ENSEMBLE_GJ_BATCHED")) == 0);
+    g_batches = g_matrices = 0;
+    g_min = 4; g_wait_us = 200;
+    if (const char* e = getenv("KIN_ENSEMBLE_GJ_MIN")) g_min = std::max(1, atoi(e));
+    if (const char* e = getenv("KIN_ENSEMBLE_GJ_WAIT_US")) g_wait_us = std::max(0, atoi(e));
     while ((int)ms.size() < pool) {
       hipStream_t m_; KIN_HIP(hipStreamCreateWithFlags(&m_, hipStreamNonBlocking));
       ms.push_back(m_); mpinv.emplace_back(); mpinv.back().alloc(2 * 32 * 32); ms_lock.emplace_back(new std::mutex());
@@ -303,15 +335,28 @@ struct EnsembleSolver {
       const int si = t % pool;
       hipStream_t f = ms[si];
       hipEvent_t done_ev = evs[t];
+      SparseLU::Slot& q = slots[t][slot];
+      const bool batched = g_batched && lu.m > 0;
       {
         std::lock_guard<std::mutex> g(*ms_lock[si]);
-        SparseLU::Slot& q = slots[t][slot];
         if (!q.W.p) lu.alloc_slot(q, f);
-        lu.factor_into(c, reps[t].jv, q, mpinv[si].p, d_bad.p + t, f);
+        if (batched) lu.factor_sparse_into(c, reps[t].jv, q, d_bad.p + t, f);
+        else lu.factor_into(c, reps[t].jv, q, mpinv[si].p, d_bad.p + t, f);
         if (keep_diag) { q.jd.alloc(N); launch_jac_diag(N, reps[t].jv, d_jdiag.p, q.jd.p, f); }
-        KIN_HIP(hipMemcpyAsync(h_bad + t, d_bad.p + t, sizeof(int), hipMemcpyDeviceToHost, f));
-        KIN_HIP(hipMemsetAsync(d_bad.p + t, 0, sizeof(int), f));
-        KIN_HIP(hipEventRecord(done_ev, f));
+        if (batched) KIN_HIP(hipEventRecord(pre_evs[t], f));
+        else {
+          KIN_HIP(hipMemcpyAsync(h_bad + t, d_bad.p + t, sizeof(int), hipMemcpyDeviceToHost, f));
+          KIN_HIP(hipMemsetAsync(d_bad.p + t, 0, sizeof(int), f));
+          KIN_HIP(hipEventRecord(done_ev, f));
+        }
+      }
+      if (batched) {
+        std::unique_lock<std::mutex> lk(gmu);
+        g_enqueued[t] = 0;
+        gq.push_back(GjReq{t, &q, pre_evs[t]});
+        gcv.notify_one();
+        gcv_members.wait(lk, [&] { return g_enqueued[t] != 0 || !g_error.empty(); });
+        if (!g_error.empty()) throw KinError(ERR_DEVICE, g_error);
       }
       KIN_HIP(hipEventSynchronize(done_ev));
       bad = h_bad[t] != 0;
@@ -319,6 +364,58 @@ struct EnsembleSolver {
     back();
     if (!err.empty()) throw KinError(ERR_DEVICE, "ensemble factorisation failed: " + err);
     return bad;
+  }
+  void gj_server() {
+    (void)hipSetDevice(h->device);
+    std::vector<GjReq> batch;
+    for (;;) {
+      batch.clear();
+      {
+        std::unique_lock<std::mutex> lk(gmu);
+        gcv.wait(lk, [&] { return g_stop || !gq.empty(); });
+        if (gq.empty()) return;          // stop requested and nothing left
+        // hold-off: members of a lockstep ensemble tend to factorise within a few rounds of each other
+        if ((int)gq.size() < g_min && g_wait_us > 0)
+          gcv.wait_for(lk, std::chrono::microseconds(g_wait_us), [&] { return g_stop || (int)gq.size() >= g_min; });
+        while (!gq.empty() && (int)batch.size() < GJ_BMAX) { batch.push_back(gq.front()); gq.pop_front(); }
+      }
+      std::string err;
+      try {
+        const int n = (int)batch.size();
+        double* S[GJ_BMAX]; double* S2[GJ_BMAX]; int* bad[GJ_BMAX];
+        for (int i = 0; i < n; i++) {
+          KIN_HIP(hipStreamWaitEvent(gs, batch[i].ready, 0));
+          S[i] = batch[i].q->W.p + lu.off_S; S2[i] = batch[i].q->S2.p; bad[i] = d_bad.p + batch[i].t;
+        }
+        const int where = launch_gauss_jordan_batched(n, S, S2, lu.mpad, gpinv.p, bad, gs);
+        for (int i = 0; i < n; i++) {
+          const int t = batch[i].t;
+          batch[i].q->sinv = where ? S2[i] : S[i];
+          KIN_HIP(hipMemcpyAsync(h_bad + t, d_bad.p + t, sizeof(int), hipMemcpyDeviceToHost, gs));
+          KIN_HIP(hipMemsetAsync(d_bad.p + t, 0, sizeof(int), gs));
+          KIN_HIP(hipEventRecord(evs[t], gs));
+        }
+        g_batches++; g_matrices += n;
+      } catch (const std::exception& e) { err = e.what(); }
+      {
+        std::lock_guard<std::mutex> lk(gmu);
+        if (!err.empty()) g_error = "dense-inverse server: " + err;
+        for (auto& r : batch) g_enqueued[r.t] = 1;
+      }
+      gcv_members.notify_all();
+      if (err.empty()) (void)hipEventSynchronize(evs[batch.back().t]);   // requests that arrive meanwhile form the next batch
+    }
+  }
+  void start_gj_server() {
+    stop_gj_server();
+    { std::lock_guard<std::mutex> lk(gmu); g_stop = false; g_error.clear(); gq.clear(); }
+    if (g_batched) g_thread = std::thread([this] { gj_server(); });
+  }
+  void stop_gj_server() {
+    if (!g_thread.joinable()) return;
+    { std::lock_guard<std::mutex> lk(gmu); g_stop = true; }
+    gcv.notify_all();
+    g_thread.join();
   }
   // a member that has finished no longer takes part; the round it was the last one missing from runs now
   void member_done() {
@@ -543,6 +640,7 @@ void batched_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
   std::vector<ResResult> res((size_t)K);
   std::vector<std::string> errs((size_t)K);
   std::vector<std::thread> th;
+  E.start_gj_server();
   for (int64_t t = 0; t < K; t++)
     th.emplace_back([&, t] {
       try {
@@ -558,6 +656,7 @@ void batched_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
       E.member_done();
     });
   for (auto& x : th) x.join();
+  E.stop_gj_server();
   for (auto& e : errs) if (!e.empty()) throw KinError(ERR_DEVICE, "ensemble member failed: " + e);
   const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   if (out_u) E.sol.download(out_u, (size_t)K * (size_t)g.cap * N, s);
@@ -568,6 +667,8 @@ void batched_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
   if (getenv("KIN_TIMING")) {
     fprintf(stderr, "[ensemble] %lld members, %lld rounds, wall %.4f s: inside rounds %.4f s (enqueue %.4f, waiting for the device %.4f), "
             "between rounds %.4f s\n", (long long)K, (long long)E.n_rounds, wall, E.t_round, E.t_enqueue, E.t_sync, wall - E.t_round);
+    fprintf(stderr, "[ensemble] dense inverses: %lld in %lld batched chains (%.2f per chain)\n", (long long)E.g_matrices, (long long)E.g_batches,
+            E.g_batches ? (double)E.g_matrices / (double)E.g_batches : 0.0);
     fprintf(stderr, "[ensemble] operations: vec %lld, rates %lld, rhs %lld, jac %lld, norms %lld, init_D %lld, drift %lld, factor %lld, corrector %lld (+%lld continued)\n",
             (long long)E.n_ops[K_VEC], (long long)E.n_ops[K_APPLY_RATES], (long long)E.n_ops[K_RHS], (long long)E.n_ops[K_JAC], (long long)E.n_ops[K_NORMS],
             (long long)E.n_ops[K_INIT_D], (long long)E.n_ops[K_DRIFT], (long long)E.n_ops[K_FACTOR], (long long)E.n_ops[K_CORRECTOR], (long long)E.n_ops[K_CORRECTOR_CONT]);

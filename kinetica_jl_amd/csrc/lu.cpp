@@ -582,6 +582,13 @@ void SparseLU::ensure_slots(int nslots, hipStream_t s) {
 }
 
 void SparseLU::factor_into(double c, const double* d_jvals, Slot& q, double* pinv_scratch, int* bad, hipStream_t s) {
+  factor_sparse_into(c, d_jvals, q, bad, s);
+  if (m > 0) q.sinv = launch_gauss_jordan(q.W.p + off_S, q.S2.p, mpad, pinv_scratch, bad, s);
+}
+
+// everything of a factorisation but the inverse of the dense Schur block (which is then complete in W + off_S, waiting to be
+// inverted: by factor_into on the same stream, or - for several slots at once - by launch_gauss_jordan_batched, ensemble.cpp)
+void SparseLU::factor_sparse_into(double c, const double* d_jvals, Slot& q, int* bad, hipStream_t s) {
   double* W = q.W.p;
   // zero everything up to the solve vectors, then scatter I - c*J
   KIN_HIP(hipMemsetAsync(W, 0, (size_t)off_y * sizeof(double), s));
@@ -598,7 +605,6 @@ void SparseLU::factor_into(double c, const double* d_jvals, Slot& q, double* pin
       launch_segsum(nvu_build.view(), SEG_PROD_NEG, W, W, SegExtra{}, s);
     }
   }
-  if (m > 0) q.sinv = launch_gauss_jordan(W + off_S, q.S2.p, mpad, pinv_scratch, bad, s);
   q.c_fact = c;
   q.crate = 1.0;
   q.valid = true;

@@ -121,6 +121,7 @@ struct SparseLU {
   // the same into a slot that lives outside this object (ensemble.cpp: every member of an ensemble has slots of its own, the
   // symbolic tables are shared); `pinv_scratch`: 2 x 32 x 32 doubles, one per stream that factorises concurrently
   void factor_into(double c, const double* d_jvals, Slot& q, double* pinv_scratch, int* bad, hipStream_t s);
+  void factor_sparse_into(double c, const double* d_jvals, Slot& q, int* bad, hipStream_t s);
   void alloc_slot(Slot& q, hipStream_t s) const;   // value arrays of one slot, zeroed
   // solves M x = b in place with the factors of `slot`: b was written to W[yloc[v]], x is read from W[xloc[v]]
   // (W = that slot's array). `skip`: optional device flag making every kernel of the solve a no-op.
@@ -140,6 +141,10 @@ void launch_lu_recip(int n, const double* diag, double* dinv, hipStream_t s);
 void launch_lu_mono(int n_ent, const int32_t* ent_ptr, const int32_t* mono_ptr, const int32_t* fac, const float* sign,
                     const int32_t* dst, double* W, hipStream_t s);
 double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, int* bad, hipStream_t s);
+// the same for up to GJ_BMAX matrices of one size in one chain of launches (blockIdx.z = matrix)
+constexpr int GJ_BMAX = 16;
+struct GjBatch { double* X[GJ_BMAX]; double* Y[GJ_BMAX]; double* pinv[GJ_BMAX]; double* pinv_next[GJ_BMAX]; int* bad[GJ_BMAX]; };
+int launch_gauss_jordan_batched(int n, double* const* S, double* const* S2, int32_t mpad, double* pinv, int* const* bad, hipStream_t s);
 void launch_gemv(const double* S, int32_t ld, int32_t m, const double* y, double* x, const int* skip, hipStream_t s);
 
 }  // namespace kin

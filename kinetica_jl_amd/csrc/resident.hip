@@ -1,8 +1,8 @@
-// Resident integrator (gfx950): one 1024-thread workgroup owns one trajectory for the whole solve. The controller is
+// Resident integrator (gfx950): one 512-thread workgroup owns one trajectory for the whole solve. The controller is
 // resident_core.hpp, compiled here with a backend whose operations are workgroup-wide phases over the trajectory's
 // vectors in global memory (L2-resident for the network sizes this path takes: up to ~2 000 species), separated by
 // workgroup barriers where the multi-workgroup integrator of solver.cpp has kernel boundaries.
-//   * Wavefront 0 runs the controller (its 64 lanes redundantly, on identical scalars); the other fifteen wait at a barrier
+//   * Wavefront 0 runs the controller (its 64 lanes redundantly, on identical scalars); the other seven wait at a barrier
 //     for its next command - the phase to run and its scalar arguments, posted in LDS - run that phase together with
 //     wavefront 0 and come back. (First version: all 1 024 threads ran the controller redundantly. Its live scalars are
 //     spilled per LANE around every phase call, and sixteen wavefronts doing that cost 70 us per step at 300 species.)

@@ -1,5 +1,5 @@
 // Resident integrator: device-visible tables and the launcher (resident.hip), host-side owner (resident.cpp).
-// One 1024-thread workgroup integrates one trajectory from u0 to the end of the time span - chunk loop, rate updates,
+// One 512-thread workgroup (8 wavefronts, 256 VGPRs each) integrates one trajectory from u0 to the end of the time span - chunk loop, rate updates,
 // retries, BDF steps, Jacobians, factorisations and corrector iterations - without leaving the GPU (resident_core.hpp).
 #pragma once
 #include "kernels.hpp"
@@ -38,7 +38,7 @@ struct ResTrajDev {
   ResResult* result;
 };
 
-// enqueues the solve of K trajectories (grid = K workgroups of 1024 threads)
+// enqueues the solve of K trajectories (grid = K workgroups of RES_WG = 512 threads)
 // `m`: dimension of the dense Schur block (sizes the dynamic LDS of its row panel; at most RES_MAX_DENSE)
 constexpr int RES_MAX_DENSE = 512;
 // dynamic LDS of the kernel: y, d, psi, scale (4 N), the solve-vector window of W, max(R, row panel of the dense inverse)

@@ -3,7 +3,7 @@
 // the BDF integrator that stands in for the reference's CVODE_BDF (solver.cpp: Solver::restart / step / select_order /
 // interpolate, including the LU cache and its guards), written ONCE against a backend `B` that supplies the vector
 // operations, the Jacobian, the factorisation and the corrector iteration:
-//   * resident.hip compiles it for the device: ONE 1024-thread workgroup owns one trajectory for the whole solve - every
+//   * resident.hip compiles it for the device: ONE 512-thread workgroup owns one trajectory for the whole solve - every
 //     thread runs this controller redundantly on identical scalars (reduction results are broadcast), the backend's
 //     operations are workgroup-wide phases separated by barriers; no host round trip, no kernel boundary per step;
 //   * tests/native/resident_host.cpp compiles it for the CPU with a sequential backend over the same tables: the

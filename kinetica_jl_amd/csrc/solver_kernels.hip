@@ -245,7 +245,7 @@ __device__ __forceinline__ void gj_invert_block_lds(double (*A)[GJ_NB + 1], doub
   if (bad && vanished) *bad = 1;                // benign race: every writer stores the same value
 }
 
-__global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv, int* bad) {
+__device__ __forceinline__ void gj_pivot_body(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv, int* bad) {
   __shared__ double A[GJ_NB][GJ_NB + 1];
   __shared__ double XS[GJ_XS];
   const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
@@ -254,13 +254,22 @@ __global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict_
   __syncthreads();
   gj_invert_block_lds(A, XS, pinv, bad);
 }
+__global__ __launch_bounds__(256) void gj_pivot_kernel(const double* __restrict__ X, int ld, int kb, double* __restrict__ pinv, int* bad) {
+  gj_pivot_body(X, ld, kb, pinv, bad);
+}
+// Several matrices of one size in one launch (the lockstep ensemble's members that factorise at the same time, ensemble.cpp):
+// blockIdx.z = matrix; the arithmetic of each is exactly the single-matrix kernel's.
+__global__ __launch_bounds__(256) void gj_pivot_batched_kernel(GjBatch B, int ld, int kb) {
+  const int z = blockIdx.z;
+  gj_pivot_body(B.X[z], ld, kb, B.pinv[z], B.bad[z]);
+}
 
 // grid = (mpad/64, 1 + mpad/64): block row 0 (dispatched first) holds ONE active workgroup (blockIdx.x == 0) that
 // looks ahead: it recomputes only the next pivot block of Y and inverts it into pinv_next while the
 // regular workgroups update their tiles, which takes the pivot inversion off the critical path.
-__global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict__ X, double* __restrict__ Y, int ld, int kb,
-                                                        int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next,
-                                                        int* bad) {
+__device__ __forceinline__ void gj_update_body(const double* __restrict__ X, double* __restrict__ Y, int ld, int kb,
+                                               int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next,
+                                               int* bad) {
   __shared__ double RP[GJ_NB][64 + 2];                 // row panel slice of this tile's columns
   __shared__ double A[GJ_NB][GJ_NB + 1];               // look-ahead workgroup only
   __shared__ double XS[GJ_XS];
@@ -362,6 +371,15 @@ __global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict
     }
   }
 }
+__global__ __launch_bounds__(256) void gj_update_kernel(const double* __restrict__ X, double* __restrict__ Y, int ld, int kb,
+                                                        int nblk, const double* __restrict__ pinv, double* __restrict__ pinv_next,
+                                                        int* bad) {
+  gj_update_body(X, Y, ld, kb, nblk, pinv, pinv_next, bad);
+}
+__global__ __launch_bounds__(256) void gj_update_batched_kernel(GjBatch B, int ld, int kb, int nblk) {
+  const int z = blockIdx.z;
+  gj_update_body(B.X[z], B.Y[z], ld, kb, nblk, B.pinv[z], B.pinv_next[z], B.bad[z]);
+}
 
 // returns the buffer that holds the inverse (S or S2)
 double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, int* bad, hipStream_t s) {
@@ -378,6 +396,25 @@ double* launch_gauss_jordan(double* S, double* S2, int32_t mpad, double* pinv, i
   }
   KIN_HIP(hipGetLastError());
   return X;
+}
+
+// n matrices (S[i], S2[i]; pivot scratch of 2 x 32 x 32 doubles each at pinv + 2048 i): one chain of launches for all of
+// them. Returns 0 when the inverses end up in S[i], 1 when in S2[i] (the same for all: one size).
+int launch_gauss_jordan_batched(int n, double* const* S, double* const* S2, int32_t mpad, double* pinv, int* const* bad, hipStream_t s) {
+  const int nblk = mpad / GJ_NB;
+  GjBatch B{};
+  for (int i = 0; i < n; i++) {
+    B.X[i] = S[i]; B.Y[i] = S2[i];
+    B.pinv[i] = pinv + (size_t)i * 2 * GJ_NB * GJ_NB; B.pinv_next[i] = B.pinv[i] + GJ_NB * GJ_NB;
+    B.bad[i] = bad[i];
+  }
+  hipLaunchKernelGGL(gj_pivot_batched_kernel, dim3(1, 1, n), dim3(256), 0, s, B, mpad, 0);
+  for (int kb = 0; kb < nblk; kb++) {
+    hipLaunchKernelGGL(gj_update_batched_kernel, dim3(mpad / 64, mpad / 64 + 1, n), dim3(256), 0, s, B, mpad, kb, nblk);
+    for (int i = 0; i < n; i++) { std::swap(B.X[i], B.Y[i]); std::swap(B.pinv[i], B.pinv_next[i]); }
+  }
+  KIN_HIP(hipGetLastError());
+  return nblk & 1;
 }
 
 // x = S[0:m, 0:m] * y : one wavefront per row

@@ -50,5 +50,31 @@ int main(int argc, char** argv) {
   printf("checksum of the inverse %016llx\n", fnv);
   printf("m=%d  GJ mean %.1f us  best %.1f us  (%d launches)  max|A inv - I| (sampled) %.2e  bad=%d\n", m, sum / reps * 1e3, best * 1e3,
          m / 32 + 1, worst, hbad);
+  // ---- batched chains (round 4): n matrices per launch, checksum of every inverse against the single-matrix one
+  for (int n : {1, 2, 4, 8, 16}) {
+    std::vector<double*> Sb(n), S2b(n); std::vector<int*> badb(n);
+    double* pb; hipMalloc(&pb, sizeof(double) * 2048 * n);
+    for (int i = 0; i < n; i++) { hipMalloc(&Sb[i], sizeof(double) * m * m); hipMalloc(&S2b[i], sizeof(double) * m * m); badb[i] = bad; }
+    float bsum = 0.f, bbest = 1e9f; int where = 0;
+    for (int r = 0; r < 8; r++) {
+      for (int i = 0; i < n; i++) hipMemcpyAsync(Sb[i], S0, sizeof(double) * m * m, hipMemcpyDeviceToDevice, s);
+      hipEventRecord(e0, s);
+      where = kin::launch_gauss_jordan_batched(n, Sb.data(), S2b.data(), m, pb, badb.data(), s);
+      hipEventRecord(e1, s);
+      hipStreamSynchronize(s);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (r >= 3) { bsum += ms; bbest = ms < bbest ? ms : bbest; }
+    }
+    bool same = true;
+    for (int i = 0; i < n; i++) {
+      std::vector<double> Ib((size_t)m * m);
+      hipMemcpy(Ib.data(), where ? S2b[i] : Sb[i], sizeof(double) * m * m, hipMemcpyDeviceToHost);
+      same = same && memcmp(Ib.data(), Inv.data(), sizeof(double) * m * m) == 0;
+    }
+    printf("batched n=%2d: mean %.1f us  best %.1f us  = %.1f us per matrix, results %s\n", n, bsum / 5 * 1e3, bbest * 1e3, bbest * 1e3 / n,
+           same ? "bit-identical to the single chain" : "DIFFER");
+    for (int i = 0; i < n; i++) { hipFree(Sb[i]); hipFree(S2b[i]); }
+    hipFree(pb);
+  }
   return 0;
 }
