@@ -750,7 +750,7 @@ def main():
 
         def ensemble_launch():
             res = {}
-            for n, Ks in ((300, (16, 256)), (1000, (16, 256))):
+            for n, Ks in ((300, (16, 256, 1024)), (1000, (16, 256, 1024))):
                 netn, Ean, An = synthetic_crn(n, 5 * n)
                 hn = capi.HipNetwork.from_flat(netn)
                 try:
@@ -763,7 +763,8 @@ def main():
                         _, ue, nsv, rcs, sts = hn.solve_ensemble(kparams(2), U0[:K], T=Tm)
                         w = time.perf_counter() - t1
                         res[f"{n}_species_K{K}"] = {"wall_s": w, "solves_per_s": K / w, "members_ok": int((rcs == 0).sum()), "members": K,
-                                                    "steps_per_member": float(np.mean([q["n_steps"] for q in sts]))}
+                                                    "steps_per_member": float(np.mean([q["n_steps"] for q in sts])),
+                                                    "steps_of_the_slowest_member": int(max(q["n_steps"] for q in sts)), "lu_slots_per_member": int(sts[0]["lu_slots"])}
                 finally:
                     hn.close()
             # ... and the 10k-species network (beyond one compute unit's LDS): lockstep rounds of batched launches (ensemble.cpp)
@@ -776,10 +777,11 @@ def main():
             res[f"{N}_species_K16_lockstep"] = {"wall_s": w, "solves_per_s": 16 / w, "members_ok": int((rcs == 0).sum()), "members": 16,
                                                  "steps_per_member": float(np.mean([q["n_steps"] for q in sts])),
                                                  "factorisations_per_member": float(np.mean([q["n_factor"] for q in sts])),
-                                                 "form": "lockstep rounds of batched launches, one host thread per member's controller; device time is "
-                                                         "dominated by the members' dense Schur inverses (0.46 ms each, DESIGN 7)"}
+                                                 "form": "lockstep rounds of batched launches, one host thread per member's controller, dense Schur inverses of "
+                                                         "members that factorise together as one batched chain (DESIGN 3.5)"}
             return dict(res, workload="kin_solve_ensemble: K members of one network, first 2 default chunks each, host buffers in and out; "
-                                      "300 / 1000 species: ONE launch of kin::resident_bdf_kernel (one workgroup per member)")
+                                      "300 / 1000 species: ONE launch of kin::resident_bdf_kernel (one workgroup per member; the members' temperatures "
+                                      "span 900-1300 K, a launch takes as long as its slowest member once K <= the 256 compute units)")
         sn = out.setdefault("solve_network", {})
         guarded(sn, "crossover", crossover)
         guarded(sn, "ensemble_one_launch", ensemble_launch)

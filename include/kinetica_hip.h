@@ -211,17 +211,21 @@ typedef struct kin_stats {
 int kin_solve(kin_network* h, const kin_params* params, const double* u0,
               const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops,
               int64_t* n_saved, int32_t* retcode, kin_stats* stats);
-/* An ENSEMBLE of K independent trajectories of one network in ONE launch (the reference leaves ensembles to the user:
+/* An ENSEMBLE of K independent trajectories of one network in ONE call (the reference leaves ensembles to the user:
  * docs/src/tutorials/ode-solution.md:190 solves member after member through solve_network, exploration/methods.jl:221).
- * Every member is integrated by the same algorithm as kin_solve, resident on the GPU - one workgroup owns one
- * trajectory from u0 to the end of the span - so a member's result is bit-identical to a K = 1 call with its inputs.
+ * Every member is integrated by the same algorithm as kin_solve (csrc/resident_core.hpp is the controller of all paths):
+ *   - a network that fits one compute unit's LDS (up to ~1 000 species): ONE launch, one workgroup owns one member from u0 to
+ *     the end of the span; a member's result is bit-identical to a K = 1 call with its inputs;
+ *   - larger networks: the members advance in lockstep rounds, every launch of a round carries all members that need that
+ *     kind of work (csrc/ensemble.cpp); a member's result equals its solo kin_solve within the step-sequence tolerance
+ *     (bit-identical on the builds tested, not guaranteed).
  *   u0[K][N]; rate constants per member k[K][R], or temperatures T[K] (Arrhenius parameters of the handle), or neither
  *   (the handle's current rates for all); discrete rate updates (tstops / T_stops / k_table as in kin_solve) are shared
  *   by all members and exclude k / T. `params` needs a save grid (solve_chunks or save_interval).
  * Outputs (any may be NULL): *n_rows = rows of the save grid; out_t[n_rows]; out_u[K][n_rows][N]; n_saved[K] rows a member
  * actually wrote; retcodes[K] (KIN_RETCODE_*); stats[K]. A call with out_u == NULL and n_saved == NULL only reports *n_rows.
- * Returns KIN_OK when the call ran, whatever the members' retcodes; KIN_ERR_UNSUPPORTED for networks beyond the resident
- * integrator's size (dense Schur block > 1024): solve those member by member with kin_solve. */
+ * Returns KIN_OK when the call ran, whatever the members' retcodes; KIN_ERR_UNSUPPORTED for a network that fits neither
+ * path (too large for the resident kernel and without a dense Schur block): solve those member by member with kin_solve. */
 int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, const double* u0, const double* k, const double* T,
                        const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* n_rows,
                        double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats);

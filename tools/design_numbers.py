@@ -1,0 +1,206 @@
+"""Writes the "Numbers" block of DESIGN.md (between the numbers:begin / numbers:end markers) from the files under profiles/.
+Every row names the file (and key) it comes from; tests/test_docs_numbers.py runs this script in check mode and fails when the
+block in DESIGN.md differs from what the files give.
+Usage: python tools/design_numbers.py [--check] [--round r04]"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = "r04"
+if "--round" in sys.argv:
+    TAG = sys.argv[sys.argv.index("--round") + 1]
+P = os.path.join(ROOT, "profiles")
+
+
+def load(name):
+    return json.load(open(os.path.join(P, name)))
+
+
+def jsonl(name):
+    return [json.loads(l) for l in open(os.path.join(P, name)) if l.startswith("{")]
+
+
+def kernel_row(csv_name, needle):
+    rows = list(csv.DictReader(open(os.path.join(P, csv_name))))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    r = [r for r in rows if needle in r["Name"]][0]
+    return int(r["Calls"]), float(r["AverageNs"]) / 1e3, 100.0 * float(r["TotalDurationNs"]) / tot
+
+
+def build():
+    rows = []   # (group, what, value, source)
+
+    def add(group, what, value, source):
+        rows.append((group, what, value, source))
+
+    b = load(f"{TAG}_bench_default.json")
+    src_b = f"{TAG}_bench_default.json"
+    rf = b["roofline"]
+    add("headline sweep", "`sweep_reg_kernel`, B = 4096, 10k / 50k: launch (bench HIP events, after 1 s spin-up)",
+        f"{rf['avg_launch_ms']:.4f} ms = {rf['achieved']:.0f} GB/s = **{rf['frac']:.3f} of 8 TB/s**", f"{src_b} `roofline`")
+    add("headline sweep", "RHS evaluations per second (`value`)", f"{b['value'] / 1e6:.2f} M/s", f"{src_b} `value`")
+    add("headline sweep", "HBM traffic (PMC, same run) / algorithmic bytes", f"{rf['traffic_over_algorithmic']:.3f}", f"{src_b} `roofline.traffic_over_algorithmic`")
+    pm = load(f"{TAG}_sweep_pmc.json")
+    add("headline sweep", f"rocprofv3 average over {pm['calls']} launches (spin-up + timed + sustained)",
+        f"{pm['avg_ns_rocprof'] / 1e3:.1f} µs (bench events in that run {pm['avg_launch_ms_bench_events'] * 1e3:.1f} µs)", f"{TAG}_sweep_pmc.json")
+    tl = pm["timed_launches_only"]
+    add("headline sweep", f"cold clocks: rocprofv3 average over the {tl['calls']} warm-up + timed launches, no spin-up",
+        f"{tl['avg_ns_rocprof'] / 1e3:.1f} µs = {pm['algorithmic_bytes_per_launch'] / tl['avg_ns_rocprof'] / 8000:.3f}", f"{TAG}_sweep_pmc.json `timed_launches_only`")
+    add("headline sweep", "PMC: (2 × FETCH_SIZE + WRITE_SIZE) KiB / algorithmic", f"{pm['traffic_over_algorithmic']:.3f}", f"{TAG}_sweep_pmc.json")
+    add("headline sweep", "CPU port, oracle RHS, 1 core", f"{b['cpu_baseline']['value']:.0f} evals/s", f"{src_b} `cpu_baseline`")
+
+    ts = b["tiled_sweep"]
+    for cfg in ("C3", "C5"):
+        k, t = ts[cfg]["k_stream"], ts[cfg]["temperature_form"]
+        add("tiled sweep", f"{cfg} ({ts[cfg]['species']} / {ts[cfg]['reactions']}, B = {ts[cfg]['states']}), k-stream form",
+            f"{k['ms']:.3f} ms = {k['frac_of_8TBps']:.3f} of 8 TB/s", f"{src_b} `tiled_sweep.{cfg}.k_stream`")
+        add("tiled sweep", f"{cfg}, temperature form (no k)", f"{t['ms']:.3f} ms = {t['evals_per_s'] / 1e6:.2f} M evals/s", f"{src_b} `tiled_sweep.{cfg}.temperature_form`")
+    t5 = load("r03_c5_tiled_pmc.json")
+    if "traffic_over_algorithmic" in t5:
+        add("tiled sweep", "C5 k-stream, PMC traffic / algorithmic (kernel unchanged since round 3)", f"{t5['traffic_over_algorithmic']:.3f}", "r03_c5_tiled_pmc.json")
+
+    ct = load(f"{TAG}_c5_table_pmc.json")
+    for kr in ct["kernels"]:
+        name = kr["kernel"].split("::")[-1]
+        add("rate table" if "rate_table" in name else "caller's-layout sweep at C5", f"`{name}`: rocprofv3 average over {kr['calls']} launches",
+            f"{kr['avg_ns_rocprof'] / 1e6:.3f} ms = {kr['achieved_GBps']:.0f} GB/s = {kr['frac_of_8TBps']:.3f}, traffic {kr['traffic_over_algorithmic']:.2f}× algorithmic",
+            f"{TAG}_c5_table_pmc.json")
+
+    sn = b["solve_network"]
+    add("C3 solve", "100 chunks (0, 0.1) s: warm / cold (handle creation + analysis + first solve)",
+        f"{sn['gpu_wall_s']:.3f} s / {sn['cold_wall_s']:.3f} s ({sn['cold_wall_s'] / sn['gpu_wall_s']:.2f}×)", f"{src_b} `solve_network`")
+    st = sn["stats"]
+    add("C3 solve", "... steps / factorisations / cache hits / dense block", f"{st['n_steps']} / {st['n_factor']} / {st['n_lu_reused']} / {st['lu_dense_dim']}", f"{src_b} `solve_network.stats`")
+    add("C3 solve", f"first {sn['same_chunks']} chunks: GPU / CPU port on 1 core", f"{sn['gpu_wall_same_chunks_s']:.3f} s / {sn['cpu_wall_same_chunks_s']:.2f} s = {sn['speedup_same_chunks_1core']:.1f}×",
+        f"{src_b} `solve_network.speedup_same_chunks_1core`")
+    ca = sn["cpu_all_cores"]
+    add("C3 solve", f"one GPU against {ca['cores']} host cores (one replica each): single solve / best K threads", f"{ca['gpu_over_all_cores']:.2f}× / {ca['gpu_over_all_cores_best_K']:.1f}×", f"{src_b} `solve_network.cpu_all_cores`")
+    add("C3 solve", "device vs CPU port on those chunks, tolerance units max / rms", f"{sn['max_dev_vs_cpu_in_tol_units']:.1f} / {sn['rms_dev_vs_cpu_in_tol_units']:.2f}", src_b)
+
+    cf = sn["configs"]
+    c3 = cf["C3_whole_span"]
+    cw, cc = c3["chunkwise_1000_chunks"], c3["complete_timespan"]
+    add("configurations", "C3 over (0, 1) s chunkwise (1 000 chunks): wall, steps, factorisations", f"{cw['wall_s']:.2f} s, {cw['stats']['n_steps']}, {cw['stats']['n_factor']}", f"{src_b} `configs.C3_whole_span`")
+    add("configurations", "C3 over (0, 1) s as ONE integration: wall, steps, corrector failures, factorisations",
+        f"{cc['wall_s']:.3f} s, {cc['stats']['n_steps']}, {cc['stats']['n_newton_fail']}, {cc['stats']['n_factor']}", f"{src_b} `configs.C3_whole_span`")
+    fa = c3["final_states_apart_in_tolerance_units"]
+    add("configurations", "... final states of the two apart, tolerance units max / rms", f"{fa['max']:.0f} / {fa['rms']:.1f}", src_b)
+    c4 = cf["C4_prefix"]
+    v = c4["vs_truth_in_tolerance_units"]
+    add("C4 prefix", "first 20 chunks (200 restarts): wall, steps, factorisations", f"{c4['wall_s']:.2f} s, {c4['stats']['n_steps']}, {c4['stats']['n_factor']}", f"{src_b} `configs.C4_prefix`")
+    add("C4 prefix", "... against `truth_c4_long.npz`: max / rms / p99.9 units (truth self-check)", f"{v['max']:.0f} / {v['rms']:.1f} / {v['p99.9']:.1f} ({v['truth_self_check']:.1f})", src_b)
+    c5 = cf["C5_static"]
+    add("configurations", "C5 static, 5 chunks: warm / cold, dense block", f"{c5['wall_s']:.2f} s / {c5['cold_wall_s_incl_create_and_analysis']:.2f} s, {c5['dense_block']}", f"{src_b} `configs.C5_static`")
+
+    for r in sn["crossover"]["rows"]:
+        cpu = r.get("cpu_port_1core_s")
+        extra = f", host-driven {r['gpu_warm_host_driven_s']:.3f} s" if "gpu_warm_host_driven_s" in r else ""
+        cpus = f"{cpu:.3f} s" + (f" for {r['cpu_chunks']} chunks" if r.get("cpu_chunks", 20) != 20 else "") if cpu is not None else "-"
+        add("crossover", f"{r['species']} species, 20 chunks: GPU warm / cold{', host-driven' if extra else ''}; CPU port 1 core",
+            f"{r['gpu_warm_s']:.3f} s / {r['gpu_cold_s']:.3f} s{extra}; {cpus} (default integrator: {r['integrator'].split(' (')[0]})", f"{src_b} `crossover.rows`")
+
+    en = sn["ensemble_one_launch"]
+    for key, e in en.items():
+        if not isinstance(e, dict) or "solves_per_s" not in e:
+            continue
+        group = "ensemble, lockstep" if "lockstep" in key else "ensemble, one launch"
+        add(group, key.replace("_", " "), f"{e['solves_per_s']:.0f} solves/s ({e['wall_s']:.3f} s, {e['members_ok']} of {e['members']} ok" + (f", steps mean {e['steps_per_member']:.0f} / slowest {e['steps_of_the_slowest_member']}" if 'steps_of_the_slowest_member' in e else "") + ")", f"{src_b} `ensemble_one_launch.{key}`")
+    for k_, e in sorted(sn["concurrent_replicas"].items()):
+        if isinstance(e, dict) and "solves_per_s" in e:
+            add("ensemble, lockstep", f"for comparison, round 3's K handles on K host threads, K = {k_} (2 chunks of C3)", f"{e['solves_per_s']:.1f} solves/s", f"{src_b} `concurrent_replicas`")
+
+    path = os.path.join(P, f"{TAG}_ensemble_resident_scaling.jsonl")
+    if os.path.exists(path):
+        for r in jsonl(f"{TAG}_ensemble_resident_scaling.jsonl"):
+            if r["species"] == 1000 or r["K"] == 1024:
+                add("ensemble, one launch", f"scaling probe: {r['species']} species, K = {r['K']}, members at {r['T']}",
+                    f"{r['solves_per_s']:.0f} solves/s (steps mean {r['steps_mean']:.0f} / slowest {r['steps_max']}, {r['slots']} cache slots per member)",
+                    f"{TAG}_ensemble_resident_scaling.jsonl")
+    path = os.path.join(P, f"{TAG}_resident_vs_host.jsonl")
+    if os.path.exists(path):
+        for r in jsonl(f"{TAG}_resident_vs_host.jsonl"):
+            add("resident vs host-driven", f"{r['species']} species (dense block {r['dense_block']}), 20 chunks: resident / host-driven",
+                f"{r['resident_s']:.3f} s / {r['host_driven_s']:.3f} s = {r['host_over_resident']:.2f}×", f"{TAG}_resident_vs_host.jsonl")
+
+    calls, avg, pct = kernel_row(f"{TAG}_solve_kernel_stats.csv", "gj_update_kernel")
+    add("solve kernel time", "C3 20 chunks: `gj_update_kernel` share of kernel time, average launch", f"{pct:.1f} %, {avg:.2f} µs × {calls}", f"{TAG}_solve_kernel_stats.csv")
+    for needle, label in (("bdf_newton_kernel", "corrector update + decision"), ("segsum_kernel<4, 1024>", "solve stage A gather"), ("segsum_kernel<2, 1024>", "Newton residual gather"),
+                          ("segsum_kernel<5, 256>", "solve stage C gather"), ("gemv_kernel", "dense GEMV"), ("rates_skip_kernel", "rates")):
+        try:
+            calls, avg, pct = kernel_row(f"{TAG}_solve_kernel_stats.csv", needle)
+            add("solve kernel time", f"... {label} (`{needle}`)", f"{pct:.1f} %, {avg:.2f} µs", f"{TAG}_solve_kernel_stats.csv")
+        except IndexError:
+            pass
+    gj = open(os.path.join(P, f"{TAG}_gj_probe_batched.txt")).read()
+    m = re.search(r"m=(\d+)\s+GJ mean ([\d.]+) us\s+best ([\d.]+) us\s+\((\d+) launches\)", gj)
+    add("Gauss-Jordan", f"dense inverse alone, m = {m.group(1)} ({m.group(4)} launches), HIP events", f"{m.group(2)} µs mean, {m.group(3)} µs best", f"{TAG}_gj_probe_batched.txt")
+    for mm in re.finditer(r"batched n=\s*(\d+): mean ([\d.]+) us\s+best ([\d.]+) us\s+= ([\d.]+) us per matrix, results (.*)", gj):
+        if mm.group(1) in ("4", "8", "16"):
+            add("Gauss-Jordan", f"batched chain, {mm.group(1)} matrices per launch", f"{mm.group(4)} µs per matrix ({mm.group(5).strip()})", f"{TAG}_gj_probe_batched.txt")
+    db = load(f"{TAG}_dense_block_options.json")["rows"]
+    ms = [r["dense_block"] for r in db if "dense_block" in r]
+    add("Gauss-Jordan", f"dense block at C3 over {len(ms)} elimination option sets (configured: {db[0]['dense_block']})", f"{min(ms)} ... {max(ms)}", f"{TAG}_dense_block_options.json")
+
+    ph = open(os.path.join(P, f"{TAG}_resident_phase_300.txt")).read()
+    head = re.search(r"N=(\d+) m=(\d+) slots=\d+ steps=(\d+) factor=(\d+) linsolve=(\d+) wall ([\d.]+) s", ph)
+
+    def phase(label):
+        return float(re.search(re.escape(label) + r"\s+([\d.]+) ms", ph).group(1))
+    add("resident phases", f"{head.group(1)} species, 20 chunks: {head.group(3)} steps, {head.group(4)} factorisations, {head.group(5)} solves",
+        f"kernel {phase('kernel'):.1f} ms = {1e3 * phase('kernel') / int(head.group(3)):.0f} µs per step", f"{TAG}_resident_phase_300.txt")
+    add("resident phases", "... factorisations (of which dense inverse) / corrector attempts (of which solves)",
+        f"{phase('factor'):.1f} ({phase('(of which dense inverse)'):.1f}) / {phase('corrector attempts'):.1f} ({phase('(solve)'):.1f}) ms", f"{TAG}_resident_phase_300.txt")
+    wl = open(os.path.join(P, f"{TAG}_wg_latency_probe.txt")).read().split("grid = 256")[0]
+    pick = {}
+    for l in wl.splitlines():
+        mm = re.match(r"\s+(.*?)\s{2,}([\d.]+) ns", l)
+        if mm:
+            pick[mm.group(1)] = float(mm.group(2))
+    add("resident phases", "in-workgroup latencies: barrier / dependent global load / LDS read / 5 wave sums DPP (bpermute) / hand-over LDS (global)",
+        f"{pick['barrier']:.0f} / {pick['dependent global load (idx chase)']:.0f} / {pick['dependent LDS read']:.0f} / {pick['5 wave sums (DPP)']:.0f} ({pick['5 wave sums (ds_bpermute)']:.0f}) / "
+        f"{pick['stage hand-over through LDS']:.0f} ({pick['stage hand-over through global memory (store, barrier, load, barrier)']:.0f}) ns", f"{TAG}_wg_latency_probe.txt")
+
+    cfab = open(os.path.join(P, f"{TAG}_cf_rules_ab.txt")).read()
+    for tag, label in (("KIN_ETACF=0.5 KIN_CF_RESET=1 KIN_CF_GROWTH_CAP=0", "round 3's rules"), ("KIN_ETACF=0.25 KIN_CF_RESET=0 KIN_CF_GROWTH_CAP=0", "adopted (ETACF 0.25, no reset on corrector failures)")):
+        blk = cfab.split("=== " + tag)[-1].split("===")[0]          # the last run with these settings
+        mm = re.search(r"wall ([\d.]+) rc 0 \{'n_steps': (\d+), 'n_rejected': (\d+), 'n_factor': (\d+), 'n_newton_fail': (\d+)\}", blk)
+        sw = re.findall(r"sweep (wide2?): (\d+) solves, failures (\d+) retries (\d+)", blk)
+        sws = "; sweeps " + ", ".join(f"{a}: {c} failures / {d} retries of {b_}" for a, b_, c, d in sw) if sw else ""
+        add("convergence-failure rules", f"C3 over (0, 1) s as one integration, {label}", f"{mm.group(1)} s, {mm.group(2)} steps, {mm.group(5)} corrector failures, {mm.group(4)} factorisations{sws}", f"{TAG}_cf_rules_ab.txt")
+
+    rd = jsonl(f"{TAG}_ramp_diag.jsonl")
+    lo, hi = min(r["max_units"] for r in rd), max(r["max_units"] for r in rd)
+    add("C4 prefix", f"3-chunk prefix under {len(rd)} solver-switch variants (tools/ramp_diag.py): max units", f"{lo:.0f} ... {hi:.0f} (default {rd[0]['max_units']:.0f}, p99.9 {rd[0]['p999']:.1f})", f"{TAG}_ramp_diag.jsonl")
+
+    rk = b.get("ranks", {})
+    add("multi-GPU", "ranks that took part in the committed bench line", f"world size {rk.get('world_size')}, backend {rk.get('backend')}; no scaling curve measured", f"{src_b} `ranks`")
+
+    out = ["| | what | value | source (`profiles/`) |", "|---|---|---|---|"]
+    last = None
+    for g, w, v_, s in rows:
+        out.append(f"| {g if g != last else ''} | {w} | {v_} | {s} |")
+        last = g
+    return "\n".join(out)
+
+
+def main():
+    block = build()
+    path = os.path.join(ROOT, "DESIGN.md")
+    text = open(path).read()
+    a, b = text.index("<!-- numbers:begin -->") + len("<!-- numbers:begin -->"), text.index("<!-- numbers:end -->")
+    new = text[:a] + "\n" + block + "\n" + text[b:]
+    if "--check" in sys.argv:
+        if new != text:
+            print("DESIGN.md's numbers block is out of date: run python tools/design_numbers.py")
+            sys.exit(1)
+        print("DESIGN.md numbers block matches profiles/")
+        return
+    open(path, "w").write(new)
+    print(block)
+
+
+if __name__ == "__main__":
+    main()
