@@ -9,7 +9,8 @@ state, reference src/solving/methods.jl:819), so time chunks do not shard (SURVE
       caller wants the whole sol_k;
   (2) independent replicas / ensemble members (`solve_ensemble`): one kin_solve per rank, no data-path collective; the
       per-species maxima identify_next_seeds reads (explore_utils.jl:344-351) are all-gathered from device buffers
-      (`gather_solution_max`);
+      (`gather_solution_max`); ensembles of ONE network shard by members (`solve_ensemble_sharded`): one
+      kin_solve_ensemble call per rank, then one row per member all-gathered;
   (3) the reactions of ONE trajectory's right-hand side (`rhs_reaction_blocks`): rank g evaluates its block of reactions
       and an all-reduce of N doubles sums the partial du. Latency bound at these sizes (80 kB at 10k species) - built so
       that the cost can be measured (`time_rhs_reaction_blocks`, reported by bench.py at N > 1), not as the recommended path.
@@ -135,6 +136,34 @@ def solve_ensemble(members, solve_one, dist=None):
         for j, i in enumerate(range(r, len(members), world)):
             out[i] = allrows[offs[r] + j]
     return out
+
+
+def solve_ensemble_sharded(h, pars, u0s, T=None, k=None, dist=None, device=None, reduce="max", solve_fn=None):
+    """(2b) An ensemble of K trajectories of ONE network over the ranks: rank r takes the contiguous block
+    shard_range(K, r, world) of members and integrates it with ONE kin_solve_ensemble call on its GPU (resident kernel or
+    lockstep rounds, csrc/resident.hip / ensemble.cpp) - no data-path collective. What travels afterwards is one row per
+    member, all-gathered in member order: reduce="max" -> max_t u_i(t) (what identify_next_seeds reads,
+    explore_utils.jl:344-351), "final" -> the last saved state. Returns (rows [K][N], retcodes [K]) on every rank.
+    `solve_fn(h, pars, u0s, T, k)` replaces h.solve_ensemble in tests without a device."""
+    import torch
+    rank, world = rank_world(dist) if _active(dist) else (0, 1)
+    u0s = np.ascontiguousarray(u0s, dtype=np.float64)
+    K, N = u0s.shape
+    lo, hi = shard_range(K, rank, world)
+    if hi > lo:
+        fn = solve_fn or (lambda h_, p_, u_, T_, k_: h_.solve_ensemble(p_, u_, T=T_, k=k_))
+        t, u, ns, rcs, _ = fn(h, pars, u0s[lo:hi], None if T is None else np.asarray(T, dtype=np.float64)[lo:hi],
+                              None if k is None else np.ascontiguousarray(k, dtype=np.float64)[lo:hi])
+        rows = np.stack([(u[i, :max(int(ns[i]), 1)].max(axis=0) if reduce == "max" else u[i, max(int(ns[i]), 1) - 1]) for i in range(hi - lo)])
+        rcs = np.asarray(rcs, dtype=np.float64)
+    else:
+        rows, rcs = np.zeros((0, N)), np.zeros(0)
+    if not _active(dist):
+        return rows, rcs.astype(np.int32)
+    dev = (device or torch.device("cuda", torch.cuda.current_device())) if _on_device(dist) else torch.device("cpu")
+    both = torch.tensor(np.concatenate([rows, rcs[:, None]], axis=1), dtype=torch.float64, device=dev)
+    full = all_gather_rows(both, dist).cpu().numpy()          # contiguous blocks in rank order = member order
+    return full[:, :N], full[:, N].astype(np.int32)
 
 
 def _nonnull_stream():

@@ -43,7 +43,17 @@ def _worker(rank, world, port, q):
         table = D.all_gather_rows(mine, dist).numpy()
         # (3) ensemble of 5 independent "solves", round-robin over ranks, results as float64 vectors
         res = D.solve_ensemble(list(range(5)), lambda m: np.array([m, dist.get_rank(), m * 10.0]), dist)
-        q.put((rank, t, table, np.array(res), status))
+        # (4) an ensemble of ONE network sharded by members (7 members over 2 ranks: 4 + 3): every rank runs ONE ensemble call on
+        # its block (here a stand-in with the C ABI's return shape: the product call needs a device), rows come back in member order
+        def fake_ensemble(h, pars, u0s, Tm, km):
+            Kb, Nn = u0s.shape
+            u = np.stack([np.stack([u0s[i] * (1.0 + j) + Tm[i] for j in range(3)]) for i in range(Kb)])      # [Kb][3 rows][N]
+            return np.arange(3.0), u, np.full(Kb, 3), (Tm > 1250.0).astype(np.int32), None
+        u0s = np.arange(7.0)[:, None] + np.zeros((7, 4))
+        Tm = 1000.0 + 50.0 * np.arange(7)
+        rows_max, rcs = D.solve_ensemble_sharded(None, None, u0s, T=Tm, dist=dist, solve_fn=fake_ensemble)
+        rows_fin, _ = D.solve_ensemble_sharded(None, None, u0s, T=Tm, dist=dist, reduce="final", solve_fn=fake_ensemble)
+        q.put((rank, t, table, np.array(res), status, rows_max, rows_fin, rcs))
     finally:
         dist.destroy_process_group()
 
@@ -61,7 +71,12 @@ def test_world_size_2_gloo():
         assert p.exitcode == 0
     T = np.linspace(500.0, 1200.0, 11)
     from kinetica_jl_amd import capi
-    for rank, t, table, res, status in out:
+    for rank, t, table, res, status, rows_max, rows_fin, rcs in out:
+        u0s = np.arange(7.0)[:, None] + np.zeros((7, 4))
+        Tm = 1000.0 + 50.0 * np.arange(7)
+        np.testing.assert_array_equal(rows_max, u0s * 3.0 + Tm[:, None])          # the largest of the three rows, member order
+        np.testing.assert_array_equal(rows_fin, u0s * 3.0 + Tm[:, None])
+        np.testing.assert_array_equal(rcs, [0, 0, 0, 0, 0, 0, 1])
         assert t == 2.0                                               # max(1.0, 2.0)
         np.testing.assert_allclose(table, np.outer(T, [1.0, 2.0, 3.0]))
         np.testing.assert_array_equal(res[:, 0], [0, 1, 2, 3, 4])

@@ -44,6 +44,10 @@ def _worker(rank, world, port, q):
         umax = D.gather_solution_max(h, dist, dev)
         ens = D.solve_ensemble([1000.0, 1050.0, 1100.0],
                                lambda Tm: (h.rates_at(Tm), h.solve(p, u0), h.solution_max())[2], dist)
+        # (2b) an ensemble of the ONE network sharded by members: 5 members -> blocks of 3 and 2, one kin_solve_ensemble call per rank
+        Tm = 1000.0 + 50.0 * np.arange(5)
+        U0 = np.tile(u0, (5, 1))
+        ens_rows, ens_rcs = D.solve_ensemble_sharded(h, p, U0, T=Tm, dist=dist, device=dev)
         # (3) one right-hand side, reactions split over the ranks, partial du summed
         k = h.rates_at(1000.0)
         uu = 10.0 ** np.random.default_rng(0).uniform(-12, 0, 300)
@@ -52,7 +56,7 @@ def _worker(rank, world, port, q):
         D.rhs_reaction_blocks(h, d_u, d_du, dist)
         torch.cuda.synchronize()
         timing = D.time_rhs_reaction_blocks(h, d_u, dist, reps=20)
-        q.put((rank, table, (lo, hi, tuple(mine.shape)), rc, u.max(axis=0), umax, np.array(ens), d_du.cpu().numpy(), k, uu, timing))
+        q.put((rank, table, (lo, hi, tuple(mine.shape)), rc, u.max(axis=0), umax, np.array(ens), d_du.cpu().numpy(), k, uu, timing, ens_rows, ens_rcs))
         h.close()
     finally:
         dist.destroy_process_group()
@@ -76,8 +80,12 @@ def test_two_ranks_on_one_card():
     T = np.linspace(500.0, 1200.0, 11)
     ref_table = orc.rate_table(Ea, A, T, k_max=1e12)
     own_max = [o[4] for o in out]
-    for rank, table, (lo, hi, shp), rc, umax_own, umax_all, ens, du, k, uu, timing in out:
+    for rank, table, (lo, hi, shp), rc, umax_own, umax_all, ens, du, k, uu, timing, ens_rows, ens_rcs in out:
         assert rc == 0
+        assert ens_rows.shape == (5, 300) and (ens_rcs == 0).all()
+        np.testing.assert_array_equal(ens_rows, out[0][11])          # the same table on every rank
+        np.testing.assert_array_equal(ens_rows[0], own_max[0])       # member 0 (1000 K) = rank 0's solo replica, bit for bit
+        np.testing.assert_array_equal(ens_rows[1], own_max[1])       # member 1 (1050 K) = rank 1's
         assert (lo, hi) == ((0, 6), (6, 11))[rank] and shp == (hi - lo, 1500)
         np.testing.assert_allclose(table, ref_table, rtol=1e-11)
         assert umax_all.shape == (2, 300)

@@ -215,6 +215,11 @@ def test_lockstep_ensemble_of_a_large_network(monkeypatch):
         assert rc == 0 and np.array_equal(ts, t)
         assert units(u[i], us) < 50                                              # measured 0 - 8
         assert abs(sts[i]["n_steps"] - st["n_steps"]) <= 0.02 * st["n_steps"] + 2
+    # the members' dense inverses as one batched Gauss-Jordan chain (default) and as chains of their own: the same arithmetic
+    monkeypatch.setenv("KIN_ENSEMBLE_GJ_BATCHED", "0")
+    t1, u1, _, rcs1, sts1 = h.solve_ensemble(kp(2e-3), np.tile(u0, (3, 1)), T=T)
+    monkeypatch.delenv("KIN_ENSEMBLE_GJ_BATCHED")
+    assert (rcs1 == 0).all() and np.array_equal(u1, u) and [q["n_steps"] for q in sts1] == [q["n_steps"] for q in sts]
     # shared discrete rate updates through the lockstep path
     tst = np.arange(4) * 0.5e-3
     Ts = np.array([900.0, 1000.0, 1100.0, 1200.0])
