@@ -648,6 +648,25 @@ def main():
             res["final_states_apart_in_tolerance_units"] = {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean()))}
             return res
 
+        def c3_30_chunks():
+            # chunkwise and as one integration against the committed tight-tolerance truth (tests/golden/truth_c3_mid.npz)
+            tp = os.path.join(ROOT, "tests", "golden", "truth_c3_mid.npz")
+            if not os.path.exists(tp):
+                return {"error": "tests/golden/truth_c3_mid.npz is missing"}
+            z = np.load(tp)
+            h.rates_at(1000.0)
+            res = {"truth": "tests/golden/truth_c3_mid.npz (CPU port at 1000x tighter tolerances, every 5th chunk end)", "truth_self_check": float(z["self_check"])}
+            for name, pr in (("chunkwise", kpc(0.03, 1e-3)), ("complete_timespan", kpc(0.03, 1e-3, save=5e-3, chunks=0, dtmin=RAMP_DTMIN))):
+                t1 = time.perf_counter()
+                tt, uu, rcq, stq, _ = h.solve(pr, u0)
+                w = time.perf_counter() - t1
+                sel = [int(np.argmin(np.abs(tt - x))) for x in z["t"]]
+                e = np.abs(uu[sel] - z["u"]) / (1e-10 + 1e-8 * np.abs(z["u"]))
+                res[name] = {"wall_s": w, "retcode": rcq, "stats": brief(stq),
+                             "vs_truth_in_tolerance_units": {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean(axis=1)).max()),
+                                                             "max_per_saved_time": [round(float(x), 1) for x in e.max(axis=1)]}}
+            return res
+
         def c4_prefix():
             tst = np.arange(201) * 1e-3
             Tst = 500.0 + 50.0 * tst
@@ -689,6 +708,7 @@ def main():
 
         cfg = {}
         guarded(cfg, "C3_whole_span", c3_full)
+        guarded(cfg, "C3_30_chunks_vs_truth", c3_30_chunks)
         guarded(cfg, "C4_prefix", c4_prefix)
         guarded(cfg, "C5_static", c5_solve)
         out.setdefault("solve_network", {})["configs"] = cfg

@@ -13,6 +13,11 @@ abstol 1e-10, reltol 1e-8 (params.jl:61-62):
     470 / 4.8 for the CPU baseline, 680 / 7.0 for the CPU baseline without the LU cache; keeping the difference history
     across rate updates - KIN_WARM_RESTART=1 - does not tighten it: 705 / 11.0 and 565 / 5.7), and the error is
     tolerance proportional: the same solve with 10x tighter tolerances must come within max e <= 100 (in DEFAULT units).
+Round 4 - longer truths (tests/golden/make_truth_configs.py c3_mid / c4_long):
+  * C3 over (0, 0.03) s, 30 chunks (truth_c3_mid.npz): chunkwise max e <= 250, rms <= 11 (measured 170 / 7.6, growing with
+    every restart); as one integration max e <= 60, rms <= 5.5 (measured 40 / 3.4);
+  * C4 ramp, first 20 chunks = 200 restarts (truth_c4_long.npz): max e <= 620, rms <= 6.4, p99.9 <= 20 (measured 515 / 5.3 /
+    15.6); the maximum sits on two major species (7705, 7150) at every save point - DESIGN.md section 5 has the diagnosis.
 """
 import os
 
@@ -29,9 +34,9 @@ pytestmark = pytest.mark.gpu
 RAMP_DTMIN = 1e-30     # see test_c4_reference_dtmin_ends_in_dtlessthanmin
 
 
-def kp(t1, chunk, save=None, abstol=1e-10, reltol=1e-8, dtmin=0.0, adaptive=True):
+def kp(t1, chunk, save=None, abstol=1e-10, reltol=1e-8, dtmin=0.0, adaptive=True, chunks=True):
     return capi.KinParams(tspan0=0.0, tspan1=t1, abstol=abstol, reltol=reltol, adaptive_tols=int(adaptive), update_tols=0,
-                          solve_chunks=1, ban_negatives=0, solve_chunkstep=chunk, maxiters=100000,
+                          solve_chunks=int(chunks), ban_negatives=0, solve_chunkstep=chunk, maxiters=100000,
                           save_interval=-1.0 if save is None else save, dtmin=dtmin)
 
 
@@ -252,6 +257,37 @@ def test_c4_twenty_chunks_against_truth(golden_dir):
     assert np.percentile(e, 99.9) <= 20                                                  # measured 15.6
     # the two worst species of the 3-chunk prefix carry the maximum here as well
     assert set(np.argsort(e.max(axis=0))[-2:]) <= {7705, 7150, *np.argsort(e.max(axis=0))[-6:]}
+    h.close()
+
+
+def test_c3_thirty_chunks_chunkwise_and_complete_against_truth(golden_dir, c3):
+    """C3 over (0, 0.03) s against `truth_c3_mid.npz` (the CPU port at 1000x tighter tolerances, 39 minutes; every 5th chunk
+    end is stored): chunkwise (30 restarts) and as ONE integration with a 5 ms save grid - the two ways the reference solves a
+    StaticODESolve (methods.jl:132-183, 717-865). Measured (tools/c3_mid_units.py): chunkwise 170 units max / rms 7.6, growing
+    from chunk to chunk (37 at 5 ms, 170 at 30 ms: every restart at order 1 adds its local error); complete 40 / 3.4. Where
+    the two disagree (bench.py: 780 units apart at 1 s) it is the chunkwise run that has drifted."""
+    net, Ea, A, k = c3
+    z = np.load(os.path.join(golden_dir, "truth_c3_mid.npz"))
+    assert float(z["self_check"]) < 15.0                       # x1e-2 against x1e-3 tolerances, in default units
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates(k)
+    u0 = np.zeros(net.n_species); u0[0] = 1.0
+    t, u, rc, st, status = h.solve(kp(0.03, 1e-3), u0)
+    assert status == capi.KIN_OK and rc == 0 and st["n_chunks"] == 30 and st["n_retries"] == 0
+    sel = [int(np.argmin(np.abs(t - tt))) for tt in z["t"]]
+    np.testing.assert_allclose(t[sel], z["t"], rtol=0, atol=1e-16)
+    e = units(u[sel], z["u"])
+    assert e.max() <= 250 and float(np.sqrt((e ** 2).mean(axis=1)).max()) <= 11
+    assert e[1].max() <= 80                                     # the first 5 chunks: measured 37
+    tc, uc, rcc, stc, status = h.solve(kp(0.03, 1e-3, save=5e-3, chunks=False, dtmin=1e-30), u0)
+    assert status == capi.KIN_OK and rcc == 0 and stc["n_restarts"] == 1 and len(tc) == 7
+    np.testing.assert_allclose(tc, z["t"], rtol=0, atol=1e-16)
+    ec = units(uc, z["u"])
+    assert ec.max() <= 60 and float(np.sqrt((ec ** 2).mean(axis=1)).max()) <= 5.5
+    # tolerance proportional: 10x tighter tolerances, chunkwise, in DEFAULT units (measured 30 / 3.2)
+    t2, u2, rc2, _, _ = h.solve(kp(0.03, 1e-3, abstol=1e-11, reltol=1e-9, dtmin=1e-30), u0)
+    e2 = units(u2[sel], z["u"])
+    assert rc2 == 0 and e2.max() <= 60 and float(np.sqrt((e2 ** 2).mean(axis=1)).max()) <= 5
     h.close()
 
 

@@ -88,6 +88,12 @@ def build():
         f"{cc['wall_s']:.3f} s, {cc['stats']['n_steps']}, {cc['stats']['n_newton_fail']}, {cc['stats']['n_factor']}", f"{src_b} `configs.C3_whole_span`")
     fa = c3["final_states_apart_in_tolerance_units"]
     add("configurations", "... final states of the two apart, tolerance units max / rms", f"{fa['max']:.0f} / {fa['rms']:.1f}", src_b)
+    c30 = cf.get("C3_30_chunks_vs_truth")
+    if c30 and "chunkwise" in c30:
+        for name in ("chunkwise", "complete_timespan"):
+            v30 = c30[name]["vs_truth_in_tolerance_units"]
+            add("configurations", f"C3 over (0, 0.03) s {name.replace('_', ' ')} against `truth_c3_mid.npz`: wall, steps; max / rms units",
+                f"{c30[name]['wall_s']:.3f} s, {c30[name]['stats']['n_steps']}; {v30['max']:.0f} / {v30['rms']:.1f}", f"{src_b} `configs.C3_30_chunks_vs_truth`")
     c4 = cf["C4_prefix"]
     v = c4["vs_truth_in_tolerance_units"]
     add("C4 prefix", "first 20 chunks (200 restarts): wall, steps, factorisations", f"{c4['wall_s']:.2f} s, {c4['stats']['n_steps']}, {c4['stats']['n_factor']}", f"{src_b} `configs.C4_prefix`")
