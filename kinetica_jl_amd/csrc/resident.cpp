@@ -168,7 +168,13 @@ void run_resident(kin_network* h, ResidentSolver& RS, const kin_params& p, const
   RS.d_net.upload(&RS.hn, 1, s);
   RS.d_par.upload(&P, 1, s);
   RS.d_traj.upload(RS.h_traj.data(), (size_t)K, s);
-  launch_resident(K, RS.dyn_lds, RS.d_net.p, RS.d_traj.p, RS.d_par.p, s);
+  // more members than compute units, and two workgroups fit one compute unit's LDS: the build with half the registers per lane
+  // (two co-resident workgroups hide each other's latencies: +20-40 % solves/s at 300 species; a member alone is 10-15 % slower)
+  static const size_t static_lds = resident_static_lds();
+  bool shared_cu = K > h->n_cu && 2 * (RS.dyn_lds + static_lds) <= (size_t)160 * 1024;
+  if (const char* e = getenv("KIN_RESIDENT_SHARED_CU")) shared_cu = atoi(e) != 0 && 2 * (RS.dyn_lds + static_lds) <= (size_t)160 * 1024;
+  if (shared_cu) launch_resident_shared_cu(K, RS.dyn_lds, RS.d_net.p, RS.d_traj.p, RS.d_par.p, s);
+  else launch_resident(K, RS.dyn_lds, RS.d_net.p, RS.d_traj.p, RS.d_par.p, s);
   res.resize(K);
   RS.d_res.download(res.data(), (size_t)K, s);
   KIN_HIP(hipStreamSynchronize(s));

@@ -917,7 +917,16 @@ __device__ __forceinline__ void count_splits(int id) {
 
 __shared__ __attribute__((aligned(16))) unsigned char g_ctl_mem[sizeof(ResidentBdf<DevBackend>)];
 
-__global__ __launch_bounds__(RES_WG) void resident_bdf_kernel(const ResNetDev* __restrict__ net_p, const ResTrajDev* __restrict__ traj,
+// Two builds of this file (Makefile: resident.hip as it is, resident_w4.hip = this file with RES_WAVES_PER_EU 4): the register
+// budget of the kernel AND of every phase it calls follows from the kernel's waves-per-SIMD attribute.
+//   2: 256 VGPRs per lane, one workgroup per compute unit - the fastest single trajectory;
+//   4: 128 VGPRs (a few spills in the corrector, the factorisation and the order change), TWO workgroups share a compute
+//      unit and hide each other's latencies: an ensemble of more members than compute units gets 20-40 % more solves/s at
+//      300 species (4 000-4 600 against 3 300-3 600), a single member is 10-15 % slower (resident.cpp picks per launch).
+#ifndef RES_WAVES_PER_EU
+#define RES_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(RES_WG) __attribute__((amdgpu_waves_per_eu(RES_WAVES_PER_EU, RES_WAVES_PER_EU))) void resident_bdf_kernel(const ResNetDev* __restrict__ net_p, const ResTrajDev* __restrict__ traj,
                                                                const ResParams* __restrict__ par_p) {
   if (threadIdx.x == 0) {
     const ResNetDev& n = *net_p;
@@ -960,12 +969,22 @@ __global__ __launch_bounds__(RES_WG) void resident_bdf_kernel(const ResNetDev* _
 
 }  // namespace
 
+#if RES_WAVES_PER_EU == 2
 size_t resident_dyn_lds(int N, int R, int m, int64_t window) {
   const int m16 = (m + 15) / 16 * 16;
   return ((size_t)4 * N + (size_t)window + (size_t)std::max(R, 16 * (m16 + 1))) * sizeof(double);
 }
+size_t resident_static_lds() {
+  hipFuncAttributes a{};
+  KIN_HIP(hipFuncGetAttributes(&a, (const void*)resident_bdf_kernel));
+  return a.sharedSizeBytes;
+}
+#define RES_LAUNCH_NAME launch_resident
+#else
+#define RES_LAUNCH_NAME launch_resident_shared_cu
+#endif
 
-void launch_resident(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s) {
+void RES_LAUNCH_NAME(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s) {
   if (K <= 0) return;
   static bool attr_set = false;
   if (!attr_set) { KIN_HIP(hipFuncSetAttribute((const void*)resident_bdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BUDGET)); attr_set = true; }

@@ -45,5 +45,8 @@ constexpr int RES_MAX_DENSE = 512;
 size_t resident_dyn_lds(int N, int R, int m, int64_t window);
 constexpr size_t RES_LDS_BUDGET = 160 * 1024 - 14 * 1024;   // what is left of a CU's LDS next to the kernel's static blocks
 void launch_resident(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
+// the same kernel built with half the registers per lane: two workgroups share a compute unit (resident_w4.hip)
+void launch_resident_shared_cu(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
+size_t resident_static_lds();    // static LDS of the kernel (what two co-resident workgroups need twice, next to 2 x dyn_lds)
 
 }  // namespace kin

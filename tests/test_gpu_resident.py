@@ -167,6 +167,30 @@ def test_ensemble_members_are_bit_identical_to_solo_solves():
     h.close()
 
 
+def test_more_members_than_compute_units_take_the_shared_cu_build(monkeypatch):
+    """K > the chip's compute units: the launch uses the kernel built with half the registers per lane, two workgroups per
+    compute unit (resident_w4.hip). Same source, same arithmetic: members equal their solo solves (the one-workgroup-per-CU
+    build) bit for bit; forced on for a small ensemble and forced off for the large one as well."""
+    net, Ea, A = synthetic_crn(100, 500)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    K = 300
+    U0 = np.zeros((K, 100)); U0[:, 0] = 1.0
+    T = np.linspace(900.0, 1300.0, K)
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(2e-3), U0, T=T)
+    assert (rcs == 0).all() and (ns == 3).all()
+    for i in (0, 137, K - 1):
+        h.rates_at(float(T[i]))
+        ts, us, rc, st, _ = h.solve(kp(2e-3), U0[i])
+        assert rc == 0 and np.array_equal(us, u[i]) and st["n_steps"] == sts[i]["n_steps"]
+    monkeypatch.setenv("KIN_RESIDENT_SHARED_CU", "0")
+    _, u0_, _, rcs0, _ = h.solve_ensemble(kp(2e-3), U0, T=T)
+    monkeypatch.setenv("KIN_RESIDENT_SHARED_CU", "1")
+    _, u1_, _, rcs1, _ = h.solve_ensemble(kp(2e-3), U0[:5], T=T[:5])
+    assert np.array_equal(u0_, u) and np.array_equal(u1_, u[:5]) and (rcs0 == 0).all() and (rcs1 == 0).all()
+    h.close()
+
+
 def test_a_member_that_fails_does_not_disturb_the_others():
     h = capi.HipNetwork.from_flat(ROB)
     ks = np.array([ROB_K, ROB_K * np.array([1.0, 1e30, 1.0]), ROB_K])      # member 1: rates that overflow the state
