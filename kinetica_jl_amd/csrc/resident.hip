@@ -26,6 +26,8 @@
 // it (src/solving/methods.jl:185-303, 717-865; solve_utils.jl:376-424, 435-509).
 #include "resident.hpp"
 
+#include <atomic>
+
 #include "exp_tab.hpp"
 #include "gj_dev.hpp"
 #include "segsum_dev.hpp"
@@ -986,8 +988,15 @@ size_t resident_static_lds() {
 
 void RES_LAUNCH_NAME(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s) {
   if (K <= 0) return;
-  static bool attr_set = false;
-  if (!attr_set) { KIN_HIP(hipFuncSetAttribute((const void*)resident_bdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BUDGET)); attr_set = true; }
+  // the attribute belongs to the (function, device) pair: handles of one process may live on different GPUs
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  KIN_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    KIN_HIP(hipFuncSetAttribute((const void*)resident_bdf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BUDGET));
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
   hipLaunchKernelGGL(resident_bdf_kernel, dim3((unsigned)K), dim3(RES_WG), dyn_lds, s, d_net, d_traj, d_par);
   KIN_HIP(hipGetLastError());
 }
