@@ -799,6 +799,27 @@ def main():
                                                  "factorisations_per_member": float(np.mean([q["n_factor"] for q in sts])),
                                                  "form": "lockstep rounds of batched launches, one host thread per member's controller, dense Schur inverses of "
                                                          "members that factorise together as one batched chain (DESIGN 3.5)"}
+            # ... and a mid-size network (beyond the resident kernel's LDS budget as well): 3 000 species, 64 members
+            net3, Ea3, A3 = synthetic_crn(3000, 15000)
+            h3 = capi.HipNetwork.from_flat(net3)
+            try:
+                h3.set_arrhenius(Ea3, A3, k_max=1e12)
+                U3 = np.zeros((64, 3000)); U3[:, 0] = 1.0
+                T3 = 1000.0 + 5.0 * np.arange(64)
+                h3.solve_ensemble(kparams(2), U3, T=T3)
+                t1 = time.perf_counter()
+                _, ue, nsv, rcs, sts = h3.solve_ensemble(kparams(2), U3, T=T3)
+                w = time.perf_counter() - t1
+                h3.rates_at(1000.0)
+                h3.solve(kparams(2), U3[0])
+                t1 = time.perf_counter()
+                h3.solve(kparams(2), U3[0])
+                w1 = time.perf_counter() - t1
+                res["3000_species_K64_lockstep"] = {"wall_s": w, "solves_per_s": 64 / w, "members_ok": int((rcs == 0).sum()), "members": 64,
+                                                    "steps_per_member": float(np.mean([q["n_steps"] for q in sts])),
+                                                    "one_member_alone_kin_solve_s": w1, "over_one_member_at_a_time": (64 / w) * w1}
+            finally:
+                h3.close()
             return dict(res, workload="kin_solve_ensemble: K members of one network, first 2 default chunks each, host buffers in and out; "
                                       "300 / 1000 species: ONE launch of kin::resident_bdf_kernel (one workgroup per member; the members' temperatures "
                                       "span 900-1300 K, a launch takes as long as its slowest member once K <= the 256 compute units)")
