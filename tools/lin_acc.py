@@ -1,11 +1,15 @@
+"""Accuracy of the device's Newton-matrix solve (kin_newton_solve: unpivoted sparse rounds, explicit triangular inverses, dense
+Schur inverse) against SuperLU on the same matrices: residuals and distance of the solutions. Usage: python tools/lin_acc.py [N] [seed]"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
 from kinetica_jl_amd import capi
 from kinetica_jl_amd.synth import synthetic_crn
 from oracle import oracle as orc, bdf as obdf
-N, R = 10000, 50000
-net, Ea, A = synthetic_crn(N, R)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+R = 5 * N
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+net, Ea, A = synthetic_crn(N, R, seed=SEED)
 on = orc.OracleNetwork.from_flat(net)
 k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
 h = capi.HipNetwork.from_flat(net); h.set_rates(k)
