@@ -25,6 +25,7 @@
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <thread>
 
 #include "lu.hpp"
 #include "solver_kernels.hpp"
@@ -206,6 +207,10 @@ struct Solver {
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 50e-3) {
           fast_sync = false; n_sync_fallbacks++; sync_ok_streak = 0; break;
         }
+        // a hand-over takes 10-100 us: spin politely (the sibling hardware thread keeps its issue slots), and once the wait
+        // is longer than a plain attempt - a factorisation is in the batch, or K handles share fewer cores - give the core away
+        __builtin_ia32_pause();
+        if (spins > 20000 && (spins & 63) == 63) std::this_thread::yield();
       }
     }
     sync_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
