@@ -232,7 +232,7 @@ int resident_solve(kin_network* h, const kin_params& p, const double* u0, const 
   if (getenv("KIN_RESIDENT_PROFILE")) {
     static const char* names[20] = {"kernel", "factor", "(of which dense inverse)", "corrector attempts", "(solve)", "predict", "change_D",
                                     "accept", "jacobian", "rhs", "(rates + residual)", "(update + sums)", "((rates))", "((stage A))", "((gemv))",
-                                    "((stage C))", "((reduce))", "(((reduce: lane sums)))", "(((reduce: first barrier)))", "(((reduce: reads + second barrier)))"};
+                                    "((stage C))", "((reduce))", "(((reduce: lane sums)))", "(((reduce: first barrier)))", "controller between phases (a worker wavefront waiting for its next command)"};
     fprintf(stderr, "[resident] N=%lld m=%d slots=%d steps=%lld factor=%lld linsolve=%lld wall %.4f s\n", (long long)N, RS.lu.m, slots,
             (long long)r.st.n_steps, (long long)r.st.n_factor, (long long)r.st.n_linsolve,
             std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());

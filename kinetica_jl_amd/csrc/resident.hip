@@ -189,7 +189,7 @@ __device__ __forceinline__ void wg_reduce(double (&v)[NV]) {
     v[q] = t;
   }
   __syncthreads();
-  if (pf) { const long long c3 = wall_clock64(); g_sh.prof[17] += c1 - c0; g_sh.prof[18] += c2 - c1; g_sh.prof[19] += c3 - c2; }
+  if (pf) { g_sh.prof[17] += c1 - c0; g_sh.prof[18] += c2 - c1; }      // (the rest of PF_REDUCE: reads + second barrier)
 }
 
 // The in-workgroup executor of a gather plan (kernels.hip: segsum_kernel spreads the same tasks over a grid): wavefront
@@ -880,8 +880,13 @@ struct DevBackend {
 
 // what the fifteen other wavefronts do: wait for a command, run its phase, until the leader posts OP_EXIT
 __device__ void worker_loop() {
+  // (profile: what the first worker wavefront spends waiting for the next command = the controller's own time between
+  // two phases, incl. the calls' register saves and the posting)
+  const bool pf = g_cx.profile && threadIdx.x == 64;
   for (;;) {
+    const long long w0 = pf ? wall_clock64() : 0;
     __syncthreads();
+    if (pf) g_sh.prof[19] += wall_clock64() - w0;
     const int op = g_sh.cmd_op;
     if (op == OP_EXIT) return;
     const int i0 = g_sh.cmd_i[0], i1 = g_sh.cmd_i[1];

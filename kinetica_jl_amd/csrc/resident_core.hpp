@@ -146,8 +146,11 @@ struct ResidentBdf {
     newton_tol = lo > P.newton_frac ? lo : P.newton_frac;
   }
 
-  KIN_HD static void compute_R(int ord, double factor, double R[6][6]) {
-    double M[6][6];
+  // work matrices of change_D: MEMBERS, not locals - on the device the controller object lives in LDS, dynamically indexed
+  // local arrays would live in scratch (= global memory: a dependent store / load pair there costs microseconds)
+  double wM[6][6], wR[6][6], wU[6][6], wRU[6][6], wp[RES_MAX_ORDER + 1];
+  KIN_HD void compute_R(int ord, double factor, double R[6][6]) {
+    double (&M)[6][6] = wM;
     for (int i = 0; i <= ord; i++)
       for (int j = 0; j <= ord; j++) M[i][j] = 0.0;
     for (int j = 0; j <= ord; j++) M[0][j] = 1.0;
@@ -159,7 +162,7 @@ struct ResidentBdf {
     }
   }
   KIN_HD void change_D(int ord, double factor) {
-    double R[6][6], U[6][6], RU[6][6];
+    double (&R)[6][6] = wR; double (&U)[6][6] = wU; double (&RU)[6][6] = wRU;
     compute_R(ord, factor, R);
     compute_R(ord, 1.0, U);
     for (int a = 0; a <= ord; a++)
@@ -390,7 +393,7 @@ struct ResidentBdf {
 
   // dense output of the step that ended at t into solution row `row`
   KIN_HD void interpolate(double ts, int64_t row) {
-    double p[RES_MAX_ORDER + 1];
+    double (&p)[RES_MAX_ORDER + 1] = wp;
     double prod = 1.0;
     p[0] = 0.0;
     for (int j = 0; j < order; j++) {
