@@ -26,6 +26,13 @@
 // it (src/solving/methods.jl:185-303, 717-865; solve_utils.jl:376-424, 435-509).
 #include "resident.hpp"
 
+// A phase is a function of its own (the whole register file, the controller's live scalars saved once per call) in the build
+// with 256 registers per lane; in the 128-register build (resident_w4.hip) the calls' register saves go to scratch memory and
+// inlining the phases is worth 13 % (300 species, 1 024 members: 4 200-4 600 -> 4 800-5 200 solves/s; no gain at 256 registers)
+#ifndef RES_PHASE
+#define RES_PHASE __device__ __noinline__
+#endif
+
 #include <atomic>
 
 #include "exp_tab.hpp"
@@ -257,7 +264,7 @@ __device__ __forceinline__ SegPlanViewG hot_plan(int id) { return plan_g(g_cx.pl
 // window are LDS arrays (L_y() ...), everything else global
 // ------------------------------------------------------------------------------------------------------------------
 enum VecOp : int { VO_LOAD_U0 = 0, VO_CHUNK_START_FROM_Y, VO_Y_FROM_CHUNK_START_CLIPPED, VO_Y_FROM_D0, VO_YTMP_FROM_D0, VO_YTMP_AXPY };
-__device__ __noinline__ void ph_vec(int op, double h0) {
+RES_PHASE void ph_vec(int op, double h0) {
   const int N = uni(g_cx.N), tid = threadIdx.x;
   double* y = L_y();
   if (op == VO_LOAD_U0) { gcd_t* u0 = glob(g_cx.T.u0); for (int i = tid; i < N; i += RES_WG) y[i] = u0[i]; }
@@ -272,7 +279,7 @@ __device__ __noinline__ void ph_vec(int op, double h0) {
   __syncthreads();
 }
 
-__device__ __noinline__ void ph_save_y(long long row, double time) {
+RES_PHASE void ph_save_y(long long row, double time) {
   const int N = uni(g_cx.N);
   const double* y = L_y();
   gd_t* o = glob(g_cx.T.sol) + (size_t)row * N;
@@ -281,7 +288,7 @@ __device__ __noinline__ void ph_save_y(long long row, double time) {
   __syncthreads();
 }
 
-__device__ __noinline__ void ph_apply_rates(long long stop) {
+RES_PHASE void ph_apply_rates(long long stop) {
   const int R = uni(g_cx.R);
   gd_t* k = glob(g_cx.T.k);
   const ResNetDev* net = g_cx.net;
@@ -312,7 +319,7 @@ __device__ __forceinline__ void rates_into(UP u) {
 }
 
 enum RhsOp : int { RO_Y_TO_F0 = 0, RO_YTMP_TO_F1, RO_YTMP_TO_F0 };
-__device__ __noinline__ void ph_rhs(int op) {
+RES_PHASE void ph_rhs(int op) {
   RES_PROF(PF_RHS);
   gd_t* out = glob(op == RO_YTMP_TO_F1 ? g_cx.T.f1 : g_cx.T.f0);
   if (op == RO_Y_TO_F0) rates_into((const double*)L_y());
@@ -324,7 +331,7 @@ __device__ __noinline__ void ph_rhs(int op) {
 }
 
 // analytic Jacobian at y into T.jv (CSR values)
-__device__ __noinline__ void ph_jac() {
+RES_PHASE void ph_jac() {
   RES_PROF(PF_JAC);
   const int R = uni(g_cx.R);
   const double* u = L_y();
@@ -344,7 +351,7 @@ __device__ __noinline__ void ph_jac() {
   __syncthreads();
 }
 
-__device__ __noinline__ ResNorms ph_norms(bool with_f1, double atol, double rtol) {
+RES_PHASE ResNorms ph_norms(bool with_f1, double atol, double rtol) {
   const int N = uni(g_cx.N);
   const double* y = L_y();
   gcd_t* f0p = glob((const double*)g_cx.T.f0); gcd_t* f1p = glob((const double*)g_cx.T.f1);
@@ -362,7 +369,7 @@ __device__ __noinline__ ResNorms ph_norms(bool with_f1, double atol, double rtol
   return ResNorms{sqrt(v[0] / Nd), sqrt(v[1] / Nd), sqrt(v[2] / Nd), v[3] > 0.0 ? 1 : 0};
 }
 
-__device__ __noinline__ void ph_init_D(bool from_ytmp, double h) {
+RES_PHASE void ph_init_D(bool from_ytmp, double h) {
   const int N = uni(g_cx.N);
   gcd_t* yt = glob((const double*)g_cx.T.ytmp);
   const double* y = L_y();
@@ -396,13 +403,13 @@ __device__ __forceinline__ void predict_body(int order, double alpha_o, double a
   }
   __syncthreads();
 }
-__device__ __noinline__ void ph_predict(int order, double alpha_o, double atol, double rtol) {
+RES_PHASE void ph_predict(int order, double alpha_o, double atol, double rtol) {
   RES_PROF(PF_PREDICT);
   predict_body(order, alpha_o, atol, rtol);
 }
 
 // D[0..ord] <- (R U)^T D[0..ord], matrix in g_sh.ru
-__device__ __noinline__ void ph_change_D(int ord) {
+RES_PHASE void ph_change_D(int ord) {
   RES_PROF(PF_CHANGE_D);
   const int N = uni(g_cx.N);
   gd_t* D = glob(g_cx.T.D);
@@ -423,7 +430,7 @@ __device__ __noinline__ void ph_change_D(int ord) {
   __syncthreads();
 }
 
-__device__ __noinline__ void ph_accept(int order) {
+RES_PHASE void ph_accept(int order) {
   RES_PROF(PF_ACCEPT);
   const int N = uni(g_cx.N);
   gd_t* D = glob(g_cx.T.D);
@@ -442,7 +449,7 @@ __device__ __noinline__ void ph_accept(int order) {
 }
 
 // dense output into solution row `row` (weights in g_sh.coef)
-__device__ __noinline__ void ph_interp(int order, long long row) {
+RES_PHASE void ph_interp(int order, long long row) {
   const int N = uni(g_cx.N);
   gcd_t* D = glob((const double*)g_cx.T.D);
   gd_t* o = glob(g_cx.T.sol) + (size_t)row * N;
@@ -456,7 +463,7 @@ __device__ __noinline__ void ph_interp(int order, long long row) {
 
 // drift guard of the LU cache at a restart (solver_kernels.hip: slot_drift_kernel): g_sh.drift[s] for every valid slot
 // (validity and c_fact of the slots in g_sh.slot_valid / slot_c, written by the caller)
-__device__ __noinline__ void ph_drift() {
+RES_PHASE void ph_drift() {
   const int N = uni(g_cx.N), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   gcd_t* jv = glob((const double*)g_cx.T.jv);
   gci_t* j_diag = glob(g_cx.net->j_diag);
@@ -556,7 +563,7 @@ __device__ __forceinline__ void gj_blocked(gd_t* S, gd_t* S2, int ld, int m16) {
 }
 
 // M = I - c J factorised into slot `slot` (SparseLU::factor); returns true when a pivot vanished
-__device__ __noinline__ bool ph_factor(int slot, double c, bool keep_diag) {
+RES_PHASE bool ph_factor(int slot, double c, bool keep_diag) {
   RES_PROF(PF_FACTOR);
   const int tid = threadIdx.x;
   const ResNetDev* net = g_cx.net;
@@ -656,7 +663,7 @@ __device__ __forceinline__ void gemv_wg(gcd_t* S, int ld, int m, const double* y
 
 // M x = b with the factors in W (global) and the vectors in the LDS window: b at win[yloc], x at win[xloc] (SparseLU::solve).
 // One function per solve form: an iteration only ever fetches the code of the form its network uses.
-__device__ __noinline__ void solve_fused(gcd_t* Wc) {
+RES_PHASE void solve_fused(gcd_t* Wc) {
   const SegExtraG ex{};
   double* win = L_win();
   const double* winc = win;
@@ -666,7 +673,7 @@ __device__ __noinline__ void solve_fused(gcd_t* Wc) {
   { RES_PROF(PF_GEMV); gemv_wg(Wc + uni((long long)g_cx.off_S), mpad, m, winc + off_y + ns, win + off_x); }
   { RES_PROF(PF_STAGEC); seg_run<SEG_PROD_SET>(hot_plan(PL_STAGEC), Wc, winc, win, winc, ex); __syncthreads(); }
 }
-__device__ __noinline__ void solve_explicit(gcd_t* Wc) {
+RES_PHASE void solve_explicit(gcd_t* Wc) {
   const SegExtraG ex{};
   double* win = L_win();
   const double* winc = win;
@@ -680,7 +687,7 @@ __device__ __noinline__ void solve_explicit(gcd_t* Wc) {
   seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_BWDT), Wc, winc, win, winc, ex); __syncthreads();
   seg_run<SEG_PROD_SET>(hot_plan(PL_BWDV), Wc, winc, win, winc, ex); __syncthreads();
 }
-__device__ __noinline__ void solve_plain(gcd_t* Wc) {
+RES_PHASE void solve_plain(gcd_t* Wc) {
   // plain substitution: the divisor of a backward row (aux) is a factor value, i.e. in global memory
   const SegExtraG ex{};
   const ResNetDev* net = g_cx.net;
@@ -751,7 +758,7 @@ struct InnerOps {
     return newton_body(slot, c, upd, order, ec, ec_m, ec_p, atol, rtol);
   }
 };
-__device__ __noinline__ ResAttempt ph_corrector() {
+RES_PHASE ResAttempt ph_corrector() {
   RES_PROF(PF_NEWTON);
   const ResCorrIn in = g_sh.corr;
   InnerOps ops;
