@@ -646,6 +646,14 @@ def main():
                                         "dtmin": RAMP_DTMIN}
             e = np.abs(fin - uu[-1]) / (1e-10 + 1e-8 * np.abs(uu[-1]))
             res["final_states_apart_in_tolerance_units"] = {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean()))}
+            # EXTENSION (kin_params.solve_chunks = 2): the same 1 000 chunks with history, order and step size carried across
+            # the chunk starts (no rate update happens there) instead of the reference's re-initialisation
+            fin_c = uu[-1].copy()
+            t1 = time.perf_counter()
+            tt, uu, rc3, st3, _ = h.solve(kpc(1.0, 1e-3, chunks=2), u0)
+            ew = np.abs(uu[-1] - fin_c) / (1e-10 + 1e-8 * np.abs(fin_c))
+            res["chunkwise_1000_chunks_warm_extension"] = {"wall_s": time.perf_counter() - t1, "retcode": rc3, "n_saved": len(tt), "stats": brief(st3),
+                                                           "final_state_vs_complete_timespan_units": {"max": float(ew.max()), "rms": float(np.sqrt((ew ** 2).mean()))}}
             return res
 
         def c3_30_chunks():
@@ -656,7 +664,8 @@ def main():
             z = np.load(tp)
             h.rates_at(1000.0)
             res = {"truth": "tests/golden/truth_c3_mid.npz (CPU port at 1000x tighter tolerances, every 5th chunk end)", "truth_self_check": float(z["self_check"])}
-            for name, pr in (("chunkwise", kpc(0.03, 1e-3)), ("complete_timespan", kpc(0.03, 1e-3, save=5e-3, chunks=0, dtmin=RAMP_DTMIN))):
+            for name, pr in (("chunkwise", kpc(0.03, 1e-3)), ("complete_timespan", kpc(0.03, 1e-3, save=5e-3, chunks=0, dtmin=RAMP_DTMIN)),
+                             ("chunkwise_warm_extension", kpc(0.03, 1e-3, chunks=2))):
                 t1 = time.perf_counter()
                 tt, uu, rcq, stq, _ = h.solve(pr, u0)
                 w = time.perf_counter() - t1

@@ -164,7 +164,10 @@ typedef struct kin_params {
   double reltol;             /* 1e-8  */
   int32_t adaptive_tols;     /* true  */
   int32_t update_tols;       /* false */
-  int32_t solve_chunks;      /* true  */
+  int32_t solve_chunks;      /* true (1): chunkwise in local time, the integrator re-initialised at every chunk start as the
+                              * reference does (methods.jl:819); 0: complete timespan; 2 (EXTENSION): chunkwise with difference
+                              * history, order and step size carried across chunk starts whose rate constants did not change
+                              * (a StaticODESolve's chunk boundaries are not events); rate updates still re-initialise */
   int32_t ban_negatives;     /* false: isoutofdomain = any(u < 0) (methods.jl:169-171) */
   double solve_chunkstep;    /* 1e-3  */
   int64_t maxiters;          /* 100000 */

@@ -177,6 +177,17 @@ struct ResidentBdf {
   KIN_HD void eval_jac() { b.eval_jac_y(); st.n_jac++; lu_valid = false; steps_since_jac = 0; jac_stamp_now = st.n_restarts; }
   KIN_HD void predict() { b.predict(order, gamma, alpha[order], atol, rtol); }
 
+  // Warm continuation at a chunk start whose rates did not change (kin_params.solve_chunks == 2; Solver::resume): the system
+  // is autonomous and chunks run in local time, so difference history, order and step size stay valid. The Jacobian is
+  // evaluated at the chunk's first state and the LU cache's drift guard runs, as at a re-initialisation.
+  KIN_HD void resume() {
+    t = 0.0;
+    st.n_restarts++;
+    eval_jac();
+    jac_current = true;
+    if (P.lu_band > 0.0 && P.lu_drift_max > 0.0) st.n_lu_dropped += b.drift_check(P.lu_drift_max);
+  }
+
   // (re)start at segment-local time 0 from the state in y: order 1, fresh initial step, fresh Jacobian (Solver::restart)
   KIN_HD bool restart(double t_bound) {
     t = 0.0;
@@ -414,6 +425,7 @@ struct ResidentBdf {
     invalidate_lu();
     b.load_u0();
     int64_t next_stop = 0, n_saved = 0, rates_in_force = -1;
+    bool have_history = false, rates_changed = false;   // warm continuation across chunk starts (solve_chunks == 2)
     int retcode = RES_RET_SUCCESS;
     for (int64_t nc = 0; nc < P.n_chunks && retcode == RES_RET_SUCCESS; nc++) {
       st.n_chunks++;
@@ -429,13 +441,14 @@ struct ResidentBdf {
       int attempts = 0;
       for (;;) {   // adaptive_solve! (solve_utils.jl:376-424)
         attempts++;
+        if (attempts > 1) have_history = false;   // a retry starts cold from the chunk's first state
         retcode = RES_RET_SUCCESS;
         iters_left = P.maxiters;
         int64_t stop_i = stop_first;
         while (variable && stop_i < P.n_stops && P.tstops[stop_i] <= t_start_global) stop_i++;
         if (variable) {
           const int64_t want = stop_i > 0 ? stop_i - 1 : 0;
-          if (want != rates_in_force) { b.apply_rates(want); rates_in_force = want; }
+          if (want != rates_in_force) { b.apply_rates(want); rates_in_force = want; rates_changed = true; }
         }
         int save_i = 0;
         double t_seg = t_loc0;
@@ -452,7 +465,10 @@ struct ResidentBdf {
           }
           if (seg_end > t_seg) {
             const double seg_len = seg_end - t_seg;
-            if (!restart(seg_len)) { retcode = RES_RET_UNSTABLE; failed = true; break; }
+            if (P.solve_chunks == 2 && have_history && !rates_changed) resume();
+            else if (!restart(seg_len)) { retcode = RES_RET_UNSTABLE; failed = true; break; }
+            have_history = true;
+            rates_changed = false;
             while (t < seg_len) {
               const StepStatus ss = step(seg_len);
               if (iters_left < 0) { retcode = RES_RET_MAXITERS; failed = true; break; }
@@ -471,7 +487,7 @@ struct ResidentBdf {
             b.y_from_D0();
           }
           t_seg = seg_end;
-          if (ends_at_stop) { b.apply_rates(stop_i); rates_in_force = stop_i; stop_i++; }
+          if (ends_at_stop) { b.apply_rates(stop_i); rates_in_force = stop_i; stop_i++; rates_changed = true; }
         }
         if (!failed) {
           if (chunks && nc == P.n_chunks - 1 && L > 1 && P.save_hits_end) {

@@ -67,7 +67,7 @@ inline void res_default_settings(ResParams& P, int n_slots_max) {
 inline void res_fill_params(ResParams& P, const kin_params& p, const ResGrid& g) {
   P.tspan0 = p.tspan0; P.tspan1 = p.tspan1; P.abstol = p.abstol; P.reltol = p.reltol; P.chunkstep = p.solve_chunkstep;
   P.dtmin = g.dtmin;
-  P.solve_chunks = p.solve_chunks != 0; P.adaptive_tols = p.adaptive_tols != 0; P.ban_negatives = p.ban_negatives != 0;
+  P.solve_chunks = p.solve_chunks == 2 ? 2 : (p.solve_chunks != 0 ? 1 : 0); P.adaptive_tols = p.adaptive_tols != 0; P.ban_negatives = p.ban_negatives != 0;
   P.save_hits_end = g.save_hits_end ? 1 : 0;
   P.maxiters = p.maxiters; P.n_chunks = g.n_chunks;
   P.L = (int32_t)g.save_local.size();

@@ -370,6 +370,28 @@ struct Solver {
     }
   }
 
+  // Warm continuation at a chunk start with unchanged rates (kin_params.solve_chunks == 2): history, order and step size are
+  // kept; the Jacobian is evaluated at the chunk's first state and the LU cache's drift guard runs as at a restart
+  void resume_chunk() {
+    spec = Spec{};
+    t = 0.0;
+    st.n_restarts++;
+    flush_accept();
+    KIN_HIP(hipMemcpyAsync(y.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    eval_jac(y.p);
+    jac_current = true;
+    if (lu_band > 0.0 && lu_drift_max > 0.0) {
+      SlotDriftArgs a;
+      const int n_checked = (int)lu.slots.size();
+      for (int i = 0; i < n_checked; i++) { a.jd[i] = lu.slots[i].valid ? lu.slots[i].jd.p : nullptr; a.c[i] = lu.slots[i].c_fact; }
+      launch_slot_drift(N, n_checked, jv.p, d_jdiag.p, a, d_drift.p, s);
+      KIN_HIP(hipMemcpyAsync(h_drift, d_drift.p, (size_t)n_checked * sizeof(double), hipMemcpyDeviceToHost, s));
+      KIN_HIP(hipStreamSynchronize(s));
+      for (int i = 0; i < n_checked; i++)
+        if (lu.slots[i].valid && !(h_drift[i] <= lu_drift_max)) { lu.slots[i].valid = false; st.n_lu_dropped++; }
+    }
+  }
+
   // CVODE's carried convergence rate (KIN_CARRY_RATE=0 switches it off): each factorisation remembers the contraction its
   // corrector iterations have shown, and the first iteration of a step is judged with it (solver_kernels.hip)
   bool carry_rate = true;
@@ -1172,7 +1194,11 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
           const double seg_len = seg_end - t_seg;
           seg_origin = t_seg + shift;
           if (continuous) S.pre_attempt(0.0);   // rates at the segment start for f0 / J of the restart
-          if (have_history && !cold_restarts) S.resume(rates_changed);
+          // kin_params.solve_chunks == 2: warm continuation at a chunk start whose rates did not change (a StaticODESolve's
+          // chunk boundaries; between the rate updates of a ramp the integrator is re-initialised as the reference does)
+          const bool warm_chunk = p.solve_chunks == 2 && have_history && !rates_changed && !continuous && !S.explicit_mode;
+          if (warm_chunk) S.resume_chunk();
+          else if (have_history && !cold_restarts) S.resume(rates_changed);
           else if (!S.restart(0.0, seg_len)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
           have_history = true;
           rates_changed = false;

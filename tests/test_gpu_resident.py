@@ -191,6 +191,34 @@ def test_more_members_than_compute_units_take_the_shared_cu_build(monkeypatch):
     h.close()
 
 
+def test_warm_chunk_continuation_in_all_three_drivers(monkeypatch):
+    """kin_params.solve_chunks = 2 through the resident kernel, the host-driven integrator and - as ensemble members - the
+    resident ensemble and the lockstep rounds: same save times as the re-initialising run, fewer steps, results within the
+    step-sequence tolerance of each other and of the re-initialising run."""
+    net, Ea, A = synthetic_crn(300, 1500)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    h.rates_at(1000.0)
+    u0 = np.zeros(300); u0[0] = 1.0
+    cold = kp(1e-2)
+    warm = kp(1e-2, solve_chunks=2)
+    tc, uc, rcc, stc, _ = h.solve(cold, u0)
+    tw, uw, rcw, stw, _ = h.solve(warm, u0)
+    assert rcc == 0 and rcw == 0 and np.array_equal(tc, tw) and stw["n_restarts"] == 10
+    assert stw["n_steps"] < 0.9 * stc["n_steps"] and units(uw, uc) < 150          # measured 970 against 1 129
+    monkeypatch.setenv("KIN_RESIDENT", "0")
+    th, uh, rch, sth, _ = h.solve(warm, u0)
+    monkeypatch.delenv("KIN_RESIDENT")
+    assert rch == 0 and np.array_equal(th, tw) and sth["lu_slots"] > 64 and abs(sth["n_steps"] - stw["n_steps"]) <= 0.1 * stw["n_steps"]
+    assert units(uh, uw) < 150
+    te, ue, _, rcs, sts = h.solve_ensemble(warm, np.tile(u0, (2, 1)), T=np.array([1000.0, 1100.0]))
+    assert (rcs == 0).all() and np.array_equal(ue[0], uw) and sts[0]["n_steps"] == stw["n_steps"]
+    monkeypatch.setenv("KIN_ENSEMBLE_BATCHED", "1")
+    tl, ul, _, rcl, stl = h.solve_ensemble(warm, np.tile(u0, (2, 1)), T=np.array([1000.0, 1100.0]))
+    assert (rcl == 0).all() and units(ul[0], uw) < 150 and abs(stl[0]["n_steps"] - stw["n_steps"]) <= 0.1 * stw["n_steps"]
+    h.close()
+
+
 def test_a_member_that_fails_does_not_disturb_the_others():
     h = capi.HipNetwork.from_flat(ROB)
     ks = np.array([ROB_K, ROB_K * np.array([1.0, 1e30, 1.0]), ROB_K])      # member 1: rates that overflow the state

@@ -183,3 +183,27 @@ def test_ban_negatives_rejects_steps_like_the_cpu_implementation():
     assert abs(st["n_steps"] - stc["n_steps"]) <= 0.05 * stc["n_steps"] + 5
     assert units(u, uc) < 100
     hr.close()
+
+
+def test_warm_continuation_across_chunk_starts():
+    """kin_params.solve_chunks = 2 (extension): history, order and step size are carried across chunk starts whose rate
+    constants did not change; rate updates still re-initialise. Same save times, fewer steps, and - the chunk boundaries of a
+    static solve are not events - the result stays with the exact solution: compared with a 100x tighter chunkwise run."""
+    net, Ea, A = synthetic_crn(200, 1000)
+    k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
+    hr = HostResident(net)
+    u0 = np.zeros(200); u0[0] = 1.0
+    tc, uc, rcc, stc = hr.solve(kp(1e-2), u0, k0=k)
+    tw, uw, rcw, stw = hr.solve(kp(1e-2, solve_chunks=2), u0, k0=k)
+    tt, ut, rct, _ = hr.solve(kp(1e-2, abstol=1e-12, reltol=1e-10, dtmin=1e-30), u0, k0=k)
+    assert rcc == 0 and rcw == 0 and rct == 0 and np.array_equal(tc, tw) and len(tw) == 11
+    assert stw["n_chunks"] == 10 and stw["n_restarts"] == 10          # a segment start each, one of them cold
+    assert stw["n_steps"] < 0.85 * stc["n_steps"] and stw["n_factor"] < stc["n_factor"]
+    assert units(uw, ut) <= 100 and units(uw, ut) <= units(uc, ut) + 20
+    # with rate updates inside the span the integrator re-initialises at each of them: warm mode changes nothing there
+    hr.set_arrhenius(Ea, A, k_max=1e12)
+    tst = np.arange(10) * 1e-3
+    Ts = 900.0 + 2e4 * tst
+    t1, u1, rc1, st1 = hr.solve(kp(1e-2), u0, tstops=tst, T_stops=Ts)
+    t2, u2, rc2, st2 = hr.solve(kp(1e-2, solve_chunks=2), u0, tstops=tst, T_stops=Ts)
+    assert rc1 == 0 and rc2 == 0 and np.array_equal(u1, u2) and st1["n_steps"] == st2["n_steps"]

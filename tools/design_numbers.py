@@ -86,11 +86,18 @@ def build():
     add("configurations", "C3 over (0, 1) s chunkwise (1 000 chunks): wall, steps, factorisations", f"{cw['wall_s']:.2f} s, {cw['stats']['n_steps']}, {cw['stats']['n_factor']}", f"{src_b} `configs.C3_whole_span`")
     add("configurations", "C3 over (0, 1) s as ONE integration: wall, steps, corrector failures, factorisations",
         f"{cc['wall_s']:.3f} s, {cc['stats']['n_steps']}, {cc['stats']['n_newton_fail']}, {cc['stats']['n_factor']}", f"{src_b} `configs.C3_whole_span`")
+    cwm = c3.get("chunkwise_1000_chunks_warm_extension")
+    if cwm:
+        add("configurations", "C3 over (0, 1) s, 1 000 chunks with warm continuation (extension `solve_chunks = 2`): wall, steps, factorisations; final state vs the single integration",
+            f"{cwm['wall_s']:.2f} s, {cwm['stats']['n_steps']}, {cwm['stats']['n_factor']}; {cwm['final_state_vs_complete_timespan_units']['max']:.0f} / {cwm['final_state_vs_complete_timespan_units']['rms']:.1f} units",
+            f"{src_b} `configs.C3_whole_span`")
     fa = c3["final_states_apart_in_tolerance_units"]
     add("configurations", "... final states of the two apart, tolerance units max / rms", f"{fa['max']:.0f} / {fa['rms']:.1f}", src_b)
     c30 = cf.get("C3_30_chunks_vs_truth")
     if c30 and "chunkwise" in c30:
-        for name in ("chunkwise", "complete_timespan"):
+        for name in ("chunkwise", "complete_timespan", "chunkwise_warm_extension"):
+            if name not in c30:
+                continue
             v30 = c30[name]["vs_truth_in_tolerance_units"]
             add("configurations", f"C3 over (0, 0.03) s {name.replace('_', ' ')} against `truth_c3_mid.npz`: wall, steps; max / rms units",
                 f"{c30[name]['wall_s']:.3f} s, {c30[name]['stats']['n_steps']}; {v30['max']:.0f} / {v30['rms']:.1f}", f"{src_b} `configs.C3_30_chunks_vs_truth`")
