@@ -85,18 +85,20 @@ def c5():
 
 
 def c3_long():
-    """C3 over (0, 0.1) s = 100 default chunks: every 10th chunk end is stored."""
+    """C3 over (0, 0.1) s = 100 default chunks: every 10th chunk end is stored. Tolerances x1e-2 (checked
+    against x1e-1): at x1e-3 = rtol 1e-11 the integration sits on the rounding floor of the right-hand side and did not finish
+    in four hours on one core of the build container (30 chunks at x1e-3 took 39 minutes, c3_mid; DESIGN 4.0 has the floor)."""
     net, Ea, A = synthetic_crn(10000, 50000)
     k = orc.arrhenius(Ea, A, 1000.0, k_max=1e12)
     u0 = np.zeros(10000); u0[0] = 1.0
     cs = cpu_bdf.CpuSolver(net)
     pars = dict(tspan=(0.0, 0.1), solve_chunks=True, solve_chunkstep=1e-3)
-    t, u = solve(cs, pars, u0, 1e-3, k0=k)
-    t2, u2 = solve(cs, pars, u0, 1e-2, k0=k)
+    t, u = solve(cs, pars, u0, 1e-2, k0=k)
+    t2, u2 = solve(cs, pars, u0, 1e-1, k0=k)
     keep = list(range(0, 101, 10))
     sc = float(units(u2[keep], u[keep]).max())
     np.savez_compressed(os.path.join(HERE, "truth_c3_long.npz"), t=t[keep], u=u[keep], self_check=sc, T=1000.0, keep=np.array(keep))
-    print("wrote truth_c3_long.npz", u[keep].shape, "x1e-2 vs x1e-3:", sc)
+    print("wrote truth_c3_long.npz", u[keep].shape, "x1e-1 vs x1e-2:", sc)
 
 
 def c3_mid():
