@@ -105,6 +105,11 @@ def build():
     v = c4["vs_truth_in_tolerance_units"]
     add("C4 prefix", "first 20 chunks (200 restarts): wall, steps, factorisations", f"{c4['wall_s']:.2f} s, {c4['stats']['n_steps']}, {c4['stats']['n_factor']}", f"{src_b} `configs.C4_prefix`")
     add("C4 prefix", "... against `truth_c4_long.npz`: max / rms / p99.9 units (truth self-check)", f"{v['max']:.0f} / {v['rms']:.1f} / {v['p99.9']:.1f} ({v['truth_self_check']:.1f})", src_b)
+    pth = os.path.join(P, f"{TAG}_c4_full_run.json")
+    if os.path.exists(pth):
+        c4f = json.load(open(pth))
+        add("C4 prefix", "the whole 14 s ramp (tools/run_configs.py c4, C4_TEND=14): wall, steps, factorisations, restarts, retries",
+            f"{c4f['wall_s']:.1f} s, {c4f['stats']['n_steps']}, {c4f['stats']['n_factor']}, {c4f['stats']['n_restarts']}, {c4f['stats']['n_retries']} (retcode {c4f['retcode']})", f"{TAG}_c4_full_run.json")
     c5 = cf["C5_static"]
     add("configurations", "C5 static, 5 chunks: warm / cold, dense block", f"{c5['wall_s']:.2f} s / {c5['cold_wall_s_incl_create_and_analysis']:.2f} s, {c5['dense_block']}", f"{src_b} `configs.C5_static`")
 
