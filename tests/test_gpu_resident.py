@@ -290,4 +290,11 @@ def test_lockstep_ensemble_of_a_large_network(monkeypatch):
     tb, ub, _, rcb, stb = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
     assert (rcr == 0).all() and (rcb == 0).all() and np.array_equal(tr, tb)
     assert units(ub, ur) < 100
+    # a member that fails (rate constants that overflow its state) leaves the rounds; the others finish as without it
+    ks = np.array([h.rates_at(float(Ti)) for Ti in T])
+    kbad = ks.copy(); kbad[1] *= 1e40
+    tf, uf, nsf, rcf, stf = h.solve_ensemble(kp(2e-3, maxiters=3000), np.tile(u0, (4, 1)), k=kbad)
+    tg, ug, _, rcg, _ = h.solve_ensemble(kp(2e-3, maxiters=3000), np.tile(u0, (4, 1)), k=ks)
+    assert rcf[1] != 0 and (rcf[[0, 2, 3]] == 0).all() and (rcg == 0).all()
+    assert np.array_equal(uf[[0, 2, 3]], ug[[0, 2, 3]])
     h.close()
