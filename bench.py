@@ -718,6 +718,25 @@ def main():
         cfg = {}
         guarded(cfg, "C3_whole_span", c3_full)
         guarded(cfg, "C3_30_chunks_vs_truth", c3_30_chunks)
+
+        def c3_100_chunks():
+            # the headline solve (100 chunks) against tests/golden/truth_c3_long.npz, as the reference runs it and with warm chunk starts
+            tp = os.path.join(ROOT, "tests", "golden", "truth_c3_long.npz")
+            if not os.path.exists(tp):
+                return {"error": "tests/golden/truth_c3_long.npz is missing"}
+            z = np.load(tp)
+            h.rates_at(1000.0)
+            res = {"truth": "tests/golden/truth_c3_long.npz (CPU port at 100x tighter tolerances, every 10th chunk end)", "truth_self_check": float(z["self_check"])}
+            for name, pr in (("chunkwise", kpc(0.1, 1e-3)), ("chunkwise_warm_extension", kpc(0.1, 1e-3, chunks=2))):
+                t1 = time.perf_counter()
+                tt, uu, rcq, stq, _ = h.solve(pr, u0)
+                w = time.perf_counter() - t1
+                sel = [int(np.argmin(np.abs(tt - x))) for x in z["t"]]
+                e = np.abs(uu[sel] - z["u"]) / (1e-10 + 1e-8 * np.abs(z["u"]))
+                res[name] = {"wall_s": w, "retcode": rcq, "stats": brief(stq),
+                             "vs_truth_in_tolerance_units": {"max": float(e.max()), "rms": float(np.sqrt((e ** 2).mean(axis=1)).max())}}
+            return res
+        guarded(cfg, "C3_100_chunks_vs_truth", c3_100_chunks)
         guarded(cfg, "C4_prefix", c4_prefix)
         guarded(cfg, "C5_static", c5_solve)
         out.setdefault("solve_network", {})["configs"] = cfg

@@ -13,7 +13,9 @@ abstol 1e-10, reltol 1e-8 (params.jl:61-62):
     470 / 4.8 for the CPU baseline, 680 / 7.0 for the CPU baseline without the LU cache; keeping the difference history
     across rate updates - KIN_WARM_RESTART=1 - does not tighten it: 705 / 11.0 and 565 / 5.7), and the error is
     tolerance proportional: the same solve with 10x tighter tolerances must come within max e <= 100 (in DEFAULT units).
-Round 4 - longer truths (tests/golden/make_truth_configs.py c3_mid / c4_long):
+Round 4 - longer truths (tests/golden/make_truth_configs.py c3_mid / c3_long / c4_long):
+  * C3 over (0, 0.1) s, 100 chunks (truth_c3_long.npz, x1e-2 tolerances): chunkwise max e <= 750, rms <= 20 (measured 589 / 14.9);
+    as one integration <= 140 / 6 (106 / 4.4); warm chunk starts <= 200 / 6 (148 / 4.2); 10x tighter <= 80 / 5 (41 / 3.1);
   * C3 over (0, 0.03) s, 30 chunks (truth_c3_mid.npz): chunkwise max e <= 250, rms <= 11 (measured 170 / 7.6, growing with
     every restart); as one integration max e <= 60, rms <= 5.5 (measured 40 / 3.4);
   * C4 ramp, first 20 chunks = 200 restarts (truth_c4_long.npz): max e <= 620, rms <= 6.4, p99.9 <= 20 (measured 515 / 5.3 /
@@ -295,6 +297,41 @@ def test_c3_thirty_chunks_chunkwise_and_complete_against_truth(golden_dir, c3):
     ew = units(uw[sel], z["u"])
     assert stw["n_steps"] < 0.8 * st["n_steps"] and stw["n_factor"] < 0.8 * st["n_factor"]     # measured 1 024 / 128 against 1 489 / 243
     assert ew.max() <= 100 and ew.max() < e.max()                                                # measured 58 against 170
+    h.close()
+
+
+def test_c3_hundred_chunks_against_truth(golden_dir, c3):
+    """C3 over (0, 0.1) s = the bench's 100-chunk solve, against `truth_c3_long.npz` (CPU port at 100x tighter tolerances - at
+    1000x it sits on the rounding floor and does not finish -, every 10th chunk end; its 10x looser sibling is 41 default units
+    away, so the truth is good to ~5). Measured (tools/c3_mid_units.py long): chunkwise as the reference runs it 589 units max /
+    rms 14.9, growing with the restarts (46 after 10 chunks); as one integration 106 / 4.4; chunkwise with warm chunk starts
+    (extension) 148 / 4.2; chunkwise at 10x tighter tolerances 41 / 3.1."""
+    net, Ea, A, k = c3
+    z = np.load(os.path.join(golden_dir, "truth_c3_long.npz"))
+    assert float(z["self_check"]) < 60.0
+    h = capi.HipNetwork.from_flat(net)
+    h.set_rates(k)
+    u0 = np.zeros(net.n_species); u0[0] = 1.0
+
+    def against_truth(t, u):
+        sel = [int(np.argmin(np.abs(t - tt))) for tt in z["t"]]
+        np.testing.assert_allclose(t[sel], z["t"], rtol=0, atol=1e-15)
+        e = units(u[sel], z["u"])
+        return float(e.max()), float(np.sqrt((e ** 2).mean(axis=1)).max()), e
+
+    t, u, rc, st, status = h.solve(kp(0.1, 1e-3), u0)
+    assert status == capi.KIN_OK and rc == 0 and st["n_chunks"] == 100 and st["n_retries"] == 0
+    mx, rms, e = against_truth(t, u)
+    assert mx <= 750 and rms <= 20 and e[1].max() <= 100
+    t, u, rc, st, status = h.solve(kp(0.1, 1e-3, save=1e-2, chunks=False, dtmin=1e-30), u0)
+    mx, rms, _ = against_truth(t, u)
+    assert rc == 0 and st["n_restarts"] == 1 and mx <= 140 and rms <= 6
+    t, u, rc, st, status = h.solve(kp(0.1, 1e-3, chunks=2), u0)
+    mx, rms, _ = against_truth(t, u)
+    assert rc == 0 and st["n_chunks"] == 100 and mx <= 200 and rms <= 6
+    t, u, rc, st, status = h.solve(kp(0.1, 1e-3, abstol=1e-11, reltol=1e-9, dtmin=1e-30), u0)
+    mx, rms, _ = against_truth(t, u)
+    assert rc == 0 and mx <= 80 and rms <= 5          # tolerance proportional, in DEFAULT units
     h.close()
 
 

@@ -101,6 +101,12 @@ def build():
             v30 = c30[name]["vs_truth_in_tolerance_units"]
             add("configurations", f"C3 over (0, 0.03) s {name.replace('_', ' ')} against `truth_c3_mid.npz`: wall, steps; max / rms units",
                 f"{c30[name]['wall_s']:.3f} s, {c30[name]['stats']['n_steps']}; {v30['max']:.0f} / {v30['rms']:.1f}", f"{src_b} `configs.C3_30_chunks_vs_truth`")
+    c100 = cf.get("C3_100_chunks_vs_truth")
+    if c100 and "chunkwise" in c100:
+        for name in ("chunkwise", "chunkwise_warm_extension"):
+            v100 = c100[name]["vs_truth_in_tolerance_units"]
+            add("configurations", f"C3 over (0, 0.1) s, 100 chunks, {name.replace('_', ' ')} against `truth_c3_long.npz`: wall, steps; max / rms units",
+                f"{c100[name]['wall_s']:.3f} s, {c100[name]['stats']['n_steps']}; {v100['max']:.0f} / {v100['rms']:.1f}", f"{src_b} `configs.C3_100_chunks_vs_truth`")
     c4 = cf["C4_prefix"]
     v = c4["vs_truth_in_tolerance_units"]
     add("C4 prefix", "first 20 chunks (200 restarts): wall, steps, factorisations", f"{c4['wall_s']:.2f} s, {c4['stats']['n_steps']}, {c4['stats']['n_factor']}", f"{src_b} `configs.C4_prefix`")
