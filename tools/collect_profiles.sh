@@ -21,7 +21,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solve_stats" -- py
 # round 4: the resident integrator (one workgroup owns the trajectory; 300 species, 20 chunks), and a lockstep ensemble of the
 # 10k-species network (16 members, first 2 chunks)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/resident_stats" -- python3 tools/solve_stats.py 300 1500 20 > "$OUT/resident_stats.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ensemble_stats" -- python3 tools/ensemble_batched_check.py 10000 16 > "$OUT/ensemble_stats.log" 2>&1
+# (the profiler itself has crashed once in this leg - a SIGSEGV inside its dispatch hook under the launches of ~20 host threads,
+# gpurun_out/prof_r04/ensemble_stats.log of that run; the same command passes without the profiler and passed under it twice:
+# the leg must not take the others' summaries with it)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ensemble_stats" -- python3 tools/ensemble_batched_check.py 10000 16 > "$OUT/ensemble_stats.log" 2>&1 || echo "ensemble leg failed under the profiler"
 python3 tools/summarize_profiles.py "$OUT" "$TAG"
 # keep the merge-back small
 find "$OUT" -name "*kernel_trace.csv" -delete
