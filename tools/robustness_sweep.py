@@ -13,6 +13,7 @@ from kinetica_jl_amd import capi  # noqa: E402
 from kinetica_jl_amd.synth import synthetic_crn  # noqa: E402
 
 bad = 0
+SOLVE_CHUNKS = int(os.environ.get("SOLVE_CHUNKS", "1"))   # 2: the warm-chunk-start extension (kin_params.solve_chunks = 2)
 BAN = int(os.environ.get("BAN_NEG", "0"))      # ODESimulationParams.ban_negatives (isoutofdomain, methods.jl:169-171)
 WIDE = len(sys.argv) > 1 and sys.argv[1] in ("wide", "wide2")      # more seeds and temperatures on the two smaller sizes
 WIDE2 = len(sys.argv) > 1 and sys.argv[1] == "wide2"               # other seeds, in-between temperatures, looser / tighter tolerances
@@ -26,7 +27,7 @@ for (n, r) in (((10000, 50000),) if BIG else ((1000, 5000), (3000, 15000)) if WI
         u0 = np.zeros(n); u0[0] = 1.0
         for T, (ATOL, RTOL) in [(T, tl) for T in ((700.0, 900.0, 1100.0, 1300.0, 1500.0) if BIG else (900.0, 1100.0, 1300.0, 1500.0) if WIDE2 else (600.0, 800.0, 1000.0, 1200.0, 1400.0, 1800.0) if WIDE else (800.0, 1000.0, 1400.0)) for tl in TOLS]:
             h.rates_at(T)
-            p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=ATOL, reltol=RTOL, adaptive_tols=1, update_tols=0, solve_chunks=1,
+            p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=ATOL, reltol=RTOL, adaptive_tols=1, update_tols=0, solve_chunks=SOLVE_CHUNKS,
                                ban_negatives=BAN, solve_chunkstep=1e-3, maxiters=100000, save_interval=1e-3, dtmin=1e-30)
             t0 = time.perf_counter()
             t, u, rc, st, status = h.solve(p, u0)
@@ -38,7 +39,7 @@ for (n, r) in (((10000, 50000),) if BIG else ((1000, 5000), (3000, 15000)) if WI
             print(json.dumps(rec), flush=True)
         # a short ramp: 600 -> 1100 K over 10 ms, rate update every 0.5 ms, 2.5 ms chunks
         tst = np.arange(21) * 5e-4
-        p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=1,
+        p = capi.KinParams(tspan0=0.0, tspan1=1e-2, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=SOLVE_CHUNKS,
                            ban_negatives=BAN, solve_chunkstep=2.5e-3, maxiters=100000, save_interval=2.5e-3, dtmin=1e-30)
         t0 = time.perf_counter()
         t, u, rc, st, status = h.solve(p, u0, tstops=tst, T_stops=600.0 + 5e4 * tst)
