@@ -128,6 +128,13 @@ int resident_max_n() {
   return v;
 }
 
+// ... and on the dense Schur block of the Newton matrix: the in-workgroup dense inverse and GEMV grow with m^3 / m^2 while the
+// host-driven path's costs are flat; at the crossover network size of the synthetic CRNs (400 species) m is 130
+int resident_max_dense_single() {
+  static const int v = getenv("KIN_RESIDENT_MAX_DENSE") ? atoi(getenv("KIN_RESIDENT_MAX_DENSE")) : 160;
+  return v;
+}
+
 ResidentSolver* get_resident(kin_network* h) {
   if (!h->resident) h->resident.reset(new ResidentSolver(h));
   return h->resident.get();
@@ -200,7 +207,7 @@ bool resident_eligible(kin_network* h, const kin_params& p, bool continuous, boo
   if (getenv("KIN_TRACE_CHUNK") || getenv("KIN_INJECT_BAD_PIVOT")) return false;
   if (getenv("KIN_WARM_RESTART") && atoi(getenv("KIN_WARM_RESTART")) != 0) return false;
   ResidentSolver* RS = get_resident(h);
-  return RS->ok;
+  return RS->ok && RS->lu.m <= resident_max_dense_single();
 }
 
 bool resident_fits(kin_network* h) { return get_resident(h)->ok; }

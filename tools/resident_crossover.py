@@ -9,7 +9,7 @@ from kinetica_jl_amd import capi
 from kinetica_jl_amd.synth import synthetic_crn
 
 sizes = [int(a) for a in sys.argv[1:]] or [100, 200, 300, 400, 500, 700, 1000]
-os.environ["KIN_RESIDENT_MAX_N"] = "100000"        # eligibility by size off: the kernel's own limits decide
+os.environ["KIN_RESIDENT_MAX_N"] = "100000"; os.environ["KIN_RESIDENT_MAX_DENSE"] = "100000"   # eligibility by size off: the kernel's own limits decide
 p = capi.KinParams(tspan0=0.0, tspan1=2e-2, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=1, ban_negatives=0,
                    solve_chunkstep=1e-3, maxiters=100000, save_interval=-1.0)
 for N in sizes:

@@ -13,7 +13,7 @@ from kinetica_jl_amd.synth import synthetic_crn
 bad = 0
 worst = 0.0
 n_runs = 0
-os.environ["KIN_RESIDENT_MAX_N"] = "600"
+os.environ["KIN_RESIDENT_MAX_N"] = "600"; os.environ["KIN_RESIDENT_MAX_DENSE"] = "512"
 for n in (60, 100, 200, 300, 400, 550):
     for seed in (12345, 1, 2, 3):
         net, Ea, A = synthetic_crn(n, 5 * n, seed=seed)
