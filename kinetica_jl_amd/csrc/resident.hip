@@ -109,7 +109,7 @@ struct ResShared {
   double pinv[16][17];
   long long prof[20];
   int bad;
-  // command of the leader wavefront to the fifteen others (see resident_bdf_kernel)
+  // command of the leader wavefront to the seven others (see resident_bdf_kernel)
   int cmd_op, cmd_i[3];
   long long cmd_l;
   double cmd_d[8];
@@ -200,7 +200,7 @@ __device__ __forceinline__ void wg_reduce(double (&v)[NV]) {
 }
 
 // The in-workgroup executor of a gather plan (kernels.hip: segsum_kernel spreads the same tasks over a grid): wavefront
-// tasks round robin over the 16 wavefronts - long rows first (one wavefront walks such a row 512 entries per pass: no
+// tasks round robin over the 8 wavefronts - long rows first (one wavefront walks such a row 512 entries per pass: no
 // workgroup-wide reduction inside a phase), then medium rows, then the ELL groups of short rows.
 // one group of LANES lanes per medium row (4 entries per lane), 64 / LANES rows per wavefront task
 // srcA / srcB: arrays of the first / second factor (segsum_dev.hpp: seg_gather2), auxp: array of the `aux` operand
@@ -260,7 +260,7 @@ __device__ __forceinline__ void seg_run1(const SegPlanViewG& p, SP src, OP_ out,
 __device__ __forceinline__ SegPlanViewG hot_plan(int id) { return plan_g(g_cx.plan[id], g_cx.split[id][0], g_cx.split[id][1]); }
 
 // ------------------------------------------------------------------------------------------------------------------
-// phases (each called by all 1 024 threads; every one ends behind a barrier). y, d, psi, scale, the rates and the solve
+// phases (each called by all 512 threads; every one ends behind a barrier). y, d, psi, scale, the rates and the solve
 // window are LDS arrays (L_y() ...), everything else global
 // ------------------------------------------------------------------------------------------------------------------
 enum VecOp : int { VO_LOAD_U0 = 0, VO_CHUNK_START_FROM_Y, VO_Y_FROM_CHUNK_START_CLIPPED, VO_Y_FROM_D0, VO_YTMP_FROM_D0, VO_YTMP_AXPY };
@@ -885,7 +885,7 @@ struct DevBackend {
   }
 };
 
-// what the fifteen other wavefronts do: wait for a command, run its phase, until the leader posts OP_EXIT
+// what the seven other wavefronts do: wait for a command, run its phase, until the leader posts OP_EXIT
 __device__ void worker_loop() {
   // (profile: what the first worker wavefront spends waiting for the next command = the controller's own time between
   // two phases, incl. the calls' register saves and the posting)
