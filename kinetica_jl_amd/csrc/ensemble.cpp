@@ -645,9 +645,41 @@ bool ensemble_batched_supported(kin_network* h, std::string* why) {
 }
 
 // K members of one (large) network, advanced in lockstep rounds; arguments and outputs as resident_ensemble (resident.cpp)
+static void batched_ensemble_block(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
+                                   const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* out_rows,
+                                   double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats);
+
+// Every member's controller runs on a host thread of its own: an ensemble of more members than KIN_ENSEMBLE_MAX_MEMBERS
+// (default 128) is integrated block after block (the device is saturated long before that many members of a large network)
 void batched_ensemble(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
                       const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* out_rows,
                       double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats) {
+  int64_t block = 128;
+  if (const char* e = getenv("KIN_ENSEMBLE_MAX_MEMBERS")) block = std::max(1, atoi(e));
+  const int64_t N = h->host.N, R = h->host.R;
+  const int64_t cap = make_res_grid(p).cap;
+  if (K <= block) {
+    batched_ensemble_block(h, p, K, u0, k, T, tstops, T_stops, k_table, n_stops, out_rows, out_t, out_u, n_saved, retcodes, stats);
+    return;
+  }
+  // the save times are the members' common grid: they are taken from the block whose best member got furthest
+  std::vector<double> tt((size_t)cap);
+  std::vector<int64_t> ns((size_t)K, 0);
+  int64_t best = -1;
+  for (int64_t m0 = 0; m0 < K; m0 += block) {
+    const int64_t n = std::min(block, K - m0);
+    batched_ensemble_block(h, p, n, u0 + m0 * N, k ? k + m0 * R : nullptr, T ? T + m0 : nullptr, tstops, T_stops, k_table, n_stops, out_rows,
+                           tt.data(), out_u ? out_u + m0 * cap * N : nullptr, ns.data() + m0, retcodes ? retcodes + m0 : nullptr,
+                           stats ? stats + m0 : nullptr);
+    const int64_t b = *std::max_element(ns.begin() + m0, ns.begin() + m0 + n);
+    if (out_t && b > best) { std::copy(tt.begin(), tt.end(), out_t); best = b; }
+  }
+  if (n_saved) std::copy(ns.begin(), ns.end(), n_saved);
+}
+
+static void batched_ensemble_block(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
+                                   const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* out_rows,
+                                   double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats) {
   auto wall0 = std::chrono::steady_clock::now();
   EnsembleSolver& E = *get_ensemble(h);
   if (!E.ok) throw KinError(ERR_UNSUPPORTED, E.why);

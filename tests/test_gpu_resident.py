@@ -290,6 +290,11 @@ def test_lockstep_ensemble_of_a_large_network(monkeypatch):
     tb, ub, _, rcb, stb = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
     assert (rcr == 0).all() and (rcb == 0).all() and np.array_equal(tr, tb)
     assert units(ub, ur) < 100
+    # more members than KIN_ENSEMBLE_MAX_MEMBERS (a host thread each): block after block, the same members
+    monkeypatch.setenv("KIN_ENSEMBLE_MAX_MEMBERS", "3")
+    tm, um, nsm, rcm, _ = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
+    monkeypatch.delenv("KIN_ENSEMBLE_MAX_MEMBERS")
+    assert (rcm == 0).all() and np.array_equal(tm, tb) and np.array_equal(um, ub) and (nsm == 3).all()
     # a member that fails (rate constants that overflow its state) leaves the rounds; the others finish as without it
     ks = np.array([h.rates_at(float(Ti)) for Ti in T])
     kbad = ks.copy(); kbad[1] *= 1e40
