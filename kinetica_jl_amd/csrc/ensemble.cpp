@@ -5,6 +5,7 @@
 #include "ensemble.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -61,7 +62,12 @@ struct EnsembleSolver {
   DevBuf<EnsRep> d_reps;
   DevBuf<EnsOp> d_ops;
   std::vector<EnsRep> reps;
-  BdfCtrl* h_ctrl = nullptr;      // pinned, K
+  BdfCtrl* h_ctrl = nullptr;      // pinned (coherent, mapped), K
+  BdfCtrl* h_ctrl_dev = nullptr;  // ... its device address
+  unsigned long long* h_seq = nullptr; unsigned long long* h_seq_dev = nullptr;   // sequence number of the last published round
+  unsigned long long seq_no = 0;
+  bool fast_sync = true;
+  int64_t n_fast = 0, n_slow = 0;
   int* h_bad = nullptr;           // pinned, K
   EnsOp* h_ops = nullptr;         // pinned, 3 K (pre-accepts | pre-changes | the round's operations by kind)
   double* h_drift = nullptr;      // pinned, K x LU_MAX_SLOTS
@@ -146,6 +152,7 @@ struct EnsembleSolver {
     for (auto& m_ : ms) if (m_) (void)hipStreamDestroy(m_);
     for (auto& e : evs) if (e) (void)hipEventDestroy(e);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
+    if (h_seq) (void)hipHostFree(h_seq);
     if (h_bad) (void)hipHostFree(h_bad);
     if (h_ops) (void)hipHostFree(h_ops);
     if (h_drift) (void)hipHostFree(h_drift);
@@ -162,7 +169,13 @@ struct EnsembleSolver {
       if (h_bad) (void)hipHostFree(h_bad);
       if (h_ops) (void)hipHostFree(h_ops);
       if (h_drift) (void)hipHostFree(h_drift);
-      KIN_HIP(hipHostMalloc((void**)&h_ctrl, (size_t)K_ * sizeof(BdfCtrl), hipHostMallocDefault));
+      KIN_HIP(hipHostMalloc((void**)&h_ctrl, (size_t)K_ * sizeof(BdfCtrl), hipHostMallocCoherent | hipHostMallocMapped));
+      if (!h_seq) { KIN_HIP(hipHostMalloc((void**)&h_seq, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)); *h_seq = 0; }
+      fast_sync = !(getenv("KIN_ENSEMBLE_FAST_SYNC") && atoi(getenv("KIN_ENSEMBLE_FAST_SYNC")) == 0) && !getenv("KIN_NO_FAST_SYNC");
+      if (hipHostGetDevicePointer((void**)&h_ctrl_dev, h_ctrl, 0) != hipSuccess || hipHostGetDevicePointer((void**)&h_seq_dev, h_seq, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        fast_sync = false;
+      }
       KIN_HIP(hipHostMalloc((void**)&h_bad, (size_t)K_ * sizeof(int), hipHostMallocDefault));
       KIN_HIP(hipHostMalloc((void**)&h_ops, (size_t)3 * K_ * sizeof(EnsOp), hipHostMallocDefault));
       KIN_HIP(hipHostMalloc((void**)&h_drift, (size_t)K_ * LU_MAX_SLOTS * sizeof(double), hipHostMallocDefault));
@@ -205,6 +218,7 @@ struct EnsembleSolver {
     g_batches = g_matrices = 0;
     factor_sync = getenv("KIN_ENSEMBLE_FACTOR_SYNC") && atoi(getenv("KIN_ENSEMBLE_FACTOR_SYNC")) != 0;
     g_min = 4; g_wait_us = 200;
+    g_min = std::min(g_min, std::max(1, K / 4));       // a small ensemble does not hold a lone request back for partners that rarely come
     if (const char* e = getenv("KIN_ENSEMBLE_GJ_MIN")) g_min = std::max(1, atoi(e));
     if (const char* e = getenv("KIN_ENSEMBLE_GJ_WAIT_US")) g_wait_us = std::max(0, atoi(e));
     while ((int)ms.size() < pool) {
@@ -212,7 +226,7 @@ struct EnsembleSolver {
       ms.push_back(m_); mpinv.emplace_back(); mpinv.back().alloc(2 * 32 * 32); ms_lock.emplace_back(new std::mutex());
     }
     active = K; arrived = 0; epoch = 0; round_error.clear(); n_rounds = 0;
-    t_enqueue = t_sync = t_round = 0.0;
+    t_enqueue = t_sync = t_round = 0.0; n_fast = n_slow = 0;
     for (auto& x : n_ops) x = 0;
     KIN_HIP(hipStreamSynchronize(s));
   }
@@ -308,9 +322,26 @@ struct EnsembleSolver {
         }
       }
       if (any_drift) KIN_HIP(hipMemcpyAsync(h_drift, d_drift.p, (size_t)K * LU_MAX_SLOTS * sizeof(double), hipMemcpyDeviceToHost, s));
-      KIN_HIP(hipMemcpyAsync(h_ctrl, d_ctrl.p, (size_t)K * sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
-      tr1 = std::chrono::steady_clock::now();
-      KIN_HIP(hipStreamSynchronize(s));
+      // the round's hand-over: the control blocks published into pinned host memory by the round's last launch and a sequence
+      // number to spin on (the host-driven integrator's scheme; ~5 us instead of the ~25 us of a copy + stream synchronisation),
+      // unless other results come back by copy in this round (drift tests, factorisation flags) or the number does not arrive
+      bool waited = false;
+      if (fast_sync && !any_drift && fac.empty()) {
+        const unsigned long long want = ++seq_no;
+        ens_publish(d_ctrl.p, h_ctrl_dev, K, h_seq_dev, want, s);
+        tr1 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+          if (*(volatile unsigned long long*)h_seq >= want) { std::atomic_thread_fence(std::memory_order_acquire); waited = true; n_fast++; break; }
+          __builtin_ia32_pause();
+          if ((spins & 4095) == 4095 && std::chrono::duration<double>(std::chrono::steady_clock::now() - tr1).count() > 50e-3) { fast_sync = false; break; }
+        }
+      }
+      if (!waited) {
+        KIN_HIP(hipMemcpyAsync(h_ctrl, d_ctrl.p, (size_t)K * sizeof(BdfCtrl), hipMemcpyDeviceToHost, s));
+        tr1 = std::chrono::steady_clock::now();
+        KIN_HIP(hipStreamSynchronize(s));
+        n_slow++;
+      }
       t_sync += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr1).count();
       for (int t = 0; t < K; t++) {
         Pending& p = pend[t];
@@ -743,6 +774,7 @@ static void batched_ensemble_block(kin_network* h, const kin_params& p, int64_t 
   if (getenv("KIN_TIMING")) {
     fprintf(stderr, "[ensemble] %lld members, %lld rounds, wall %.4f s: inside rounds %.4f s (enqueue %.4f, waiting for the device %.4f), "
             "between rounds %.4f s\n", (long long)K, (long long)E.n_rounds, wall, E.t_round, E.t_enqueue, E.t_sync, wall - E.t_round);
+    fprintf(stderr, "[ensemble] round hand-overs: %lld through pinned memory, %lld by copy + stream synchronisation\n", (long long)E.n_fast, (long long)E.n_slow);
     fprintf(stderr, "[ensemble] dense inverses: %lld in %lld batched chains (%.2f per chain)\n", (long long)E.g_matrices, (long long)E.g_batches,
             E.g_batches ? (double)E.g_matrices / (double)E.g_batches : 0.0);
     fprintf(stderr, "[ensemble] operations: vec %lld, rates %lld, rhs %lld, jac %lld, norms %lld, init_D %lld, drift %lld, factor %lld, corrector %lld (+%lld continued)\n",

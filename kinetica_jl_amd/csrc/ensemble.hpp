@@ -56,5 +56,7 @@ struct EnsSolveTables {
 void ens_predict(const EnsSolveTables& T, const EnsRep* reps, const EnsOp* d_ops, int n, hipStream_t s);
 void ens_iterations(const EnsSolveTables& T, const EnsRep* reps, const EnsOp* d_ops, int n, int it0, int iters, hipStream_t s);
 int ens_reduce_doubles(int N);   // doubles of EnsRep::part
+// the members' control blocks into pinned host memory + a sequence number behind them (a round's hand-over without a stream sync)
+void ens_publish(const BdfCtrl* ctrl, BdfCtrl* host_ctrl_dev, int K, unsigned long long* host_seq_dev, unsigned long long seq, hipStream_t s);
 
 }  // namespace kin
