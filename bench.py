@@ -827,6 +827,17 @@ def main():
                                                  "factorisations_per_member": float(np.mean([q["n_factor"] for q in sts])),
                                                  "form": "lockstep rounds of batched launches, one host thread per member's controller, dense Schur inverses of "
                                                          "members that factorise together as one batched chain (DESIGN 3.5)"}
+            # ... few members of the same network: K kin_solve calls on K host threads, one solve-only copy of the handle each
+            for K8 in (4, 8):
+                U8 = np.zeros((K8, N)); U8[:, 0] = 1.0
+                T8 = 1000.0 + 10.0 * np.arange(K8)
+                h.solve_ensemble(kparams(2), U8, T=T8)
+                t1 = time.perf_counter()
+                _, ue, nsv, rcs, sts = h.solve_ensemble(kparams(2), U8, T=T8)
+                w = time.perf_counter() - t1
+                res[f"{N}_species_K{K8}_threads"] = {"wall_s": w, "solves_per_s": K8 / w, "members_ok": int((rcs == 0).sum()), "members": K8,
+                                                    "steps_per_member": float(np.mean([q["n_steps"] for q in sts])),
+                                                    "form": "K <= 12 members of a network beyond the resident kernel: K kin_solve calls on K host threads"}
             # ... and a mid-size network (beyond the resident kernel's LDS budget as well): 3 000 species, 64 members
             net3, Ea3, A3 = synthetic_crn(3000, 15000)
             h3 = capi.HipNetwork.from_flat(net3)

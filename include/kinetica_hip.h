@@ -219,9 +219,11 @@ int kin_solve(kin_network* h, const kin_params* params, const double* u0,
  * Every member is integrated by the same algorithm as kin_solve (csrc/resident_core.hpp is the controller of all paths):
  *   - a network that fits one compute unit's LDS (up to ~1 000 species): ONE launch, one workgroup owns one member from u0 to
  *     the end of the span; a member's result is bit-identical to a K = 1 call with its inputs;
- *   - larger networks: the members advance in lockstep rounds, every launch of a round carries all members that need that
- *     kind of work (csrc/ensemble.cpp); a member's result equals its solo kin_solve within the step-sequence tolerance
- *     (bit-identical on the builds tested, not guaranteed).
+ *   - larger networks, up to 12 members (KIN_ENSEMBLE_THREADS): K kin_solve calls on K host threads, each on a solve-only copy
+ *     of the handle (kept with the handle for later calls); bit-identical to kin_solve on the member's inputs;
+ *   - larger networks, more members: the members advance in lockstep rounds, every launch of a round carries all members
+ *     that need that kind of work (csrc/ensemble.cpp); a member's result equals its solo kin_solve within the step-sequence
+ *     tolerance.
  *   u0[K][N]; rate constants per member k[K][R], or temperatures T[K] (Arrhenius parameters of the handle), or neither
  *   (the handle's current rates for all); discrete rate updates (tstops / T_stops / k_table as in kin_solve) are shared
  *   by all members and exclude k / T. `params` needs a save grid (solve_chunks or save_interval).

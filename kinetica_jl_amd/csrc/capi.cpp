@@ -4,7 +4,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
+#include <mutex>
 #include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "handle.hpp"
 #include "lu.hpp"
@@ -341,6 +346,103 @@ int kin_solve(kin_network* h, const kin_params* params, const double* u0, const 
   KIN_CATCH(h)
 }
 
+namespace {
+
+// A solve-only copy of a handle: the compiled tables again on the device, own stream and work vectors; Solver, symbolic LU and LU
+// cache are built by its first solve and stay with it
+kin_network* clone_for_solves(kin_network* h) {
+  std::unique_ptr<kin_network> c(new kin_network());
+  c->host = h->host;
+  c->device = h->device; c->n_cu = h->n_cu;
+  KIN_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const NetworkHost& N = c->host;
+  hipStream_t s = c->stream;
+  c->x0.upload(N.x0, s); c->x1.upload(N.x1, s);
+  c->sp_ptr.upload(N.sp_ptr, s); c->sp_rxn.upload(N.sp_rxn, s); c->sp_coef.upload(N.sp_coef, s);
+  c->rhs_plan.upload(build_seg_plan(N.N, N.sp_ptr.data(), nullptr, N.sp_rxn.data(), nullptr, N.sp_coef.data(), false), s);
+  c->jac_plan.upload(build_seg_plan(N.nnz(), N.jc_ptr.data(), nullptr, N.jc_src.data(), nullptr, N.jc_coef.data(), false), s);
+  c->k.alloc(N.R); c->rate.alloc(N.R); c->dr.alloc(2 * N.R + 2);
+  c->u.alloc(N.N); c->du.alloc(N.N); c->jvals.alloc(N.nnz());
+  KIN_HIP(hipStreamSynchronize(s));
+  return c.release();
+}
+
+int replica_threads_max() {
+  static const int v = getenv("KIN_ENSEMBLE_THREADS") ? atoi(getenv("KIN_ENSEMBLE_THREADS")) : 12;
+  return v;
+}
+
+// A SMALL ensemble of a LARGE network: K independent kin_solve calls on K host threads, one solve-only copy of the handle each.
+// Every member is, bit for bit, what kin_solve gives for its inputs. A chain of ~14 small dependent launches per step keeps one
+// trajectory at 6.7 solves/s (first 2 chunks of the 10k-species network) and K of them at 11 / 17 / 17 / 16 for K = 2 / 4 / 8 / 12 - the
+// dispatch rate of the chip's queues; the lockstep rounds of ensemble.cpp only overtake that from K = 16 on.
+void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
+                      const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* n_rows,
+                      double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats) {
+  const int64_t N = h->host.N, R = h->host.R;
+  const int64_t cap = make_res_grid(p).cap;
+  if (n_rows) *n_rows = cap;
+  // EMPIRICAL (ROCm 7.2, MI355X; tools/replica_sequence.py): members whose streams are among the first ~4 streams of the
+  // process slow each other down when they run together - K = 4: 11.4 solves/s, with three or more streams created BEFORE theirs
+  // (and kept alive; destroyed ones do not count) 17.0; K = 8: 13.3 -> 16.7; K = 12: 13.9 -> 16.3. Which thread creates a
+  // stream makes no difference. bench.py's concurrent_replicas never saw it: torch's own streams play that role there. Four
+  // idle placeholder streams are therefore created once per process in front of the first replica's.
+  {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      const int n = getenv("KIN_REPLICA_PLACEHOLDER_STREAMS") ? atoi(getenv("KIN_REPLICA_PLACEHOLDER_STREAMS")) : 4;
+      for (int i = 0; i < n; i++) { hipStream_t d = nullptr; if (hipStreamCreateWithFlags(&d, hipStreamNonBlocking) != hipSuccess) (void)hipGetLastError(); }
+    });
+  }
+  while ((int64_t)h->replicas.size() < K) {
+    h->replicas.push_back(clone_for_solves(h));
+    h->replicas.back()->lu_budget_mb = (size_t)(200 * 1024) / (size_t)std::max<int64_t>(K, 6);   // K LU caches share ~200 GB of the 288
+  }
+  KIN_HIP(hipStreamSynchronize(h->stream));
+  std::vector<std::string> errs((size_t)K);
+  std::vector<std::thread> th;
+  for (int64_t t = 0; t < K; t++)
+    th.emplace_back([&, t] {
+      try {
+        kin_network* c = h->replicas[(size_t)t];
+        KIN_HIP(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        if (h->has_arrhenius) {
+          c->Ea.alloc(R); c->A.alloc(R);
+          KIN_HIP(hipMemcpyAsync(c->Ea.p, h->Ea.p, (size_t)R * sizeof(double), hipMemcpyDeviceToDevice, s));
+          KIN_HIP(hipMemcpyAsync(c->A.p, h->A.p, (size_t)R * sizeof(double), hipMemcpyDeviceToDevice, s));
+          c->has_arrhenius = true; c->has_kmax = h->has_kmax; c->k_max = h->k_max; c->t_mult = h->t_mult;
+        }
+        if (n_stops == 0) {
+          if (k) KIN_HIP(hipMemcpyAsync(c->k.p, k + t * R, (size_t)R * sizeof(double), hipMemcpyHostToDevice, s));
+          else if (T) launch_arrhenius(R, c->Ea.p, c->A.p, c->has_kmax, c->k_max, c->t_mult, T[t], c->k.p, s);
+          else KIN_HIP(hipMemcpyAsync(c->k.p, h->k.p, (size_t)R * sizeof(double), hipMemcpyDeviceToDevice, s));
+          c->has_rates = true; c->k_pending = false;
+        }
+        KIN_HIP(hipStreamSynchronize(s));
+        kin_stats st{};
+        const int rc = solve_entry(c, p, u0 + t * N, tstops, T_stops, k_table, n_stops, &st);
+        if (retcodes) retcodes[t] = rc;
+        if (stats) stats[t] = st;
+        const int64_t ns = std::min<int64_t>(c->n_saved, cap);
+        if (n_saved) n_saved[t] = ns;
+        if (out_u && ns > 0) c->d_sol_u.download(out_u + (size_t)t * cap * N, (size_t)ns * N, s);
+        if (out_t && t == 0) { for (int64_t i = 0; i < ns && i < (int64_t)c->sol_t.size(); i++) out_t[i] = c->sol_t[(size_t)i]; }
+        KIN_HIP(hipStreamSynchronize(s));
+      } catch (const std::exception& e) { errs[(size_t)t] = e.what(); }
+    });
+  for (auto& x : th) x.join();
+  for (auto& e : errs) if (!e.empty()) throw KinError(ERR_DEVICE, "ensemble member failed: " + e);
+  // the save times are the members' common grid: member 0's, or - if it stopped early - those of the member that got furthest
+  if (out_t && n_saved) {
+    int64_t best = 0;
+    for (int64_t t = 1; t < K; t++) if (n_saved[t] > n_saved[best]) best = t;
+    if (best != 0) { const auto& tt = h->replicas[(size_t)best]->sol_t; for (int64_t i = 0; i < n_saved[best] && i < (int64_t)tt.size(); i++) out_t[i] = tt[(size_t)i]; }
+  }
+}
+
+}  // namespace
+
 int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, const double* u0, const double* k, const double* T,
                        const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* n_rows,
                        double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats) {
@@ -360,6 +462,8 @@ int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, cons
     const bool force_batched = getenv("KIN_ENSEMBLE_BATCHED") && atoi(getenv("KIN_ENSEMBLE_BATCHED")) != 0;
     if (!force_batched && resident_fits(h))
       resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
+    else if (!force_batched && K <= replica_threads_max())      // few members of a large network: K kin_solve calls on K threads
+      replica_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
     else
       batched_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
   }

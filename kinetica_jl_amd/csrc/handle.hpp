@@ -70,6 +70,10 @@ struct kin_network {
   std::unique_ptr<kin::IntegratorState> integ;   // return_integrator=true stepping state
   std::unique_ptr<kin::ResidentSolver, kin::ResidentDeleter> resident;   // one-workgroup-per-trajectory integrator (resident.cpp)
   std::unique_ptr<kin::EnsembleSolver, kin::EnsembleDeleter> ensemble;   // lockstep ensemble of large networks (ensemble.cpp)
+  // solve-only copies of this handle (own stream, work vectors, Solver and LU cache; no sweep tables): a SMALL ensemble of a
+  // large network is K independent kin_solve calls on K host threads (capi.cpp: replica_ensemble)
+  std::vector<kin_network*> replicas;
+  size_t lu_budget_mb = 0;   // device memory of this handle's LU cache (0: KIN_LU_CACHE_MB, default 32768); set on replicas
   std::vector<double> sol_t, sol_u;
   kin::DevBuf<double> d_sol_u;   // saved states on the device, [n_saved][N]
   int64_t n_saved = 0;

@@ -128,6 +128,7 @@ struct Solver {
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
+      if (h->lu_budget_mb > 0) budget_mb = std::min(budget_mb, h->lu_budget_mb);   // a replica's share (capi.cpp: replica_ensemble)
       const size_t fit = std::max<size_t>(1, budget_mb * 1024 * 1024 / std::max<size_t>(1, lu.slot_bytes()));
       lu_slots = (int)std::min<size_t>(std::min<size_t>((size_t)want, fit), (size_t)LU_MAX_SLOTS);
       d_jdiag.upload(H.j_diag, s);
@@ -1499,6 +1500,8 @@ void newton_solve(kin_network* h, double c, const double* u, const double* b, do
 
 kin_network::kin_network() {}
 kin_network::~kin_network() {
+  for (kin_network* r : replicas) delete r;
+  replicas.clear();
   integ.reset();
   solver.reset();
   if (stream) (void)hipStreamDestroy(stream);

@@ -249,11 +249,42 @@ def test_mid_size_network_through_the_ensemble_entry_point():
     h.close()
 
 
+def test_few_members_of_a_large_network_are_kin_solve_calls_on_threads():
+    """kin_solve_ensemble beyond the resident kernel's size with K <= KIN_ENSEMBLE_THREADS (12): K solve-only copies of the
+    handle, one host thread each - every member bit-identical to kin_solve on its inputs, statistics included; per-member rate
+    constants, temperatures, shared rate updates; a failing member does not disturb the others."""
+    net, Ea, A = synthetic_crn(2000, 10000)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    u0 = np.zeros(2000); u0[0] = 1.0
+    T = np.array([950.0, 1050.0, 1150.0])
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(2e-3), np.tile(u0, (3, 1)), T=T)
+    assert (rcs == 0).all() and (ns == 3).all() and sts[0]["lu_slots"] > 64          # the host-driven integrator's cache
+    for i in range(3):
+        h.rates_at(float(T[i]))
+        ts, us, rc, st, _ = h.solve(kp(2e-3), u0)
+        assert rc == 0 and np.array_equal(ts, t) and np.array_equal(us, u[i])
+        assert st["n_steps"] == sts[i]["n_steps"] and st["n_factor"] == sts[i]["n_factor"]
+    ks = np.array([h.rates_at(float(Ti)) for Ti in T])
+    t2, u2, _, rcs2, _ = h.solve_ensemble(kp(2e-3), np.tile(u0, (3, 1)), k=ks)
+    assert (rcs2 == 0).all() and np.array_equal(u2, u)
+    tst = np.arange(4) * 0.5e-3
+    Ts = np.array([900.0, 1000.0, 1100.0, 1200.0])
+    t3, u3, _, rcs3, sts3 = h.solve_ensemble(kp(2e-3, save=5e-4), np.tile(u0, (2, 1)), tstops=tst, T_stops=Ts)
+    ts, us, rc, st, _ = h.solve(kp(2e-3, save=5e-4), u0, tstops=tst, T_stops=Ts)
+    assert (rcs3 == 0).all() and rc == 0 and np.array_equal(ts, t3) and np.array_equal(us, u3[0]) and np.array_equal(u3[0], u3[1])
+    kbad = ks.copy(); kbad[1] *= 1e40
+    t4, u4, ns4, rcs4, _ = h.solve_ensemble(kp(2e-3, maxiters=3000), np.tile(u0, (3, 1)), k=kbad)
+    assert rcs4[1] != 0 and rcs4[0] == 0 and rcs4[2] == 0 and np.array_equal(u4[0], u[0]) and np.array_equal(u4[2], u[2])
+    h.close()
+
+
 def test_lockstep_ensemble_of_a_large_network(monkeypatch):
     """kin_solve_ensemble beyond the resident kernel's size (ensemble.cpp): members advance in lockstep rounds of batched
     launches, each with the controller the resident kernel runs. At C3 size against solo kin_solve runs of the same inputs
     (the host-driven integrator: same kernels' arithmetic, an independent controller implementation), and - forced at 1 000
     species - against the resident kernel's ensemble of the same members."""
+    monkeypatch.setenv("KIN_ENSEMBLE_BATCHED", "1")       # (three members would otherwise be three kin_solve calls on threads)
     net, Ea, A = synthetic_crn(10000, 50000)
     h = capi.HipNetwork.from_flat(net)
     h.set_arrhenius(Ea, A, k_max=1e12)
@@ -280,12 +311,13 @@ def test_lockstep_ensemble_of_a_large_network(monkeypatch):
     assert (rcs2 == 0).all() and rc == 0 and np.array_equal(ts, t2) and sts2[0]["n_restarts"] == 4
     assert units(u2[0], us) < 50 and np.array_equal(u2[0], u2[1])
     h.close()
+    monkeypatch.delenv("KIN_ENSEMBLE_BATCHED")
     net, Ea, A = synthetic_crn(1000, 5000)
     h = capi.HipNetwork.from_flat(net)
     h.set_arrhenius(Ea, A, k_max=1e12)
     u0 = np.zeros(1000); u0[0] = 1.0
     T = np.array([950.0, 1050.0, 1150.0, 1250.0])
-    tr, ur, _, rcr, _ = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
+    tr, ur, _, rcr, _ = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)          # fits the resident kernel: one launch
     monkeypatch.setenv("KIN_ENSEMBLE_BATCHED", "1")
     tb, ub, _, rcb, stb = h.solve_ensemble(kp(2e-3), np.tile(u0, (4, 1)), T=T)
     assert (rcr == 0).all() and (rcb == 0).all() and np.array_equal(tr, tb)

@@ -130,7 +130,7 @@ def build():
     for key, e in en.items():
         if not isinstance(e, dict) or "solves_per_s" not in e:
             continue
-        group = "ensemble, lockstep" if "lockstep" in key else "ensemble, one launch"
+        group = "ensemble, lockstep" if "lockstep" in key else ("ensemble, threads" if "threads" in key else "ensemble, one launch")
         add(group, key.replace("_", " "), f"{e['solves_per_s']:.0f} solves/s ({e['wall_s']:.3f} s, {e['members_ok']} of {e['members']} ok" + (f", steps mean {e['steps_per_member']:.0f} / slowest {e['steps_of_the_slowest_member']}" if 'steps_of_the_slowest_member' in e else "") + ")", f"{src_b} `ensemble_one_launch.{key}`")
     for k_, e in sorted(sn["concurrent_replicas"].items()):
         if isinstance(e, dict) and "solves_per_s" in e:

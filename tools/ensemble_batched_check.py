@@ -7,6 +7,8 @@ import numpy as np
 from kinetica_jl_amd import capi
 from kinetica_jl_amd.synth import synthetic_crn
 
+if not os.environ.get("ENS_DEFAULT_ROUTE"):        # this tool measures the lockstep rounds; K <= 12 would otherwise be K kin_solve calls on threads
+    os.environ.setdefault("KIN_ENSEMBLE_BATCHED", "1")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 Ks = [int(a) for a in sys.argv[2:]] or [4, 16]
 net, Ea, A = synthetic_crn(N, 5 * N)
