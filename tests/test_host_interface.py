@@ -122,6 +122,17 @@ def test_solver_sentinels_carry_dtmin():
     assert p.to_kin_params().dtmin == 1e-30
 
 
+def test_warm_chunk_starts_travel_as_solve_chunks_2():
+    """`HIPBDF(warm_chunks=True)` (extension): chunkwise solve without re-initialisation at chunk starts whose rates did not
+    change = kin_params.solve_chunks 2; plain chunkwise 1, complete timespan 0 whatever the option says."""
+    base = dict(tspan=(0.0, 1.0), u0={"A": 1.0}, solve_chunkstep=0.5)
+    assert S.ODESimulationParams(solver=S.HIPBDF(), **base).to_kin_params().solve_chunks == 1
+    assert S.ODESimulationParams(solver=S.HIPBDF(warm_chunks=True), **base).to_kin_params().solve_chunks == 2
+    assert S.ODESimulationParams(solver=S.HIPBDF(warm_chunks=True), solve_chunks=False, **base).to_kin_params().solve_chunks == 0
+    assert S.ODESimulationParams(solver=None, **base).to_kin_params().solve_chunks == 1
+    assert S.ODESimulationParams(solver=S.HIPRK45(), **base).to_kin_params().solve_chunks == 1
+
+
 def test_discrete_stop_temperatures_is_the_interpolation_half_of_calculate_discrete_rates():
     cs = C.ConditionSet({"T": C.LinearGradientProfile(rate=50.0, X_start=500.0, X_end=510.0)}, ts_update=0.05)
     pars = S.ODESimulationParams(tspan=(0.0, 0.2), u0={"A": 1.0}, solve_chunkstep=0.1)
