@@ -68,6 +68,16 @@ struct ResidentSolver {
     for (int r = 0; r <= lu.nrounds; r++) hn.round_e0[r] = lu.ent_ptr[lu.round_ptr[r]];
     hn.rhs_plan = h->rhs_plan.view(); hn.jac_plan = h->jac_plan.view(); hn.resid_plan = resid_plan.view();
     hn.lz_build = lu.lz_build.view(); hn.nvu_build = lu.nvu_build.view(); hn.stageA = lu.stageA.view(); hn.stageC = lu.stageC.view();
+    // LDS for the task descriptors of the corrector's three gather plans, where it is to be had: not beyond the kernel's budget,
+    // and not at the price of the second workgroup per compute unit an ensemble would get without them
+    {
+      const size_t desc = resident_desc_bytes(hn.resid_plan, hn.stageA, hn.stageC);
+      const size_t static_lds = resident_static_lds();
+      const bool two_before = 2 * (dyn_lds + static_lds) <= (size_t)160 * 1024, two_after = 2 * (dyn_lds + desc + static_lds) <= (size_t)160 * 1024;
+      const bool off = getenv("KIN_RESIDENT_LDS_DESC") && atoi(getenv("KIN_RESIDENT_LDS_DESC")) == 0;
+      hn.desc_in_lds = (!off && lu.fused_tri && dyn_lds + desc <= RES_LDS_BUDGET && (two_after || !two_before)) ? 1 : 0;
+      if (hn.desc_in_lds) dyn_lds += desc;
+    }
     hn.fwdZ = lu.fwdZ.view(); hn.fwd_dense = lu.fwd_dense.view(); hn.bwdT = lu.bwdT.view(); hn.bwdV = lu.bwdV.view();
     for (int r = 0; r < lu.nrounds; r++) { hn.schur[r] = lu.schur[r].view(); hn.fwd[r] = lu.fwd[r].view(); hn.bwd[r] = lu.bwd[r].view(); }
     // the multi-workgroup factorisation's slot (SparseLU::analyze allocates one) is not used by this path

@@ -82,6 +82,14 @@ __device__ __forceinline__ SegPlanViewG plan_g(const SegPlanView& p, int n64 = -
   return g;
 }
 struct SegExtraG { const double* psi = nullptr; const double* d = nullptr; double cscal = 0.0; };   // (LDS vectors)
+// ... and one whose TASK DESCRIPTORS (row ranges, destinations, aux positions: a few hundred integers per plan) sit in LDS: the
+// first of a task's two dependent round trips to L2 becomes an LDS read (the three plans of every corrector iteration)
+struct SegPlanViewL {
+  const int32_t *grp_off, *grp_dst, *grp_aux; gci_t *ell_a, *ell_b; gcf_t* ell_c;
+  const int32_t *seg_beg, *seg_end, *seg_dst, *seg_aux, *blk_beg, *blk_end, *blk_dst, *blk_aux; gci_t *long_a, *long_b; gcf_t* long_c;
+  int32_t G, S, B, val_base, ell_total;
+  int32_t n64, n32;
+};
 
 // hot gather plans kept in LDS (the per-round plans of the factorisation stay in global memory)
 enum : int { PL_RHS = 0, PL_JAC, PL_RESID, PL_LZ, PL_NVU, PL_STAGEA, PL_STAGEC, PL_FWDZ, PL_FWD_DENSE, PL_BWDT, PL_BWDV, PL_COUNT };
@@ -94,6 +102,7 @@ struct ResCtx {
   int32_t split[PL_COUNT][2];   // n64, n32 of the hot plans (counted once by the kernel's prologue)
   int32_t profile;
   int32_t l_y, l_d, l_psi, l_scale, l_win, l_rate;   // offsets (doubles) of the LDS-resident vectors in g_dyn
+  int32_t desc_on, desc_off[3];                      // task descriptors of PL_RESID / PL_STAGEA / PL_STAGEC in g_dyn (offsets in int32)
   int64_t off_vec_end;
   int32_t N, R, nnzJ, ns, m, m16, mpad, nrounds, n_mono_ent, solve_mode, has_kmax, n_slots, rate_mode;
   int64_t off_diag, off_U, off_L, off_S, off_y, off_x, off_dinv, w_size;
@@ -204,8 +213,8 @@ __device__ __forceinline__ void wg_reduce(double (&v)[NV]) {
 // workgroup-wide reduction inside a phase), then medium rows, then the ELL groups of short rows.
 // one group of LANES lanes per medium row (4 entries per lane), 64 / LANES rows per wavefront task
 // srcA / srcB: arrays of the first / second factor (segsum_dev.hpp: seg_gather2), auxp: array of the `aux` operand
-template <int OP, int LANES, class SA, class SB, class OP_, class AP>
-__device__ __forceinline__ void seg_rows_grouped(const SegPlanViewG& p, SA srcA, SB srcB, OP_ out, AP auxp, const SegExtraG& ex, bool impl, int row0, int row_end) {
+template <int OP, int LANES, class V, class SA, class SB, class OP_, class AP>
+__device__ __forceinline__ void seg_rows_grouped(const V& p, SA srcA, SB srcB, OP_ out, AP auxp, const SegExtraG& ex, bool impl, int row0, int row_end) {
   const int lane = threadIdx.x & 63;
   const int g = lane / LANES, l = lane % LANES;
   const int sidx = row0 + g;
@@ -218,8 +227,8 @@ __device__ __forceinline__ void seg_rows_grouped(const SegPlanViewG& p, SA srcA,
   if (l == LANES - 1 && dst >= 0) seg_store<OP>(out, dst, acc, pre, ex);
 }
 
-template <int OP, class SA, class SB, class OP_, class AP>
-__device__ __forceinline__ void seg_run(const SegPlanViewG& p, SA srcA, SB srcB, OP_ out, AP auxp, const SegExtraG& ex) {
+template <int OP, class V, class SA, class SB, class OP_, class AP>
+__device__ __forceinline__ void seg_run(const V& p, SA srcA, SB srcB, OP_ out, AP auxp, const SegExtraG& ex) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool impl = p.val_base >= 0;
   // task list: long rows, medium rows > 64 entries (a wavefront each), 33 .. 64 (four per wavefront), 9 .. 32 (eight per
@@ -254,10 +263,33 @@ __device__ __forceinline__ void seg_run(const SegPlanViewG& p, SA srcA, SB srcB,
   }
 }
 // everything in one array (the factorisation's updates, the right-hand side, the Jacobian)
-template <int OP, class SP, class OP_>
-__device__ __forceinline__ void seg_run1(const SegPlanViewG& p, SP src, OP_ out, const SegExtraG& ex) { seg_run<OP>(p, src, src, out, src, ex); }
+template <int OP, class V, class SP, class OP_>
+__device__ __forceinline__ void seg_run1(const V& p, SP src, OP_ out, const SegExtraG& ex) { seg_run<OP>(p, src, src, out, src, ex); }
 
 __device__ __forceinline__ SegPlanViewG hot_plan(int id) { return plan_g(g_cx.plan[id], g_cx.split[id][0], g_cx.split[id][1]); }
+// the LDS-descriptor view of hot plan `id` (slot 0 / 1 / 2 = PL_RESID / PL_STAGEA / PL_STAGEC); layout of a slot, in int32:
+// grp_off [G + 1] | grp_dst [64 G] | grp_aux [64 G] | seg_beg, seg_end, seg_dst, seg_aux [S each] | blk_beg, blk_end, blk_dst, blk_aux [B each]
+__device__ __forceinline__ int desc_ints(const SegPlanView& p) { return (p.G + 1) + 128 * p.G + 4 * p.S + 4 * p.B; }
+__device__ __forceinline__ SegPlanViewL lds_plan(int slot, int id) {
+  const SegPlanViewG g = hot_plan(id);
+  SegPlanViewL l;
+  const int32_t* b = reinterpret_cast<const int32_t*>(g_dyn) + uni(g_cx.desc_off[slot]);
+  l.grp_off = b; b += g.G + 1; l.grp_dst = b; b += 64 * g.G; l.grp_aux = b; b += 64 * g.G;
+  l.seg_beg = b; b += g.S; l.seg_end = b; b += g.S; l.seg_dst = b; b += g.S; l.seg_aux = b; b += g.S;
+  l.blk_beg = b; b += g.B; l.blk_end = b; b += g.B; l.blk_dst = b; b += g.B; l.blk_aux = b;
+  l.ell_a = g.ell_a; l.ell_b = g.ell_b; l.ell_c = g.ell_c; l.long_a = g.long_a; l.long_b = g.long_b; l.long_c = g.long_c;
+  l.G = g.G; l.S = g.S; l.B = g.B; l.val_base = g.val_base; l.ell_total = g.ell_total; l.n64 = g.n64; l.n32 = g.n32;
+  return l;
+}
+// all threads: copies the descriptors of hot plan `id` into its LDS slot
+__device__ __forceinline__ void stage_descriptors(int slot, int id) {
+  const SegPlanViewG g = hot_plan(id);
+  int32_t* b = reinterpret_cast<int32_t*>(g_dyn) + uni(g_cx.desc_off[slot]);
+  auto put = [&](gci_t* src, int n) { for (int i = threadIdx.x; i < n; i += RES_WG) b[i] = src[i]; b += n; };
+  put(g.grp_off, g.G + 1); put(g.grp_dst, 64 * g.G); put(g.grp_aux, 64 * g.G);
+  put(g.seg_beg, g.S); put(g.seg_end, g.S); put(g.seg_dst, g.S); put(g.seg_aux, g.S);
+  put(g.blk_beg, g.B); put(g.blk_end, g.B); put(g.blk_dst, g.B); put(g.blk_aux, g.B);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // phases (each called by all 512 threads; every one ends behind a barrier). y, d, psi, scale, the rates and the solve
@@ -669,9 +701,14 @@ RES_PHASE void solve_fused(gcd_t* Wc) {
   const double* winc = win;
   const int m = uni(g_cx.m), mpad = uni(g_cx.mpad), ns = uni(g_cx.ns);
   const long long off_y = uni((long long)g_cx.off_y), off_x = uni((long long)g_cx.off_x);
-  { RES_PROF(PF_STAGEA); seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_STAGEA), Wc, winc, win, winc, ex); __syncthreads(); }
+  const bool ld = uni(g_cx.desc_on) != 0;
+  { RES_PROF(PF_STAGEA);
+    if (ld) seg_run<SEG_PROD_AUXSUB>(lds_plan(1, PL_STAGEA), Wc, winc, win, winc, ex); else seg_run<SEG_PROD_AUXSUB>(hot_plan(PL_STAGEA), Wc, winc, win, winc, ex);
+    __syncthreads(); }
   { RES_PROF(PF_GEMV); gemv_wg(Wc + uni((long long)g_cx.off_S), mpad, m, winc + off_y + ns, win + off_x); }
-  { RES_PROF(PF_STAGEC); seg_run<SEG_PROD_SET>(hot_plan(PL_STAGEC), Wc, winc, win, winc, ex); __syncthreads(); }
+  { RES_PROF(PF_STAGEC);
+    if (ld) seg_run<SEG_PROD_SET>(lds_plan(2, PL_STAGEC), Wc, winc, win, winc, ex); else seg_run<SEG_PROD_SET>(hot_plan(PL_STAGEC), Wc, winc, win, winc, ex);
+    __syncthreads(); }
 }
 RES_PHASE void solve_explicit(gcd_t* Wc) {
   const SegExtraG ex{};
@@ -721,7 +758,8 @@ __device__ __forceinline__ ResSums newton_body(int slot, double c, double upd, i
     SegExtraG ex;
     ex.psi = L_psi(); ex.d = d; ex.cscal = c;
     const double* rate = L_rate();
-    seg_run<SEG_COEF_BDF>(hot_plan(PL_RESID), rate, rate, win, rate, ex);
+    if (uni(g_cx.desc_on) != 0) seg_run<SEG_COEF_BDF>(lds_plan(0, PL_RESID), rate, rate, win, rate, ex);
+    else seg_run<SEG_COEF_BDF>(hot_plan(PL_RESID), rate, rate, win, rate, ex);
     __syncthreads();
   }
   { RES_PROF(PF_SOLVE); solve_wg(Wc); }
@@ -961,11 +999,20 @@ __global__ __launch_bounds__(RES_WG) __attribute__((amdgpu_waves_per_eu(RES_WAVE
     g_cx.off_vec_end = n.off_vec_end;
     const int win = (int)(n.off_vec_end - n.off_y);
     g_cx.l_y = 0; g_cx.l_d = n.N; g_cx.l_psi = 2 * n.N; g_cx.l_scale = 3 * n.N; g_cx.l_win = 4 * n.N; g_cx.l_rate = 4 * n.N + win;
+    // task descriptors of the corrector's three plans behind the vectors (the host provisioned the LDS for them or did not)
+    g_cx.desc_on = n.desc_in_lds;
+    const int m16_ = (n.m + 15) / 16 * 16;
+    const int tail = n.R > 16 * (m16_ + 1) ? n.R : 16 * (m16_ + 1);
+    int off = 2 * (4 * n.N + win + tail);       // in int32
+    g_cx.desc_off[0] = off; off += desc_ints(n.resid_plan);
+    g_cx.desc_off[1] = off; off += desc_ints(n.stageA);
+    g_cx.desc_off[2] = off;
   }
   if (threadIdx.x < 20) g_sh.prof[threadIdx.x] = 0;
   __syncthreads();
   for (int id = 0; id < PL_COUNT; id++) count_splits(id);
   __syncthreads();
+  if (g_cx.desc_on) { stage_descriptors(0, PL_RESID); stage_descriptors(1, PL_STAGEA); stage_descriptors(2, PL_STAGEC); __syncthreads(); }
   if (threadIdx.x >= 64) { worker_loop(); return; }
   // the leader wavefront: controller state and parameters live in LDS (one wavefront in lockstep: no hazards), not in
   // registers that would be spilled around every phase call
@@ -987,6 +1034,10 @@ __global__ __launch_bounds__(RES_WG) __attribute__((amdgpu_waves_per_eu(RES_WAVE
 size_t resident_dyn_lds(int N, int R, int m, int64_t window) {
   const int m16 = (m + 15) / 16 * 16;
   return ((size_t)4 * N + (size_t)window + (size_t)std::max(R, 16 * (m16 + 1))) * sizeof(double);
+}
+size_t resident_desc_bytes(const SegPlanView& resid, const SegPlanView& stageA, const SegPlanView& stageC) {
+  auto ints = [](const SegPlanView& p) { return (size_t)(p.G + 1) + 128 * (size_t)p.G + 4 * (size_t)p.S + 4 * (size_t)p.B; };
+  return (ints(resid) + ints(stageA) + ints(stageC) + 2) / 2 * 2 * sizeof(int32_t);
 }
 size_t resident_static_lds() {
   hipFuncAttributes a{};

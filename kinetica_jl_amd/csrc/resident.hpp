@@ -15,6 +15,7 @@ enum : int { RES_SOLVE_FUSED = 0, RES_SOLVE_EXPLICIT = 1, RES_SOLVE_PLAIN = 2 };
 // immutable per network: reaction tables, gather plans, symbolic LU (device pointers)
 struct ResNetDev {
   int32_t N, R, nnzJ, ns, m, mpad, nrounds, n_mono_ent, solve_mode, has_kmax;
+  int32_t desc_in_lds, pad0_;      // the launch provisions LDS for the task descriptors of resid_plan / stageA / stageC
   int64_t off_diag, off_U, off_L, off_S, off_y, off_x, off_dinv, off_vec_end, w_size;
   double k_max, t_mult;
   const int32_t *x0, *x1, *jmap, *ent_pivot, *yloc, *xloc, *j_diag;
@@ -43,6 +44,7 @@ struct ResTrajDev {
 constexpr int RES_MAX_DENSE = 512;
 // dynamic LDS of the kernel: y, d, psi, scale (4 N), the solve-vector window of W, max(R, row panel of the dense inverse)
 size_t resident_dyn_lds(int N, int R, int m, int64_t window);
+size_t resident_desc_bytes(const SegPlanView& resid, const SegPlanView& stageA, const SegPlanView& stageC);   // ... + these, when they fit
 constexpr size_t RES_LDS_BUDGET = 160 * 1024 - 14 * 1024;   // what is left of a CU's LDS next to the kernel's static blocks
 void launch_resident(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
 // the same kernel built with half the registers per lane: two workgroups share a compute unit (resident_w4.hip)
