@@ -177,7 +177,7 @@ template <int LANES>
 __device__ __forceinline__ double dpp_sum(double v) {
   v += dpp_mov<0x111>(v);                    // row_shr:1
   v += dpp_mov<0x112>(v);                    // row_shr:2
-  v += dpp_mov<0x114>(v);                    // row_shr:4
+  if (LANES >= 8) v += dpp_mov<0x114>(v);    // row_shr:4
   if (LANES >= 16) v += dpp_mov<0x118>(v);   // row_shr:8
   if (LANES >= 64) { v += dpp_mov<0x142>(v); v += dpp_mov<0x143>(v); }   // row_bcast:15, row_bcast:31
   return v;
@@ -669,28 +669,39 @@ RES_PHASE bool ph_factor(int slot, double c, bool keep_diag) {
   return bad;
 }
 
-// x = S^-1 y2; y2 and x in the LDS window. A group of 16 lanes takes a row (64 rows per pass of the workgroup, a row's
-// loads all in flight): one wavefront per row (solver_kernels.hip: gemv_kernel) is seven dependent rounds at m = 108
-__device__ __forceinline__ void gemv_wg(gcd_t* S, int ld, int m, const double* y2, double* x) {
-  const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;   // RES_WG / 16 groups
-  for (int row0 = 0; row0 < m; row0 += RES_WG / 16) {
+// x = S^-1 y2; y2 and x in the LDS window. A group of LANES lanes takes a row with all of the row's loads in flight; LANES is
+// chosen so that the workgroup covers the rows in as few passes as possible (m <= 128: 4 lanes per row, one pass - with 16 lanes
+// per row m = 108 took four passes of seven loads per lane: 2.7 us per solve against 1.x now; one wavefront per row, as
+// solver_kernels.hip's gemv_kernel has it, is seven dependent rounds)
+template <int LANES>
+__device__ __forceinline__ void gemv_rows(gcd_t* S, int ld, int m, const double* y2, double* x) {
+  const int l = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+  for (int row0 = 0; row0 < m; row0 += RES_WG / LANES) {
     const int row = row0 + grp;
     double acc = 0.0;
     if (row < m) {
       gcd_t* a = S + (size_t)row * ld;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       int j = l;
-      for (; j + 48 < m; j += 64) {
-        const double p0 = a[j], p1 = a[j + 16], p2 = a[j + 32], p3 = a[j + 48];
-        a0 += p0 * y2[j]; a1 += p1 * y2[j + 16]; a2 += p2 * y2[j + 32]; a3 += p3 * y2[j + 48];
+      for (; j + 3 * LANES < m; j += 4 * LANES) {
+        const double p0 = a[j], p1 = a[j + LANES], p2 = a[j + 2 * LANES], p3 = a[j + 3 * LANES];
+        a0 += p0 * y2[j]; a1 += p1 * y2[j + LANES]; a2 += p2 * y2[j + 2 * LANES]; a3 += p3 * y2[j + 3 * LANES];
       }
-      for (; j < m; j += 16) a0 += a[j] * y2[j];
-      acc = (a0 + a1) + (a2 + a3);
+      double q0 = 0.0, q1 = 0.0, q2 = 0.0;       // up to three more columns, their loads issued together
+      if (j < m) q0 = a[j] * y2[j];
+      if (j + LANES < m) q1 = a[j + LANES] * y2[j + LANES];
+      if (j + 2 * LANES < m) q2 = a[j + 2 * LANES] * y2[j + 2 * LANES];
+      acc = ((a0 + a1) + (a2 + a3)) + ((q0 + q1) + q2);
     }
-    acc = dpp_sum<16>(acc);
-    if (l == 15 && row < m) x[row] = acc;
+    acc = dpp_sum<LANES>(acc);
+    if (l == LANES - 1 && row < m) x[row] = acc;
   }
   __syncthreads();
+}
+__device__ __forceinline__ void gemv_wg(gcd_t* S, int ld, int m, const double* y2, double* x) {
+  if (m <= RES_WG / 4) gemv_rows<4>(S, ld, m, y2, x);
+  else if (m <= RES_WG / 8 * 2) gemv_rows<8>(S, ld, m, y2, x);
+  else gemv_rows<16>(S, ld, m, y2, x);
 }
 
 // M x = b with the factors in W (global) and the vectors in the LDS window: b at win[yloc], x at win[xloc] (SparseLU::solve).
