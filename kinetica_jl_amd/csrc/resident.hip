@@ -115,7 +115,7 @@ struct ResShared {
   double coef[8], gamma[8];
   double drift[RES_MAX_SLOTS], slot_c[RES_MAX_SLOTS];
   int slot_valid[RES_MAX_SLOTS];
-  double pinv[16][17];
+  double pinv[2][16][17];   // pivot-block inverses of the dense Gauss-Jordan: current / next (look-ahead)
   long long prof[20];
   int bad;
   // command of the leader wavefront to the seven others (see resident_bdf_kernel)
@@ -532,26 +532,50 @@ __device__ __forceinline__ void gj_blocked(gd_t* S, gd_t* S2, int ld, int m16) {
   double* rp = L_rate();   // (no rates are live during a factorisation)
   gd_t* X = S;
   gd_t* Y = S2;
-  for (int kb = 0; kb < nb; kb++) {
-    const int K0 = kb * 16;
+  // Look-ahead: the LAST wavefront does not take row strips; during the update of step kb it forms the next pivot block
+  // Y[K+1, K+1] itself and inverts it - the 16 dependent pivots of gj_inv16_wave (2.7 us on one wavefront) then run next to the
+  // other wavefronts' tile updates instead of in front of them. Used when giving that wavefront up does not lengthen the update
+  // (the strips spread over 7 wavefronts in as many rounds as over 8). The pivot block it inverts is, bit for bit, the tile its
+  // owner writes to Y.
+  const int nw = ((nb + RES_WAVES - 2) / (RES_WAVES - 1) == (nb + RES_WAVES - 1) / RES_WAVES) ? RES_WAVES - 1 : RES_WAVES;
+  const bool look = nw < RES_WAVES;
+  auto invert_into = [&](double (*P)[17], double (&a)[4]) {       // one wavefront; a = the block in (row lane >> 2, 4 columns) layout
+    const int r = lane >> 2, c0 = (lane & 3) * 4;
+    const bool vanished = gj_inv16_wave(a, lane);
+#pragma unroll
+    for (int x = 0; x < 4; x++) P[r][c0 + x] = a[x];
+    if (vanished) g_sh.bad = 1;
+  };
+  if (look) {
     if (wave == 0) {
       const int r = lane >> 2, c0 = (lane & 3) * 4;
       double a[4];
 #pragma unroll
-      for (int x = 0; x < 4; x++) a[x] = X[(size_t)(K0 + r) * ld + K0 + c0 + x];
-      const bool vanished = gj_inv16_wave(a, lane);
-#pragma unroll
-      for (int x = 0; x < 4; x++) g_sh.pinv[r][c0 + x] = a[x];
-      if (vanished) g_sh.bad = 1;
+      for (int x = 0; x < 4; x++) a[x] = X[(size_t)r * ld + c0 + x];
+      invert_into(g_sh.pinv[0], a);
     }
     __syncthreads();
-    // row panel: wavefront w forms the 16 x 16 tiles J = w, w + 16, ...
+  }
+  for (int kb = 0; kb < nb; kb++) {
+    const int K0 = kb * 16;
+    double (*P)[17] = g_sh.pinv[look ? (kb & 1) : 0];
+    if (!look) {
+      if (wave == 0) {
+        const int r = lane >> 2, c0 = (lane & 3) * 4;
+        double a[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) a[x] = X[(size_t)(K0 + r) * ld + K0 + c0 + x];
+        invert_into(P, a);
+      }
+      __syncthreads();
+    }
+    // row panel: wavefront w forms the 16 x 16 tiles J = w, w + 8, ...
     for (int J = wave; J < nb; J += RES_WAVES) {
       res_d4 acc = {0.0, 0.0, 0.0, 0.0};
       if (J != kb) {
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-          const double ap = g_sh.pinv[li][4 * ks + lk];
+          const double ap = P[li][4 * ks + lk];
           const double bx = X[(size_t)(K0 + 4 * ks + lk) * ld + J * 16 + li];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bx, acc, 0, 0, 0);
         }
@@ -559,30 +583,55 @@ __device__ __forceinline__ void gj_blocked(gd_t* S, gd_t* S2, int ld, int m16) {
 #pragma unroll
       for (int v = 0; v < 4; v++) {
         const int i = 4 * v + lk;
-        rp[i * ldr + J * 16 + li] = (J == kb) ? g_sh.pinv[i][li] : acc[v];
+        rp[i * ldr + J * 16 + li] = (J == kb) ? P[i][li] : acc[v];
       }
     }
     __syncthreads();
-    // update: wavefront w takes the row strips I = w, w + 16, ...; its column-panel tile X[I,K] is loaded once per strip
-    for (int I = wave; I < nb; I += RES_WAVES) {
-      if (I == kb) {
-        for (int J = 0; J < nb; J++)
+    if (look && wave == RES_WAVES - 1) {
+      // the next pivot block after this step, formed like any tile of strip kb + 1, then inverted
+      const int I = kb + 1;
+      if (I < nb) {
+        double (*Pn)[17] = g_sh.pinv[I & 1];
+        double a[4], xo[4];
 #pragma unroll
-          for (int v = 0; v < 4; v++) Y[(size_t)(K0 + 4 * v + lk) * ld + J * 16 + li] = rp[(4 * v + lk) * ldr + J * 16 + li];
-        continue;
-      }
-      double a[4];
+        for (int ks = 0; ks < 4; ks++) a[ks] = X[(size_t)(I * 16 + li) * ld + K0 + 4 * ks + lk];
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) a[ks] = X[(size_t)(I * 16 + li) * ld + K0 + 4 * ks + lk];
-      for (int J = 0; J < nb; J++) {
-        double xo[4];
-#pragma unroll
-        for (int v = 0; v < 4; v++) xo[v] = (J == kb) ? 0.0 : X[(size_t)(I * 16 + 4 * v + lk) * ld + J * 16 + li];
+        for (int v = 0; v < 4; v++) xo[v] = X[(size_t)(I * 16 + 4 * v + lk) * ld + I * 16 + li];
         res_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], rp[(4 * ks + lk) * ldr + J * 16 + li], acc, 0, 0, 0);
+        for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], rp[(4 * ks + lk) * ldr + I * 16 + li], acc, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 4; v++) Y[(size_t)(I * 16 + 4 * v + lk) * ld + J * 16 + li] = xo[v] - acc[v];
+        for (int v = 0; v < 4; v++) Pn[4 * v + lk][li] = xo[v] - acc[v];
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane >> 2, c0 = (lane & 3) * 4;
+        double b4[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) b4[x] = Pn[r][c0 + x];
+        __builtin_amdgcn_wave_barrier();
+        invert_into(Pn, b4);
+      }
+    } else {
+      // update: wavefront w takes the row strips I = w, w + nw, ...; its column-panel tile X[I,K] is loaded once per strip
+      for (int I = wave; I < nb; I += nw) {
+        if (I == kb) {
+          for (int J = 0; J < nb; J++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) Y[(size_t)(K0 + 4 * v + lk) * ld + J * 16 + li] = rp[(4 * v + lk) * ldr + J * 16 + li];
+          continue;
+        }
+        double a[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) a[ks] = X[(size_t)(I * 16 + li) * ld + K0 + 4 * ks + lk];
+        for (int J = 0; J < nb; J++) {
+          double xo[4];
+#pragma unroll
+          for (int v = 0; v < 4; v++) xo[v] = (J == kb) ? 0.0 : X[(size_t)(I * 16 + 4 * v + lk) * ld + J * 16 + li];
+          res_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], rp[(4 * ks + lk) * ldr + J * 16 + li], acc, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 4; v++) Y[(size_t)(I * 16 + 4 * v + lk) * ld + J * 16 + li] = xo[v] - acc[v];
+        }
       }
     }
     __syncthreads();

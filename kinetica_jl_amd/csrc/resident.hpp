@@ -45,7 +45,7 @@ constexpr int RES_MAX_DENSE = 512;
 // dynamic LDS of the kernel: y, d, psi, scale (4 N), the solve-vector window of W, max(R, row panel of the dense inverse)
 size_t resident_dyn_lds(int N, int R, int m, int64_t window);
 size_t resident_desc_bytes(const SegPlanView& resid, const SegPlanView& stageA, const SegPlanView& stageC);   // ... + these, when they fit
-constexpr size_t RES_LDS_BUDGET = 160 * 1024 - 14 * 1024;   // what is left of a CU's LDS next to the kernel's static blocks
+constexpr size_t RES_LDS_BUDGET = 160 * 1024 - 16 * 1024;   // what is left of a CU's LDS next to the kernel's static blocks
 void launch_resident(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
 // the same kernel built with half the registers per lane: two workgroups share a compute unit (resident_w4.hip)
 void launch_resident_shared_cu(int K, size_t dyn_lds, const ResNetDev* d_net, const ResTrajDev* d_traj, const ResParams* d_par, hipStream_t s);
