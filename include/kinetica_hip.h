@@ -103,8 +103,10 @@ int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const doub
  * analysis over sol.u) has no layout to inherit, so the library defines one in which ONE pass over a state's rate
  * constants needs random access to on-chip memory only (kinetica_jl_amd/csrc/tiled.hpp):
  *   species   [ hubs | window 0 | window 1 | ... ]   (the caller's order when the state fits on-chip memory, N <= 10 000)
- *   reactions every reaction next to its exact reverse, grouped by window: a k row has k_len = 2 x records doubles,
- *             reaction r at slot_of_reaction[r], 0.0 in the reverse slot of a reaction without one.
+ *   reactions every reaction next to its exact reverse, grouped by window; within a window the pairs first (two slots per
+ *             record, 0.0 in the reverse slot of a reaction without one), then - when the network has lost a noticeable
+ *             part of its reverses, as after the low-k cutoff (solve_utils.jl:213-245) - the reactions without a reverse
+ *             at one slot each: a k row has k_len <= 2 x records doubles, reaction r at slot_of_reaction[r].
  * KIN_ERR_UNSUPPORTED (from every call of this block) when the network has no such layout: more than two product
  * molecules in a reaction, or rarely referenced species that do not fall apart into window-sized groups. */
 /* k_len; species_of_lib[N] (library position -> species id, + index_base); slot_of_reaction[R] (+ index_base);
@@ -113,15 +115,18 @@ int kin_rhs_batched_dev(kin_network* h, int64_t B, const double* d_u, const doub
 int kin_lib_layout(kin_network* h, int index_base, int64_t* k_len, int64_t* species_of_lib, int64_t* slot_of_reaction,
                    int32_t* species_identity, int64_t* info);
 /* The same layout computed on the host alone (no device, no handle): what the library-order tables contain, for tools
- * and for tests that replay the sweep's arithmetic on the CPU. `hubs` = 0 lets the library choose. info[8] = hubs,
- * windows, records, on-chip entries, split-accumulator entries, workgroup size, first window entry, iteration rows;
+ * and for tests that replay the sweep's arithmetic on the CPU. `hubs` = 0 lets the library choose. info[10] = hubs,
+ * windows, records, on-chip entries, split-accumulator entries, workgroup size, first window entry, iteration rows,
+ * k_len, 1 if some window ends in one-slot records;
  * rec[records] = packed 64-bit records (four 14-bit on-chip labels with fixed roles + 3 flag bits at bit 56),
- * rowtab[2 x rows], seg_q[windows + 1], win_off / win_cnt[windows], copy_src[copies]. Call once with NULL arrays for
- * the sizes. */
+ * rowtab[2 x rows], seg_q[windows + 1], win_off / win_cnt[windows], copy_src[copies], seg_k[2 x windows] = slot of the
+ * window's first record and the number of its records that have two slots (record i of the window: slot + 2 i below
+ * that number n2, slot + n2 + i from it on). Call once with NULL arrays for the sizes. */
 int kin_lib_layout_host(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr, const int64_t* reac_idx,
                         const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
                         int index_base, int hubs, int64_t* info, int64_t* species_of_lib, int64_t* slot_of_reaction,
-                        uint64_t* rec, int32_t* rowtab, int32_t* seg_q, int32_t* win_off, int32_t* win_cnt, int32_t* copy_src);
+                        uint64_t* rec, int32_t* rowtab, int32_t* seg_q, int32_t* win_off, int32_t* win_cnt, int32_t* copy_src,
+                        int32_t* seg_k);
 /* Symbolic analysis of the Newton-matrix factorisation (I - c J; the reference's solver does this inside KLU,
  * docs/src/getting-started.md:69) WITHOUT a device: sizes only. Arguments <= 0 take the library's defaults.
  * info[0..11] = sparse pivots, dense block dimension, elimination rounds, nnz(U), nnz(L11^-1), nnz(U11^-1), nnz(L21 L11^-1),

@@ -156,21 +156,22 @@ def lib_layout_host(net, hubs=0):
                                                               net.prod_idx, net.prod_sto)]
     P32, PU64 = POINTER(c_int32), POINTER(ctypes.c_uint64)
     L.kin_lib_layout_host.argtypes = [c_int64, c_int64] + [POINTER(c_int64)] * 6 + [c_int, c_int, POINTER(c_int64), POINTER(c_int64),
-                                                                                  POINTER(c_int64), PU64, P32, P32, P32, P32, P32]
-    info = np.zeros(8, np.int64)
+                                                                                  POINTER(c_int64), PU64, P32, P32, P32, P32, P32, P32]
+    info = np.zeros(10, np.int64)
     head = [int(net.n_species), int(net.n_reactions)] + [_p64(a) for a in arrs] + [0, int(hubs), _p64(info)]
-    st = L.kin_lib_layout_host(*head, None, None, None, None, None, None, None, None)
+    st = L.kin_lib_layout_host(*head, None, None, None, None, None, None, None, None, None)
     if st != KIN_OK:
         raise KineticaHipError(st, "network has no tiled layout")
-    h, T, P, E, n_copy, BS, wbase, Q = [int(x) for x in info]
+    h, T, P, E, n_copy, BS, wbase, Q, k_len, has_singles = [int(x) for x in info]
     sp = np.empty(net.n_species, np.int64); slot = np.empty(net.n_reactions, np.int64)
     rec = np.empty(max(P, 1), np.uint64); rowtab = np.empty(max(2 * Q, 1), np.int32); seg_q = np.empty(T + 1, np.int32)
     woff = np.empty(T, np.int32); wcnt = np.empty(T, np.int32); copy_src = np.empty(max(n_copy, 1), np.int32)
+    seg_k = np.empty(2 * T, np.int32)
     i32 = lambda a: a.ctypes.data_as(P32)
     st = L.kin_lib_layout_host(*head, _p64(sp), _p64(slot), rec.ctypes.data_as(PU64), i32(rowtab), i32(seg_q), i32(woff), i32(wcnt),
-                               i32(copy_src))
+                               i32(copy_src), i32(seg_k))
     assert st == KIN_OK
-    return dict(h=h, T=T, P=P, E=E, n_copy=n_copy, BS=BS, wbase=wbase, Q=Q, species_of_lib=sp, slot_of_reaction=slot,
+    return dict(k_len=k_len, has_singles=bool(has_singles), seg_k=seg_k.reshape(T, 2), h=h, T=T, P=P, E=E, n_copy=n_copy, BS=BS, wbase=wbase, Q=Q, species_of_lib=sp, slot_of_reaction=slot,
                 rec=rec[:P], rowtab=rowtab[:2 * Q].reshape(Q, 2), seg_q=seg_q, win_off=woff, win_cnt=wcnt, copy_src=copy_src[:n_copy])
 
 

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 
@@ -216,31 +218,215 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   std::vector<std::vector<int32_t>> seg(T);
   for (int32_t p = 0; p < P; p++) seg[seg_of_rec[p]].push_back(p);
   auto cls = [&](int32_t p) { return (recs[p].f[1] >= 0 ? 1 : 0) | (recs[p].f[3] >= 0 ? 2 : 0); };
-  L.rec.clear(); L.kf.clear(); L.kr.clear();
+  L.rec.clear(); L.kf.clear(); L.kr.clear(); L.kslot.clear(); L.seg_k.clear();
+  L.KL = 0; L.has_singles = false; L.pad_slots.clear();
   L.rowtab.clear(); L.seg_q.assign(1, 0);
   L.slot_of_reaction.assign(R, -1);
+  // Inside a class the order is free, and so are the order of a record's two reactants / two products, which reaction of a
+  // pair plays the forward role, and the accumulator entry a split hub's occurrence uses: all are chosen so that the 16
+  // records of a lane group (segment positions 16 g .. 16 g + 15) hit 16 different banks in each field. A ds_add_f64 is
+  // executed in four groups of 16 contiguous lanes over 16 banks of 8 bytes (bank = label mod 16), a ds_read_b64 in two
+  // halves of 32 lanes over 32 banks (tools/lds_group_probe.hip: ds_add_f64 3.4 ns per wave instruction when a group's
+  // labels differ mod 16, 9-11 ns for random labels, 8.4 ns for two lanes of a group on one address; lanes of different
+  // groups never conflict). Unscheduled, the labels of the synthetic CRNs cost 3.0 LDS cycles per group and field; with the
+  // schedule 1.2-1.5 (the bank loads of a class are not uniform, so some conflicts must stay). SQ_LDS_BANK_CONFLICT of the
+  // C5 sweep: 78 M -> 18 M cycles per launch, LDS-active cycles 202 M -> 101 M (profiles/r04_c5_tiled_pmc.json).
+  // KIN_TILED_SCHEDULE=0 keeps the plain order (A/B), KIN_TILED_SCAN sets the number of candidates in sight: 256 keeps the
+  // library order close to the caller's reaction order (kin_rates_to_lib_dev gathers from a narrow range per wavefront) and
+  // is as fast in the sweep as 2 048.
+  const bool schedule = !(getenv("KIN_TILED_SCHEDULE") && atoi(getenv("KIN_TILED_SCHEDULE")) == 0);
+  // Records without a reverse reaction (what the low-k cutoff leaves of a pair, solve_utils.jl:213-245) come last in their
+  // segment and take ONE rate-constant slot there; the records before them - all pairs, filled up to whole wavefronts with
+  // single ones - take two (tiled.hpp: seg_k). Only when that shortens the k row noticeably: a network that has all its
+  // pairs keeps the plain layout and the plain instantiation of the kernel.
+  int64_t n_single = 0;
+  for (const Rec& q : recs) n_single += q.kr < 0;
+  const bool compact = n_single * 20 >= (int64_t)P && !(getenv("KIN_TILED_SINGLES") && atoi(getenv("KIN_TILED_SINGLES")) == 0);
+  auto kind = [&](int32_t p) { return compact && recs[p].kr < 0 ? 4 : 0; };
+  int SCAN = 256;          // candidates in sight per position
+  if (const char* e = getenv("KIN_TILED_SCAN")) SCAN = std::max(16, atoi(e));
+  int64_t sched_slots = 0, sched_conflicts = 0, dbg_defer = 0;
+  double dbg_sec = 0.0;
   for (int t = 0; t < T; t++) {
-    std::stable_sort(seg[t].begin(), seg[t].end(), [&](int32_t a, int32_t b) { return cls(a) < cls(b); });
+    std::stable_sort(seg[t].begin(), seg[t].end(), [&](int32_t a, int32_t b) { return (kind(a) | cls(a)) < (kind(b) | cls(b)); });
     const int32_t base = (int32_t)L.kf.size(), n = (int32_t)seg[t].size();
+    // label options of field j of record p: a window entry, a hub entry, or a split hub's eight entries
+    auto options = [&](int32_t p, int j, uint64_t* opt) -> int {
+      const int32_t sp = recs[p].f[j];
+      if (sp < 0) return 0;
+      const int32_t li = L.lib_of_species[sp];
+      if (li >= h) { opt[0] = (uint64_t)(L.wbase + (li - L.win_off[t])); return 1; }
+      opt[0] = (uint64_t)li;
+      if (copy_rank[sp] < 0) return 1;
+      for (int c = 0; c < TILED_COPIES; c++) opt[1 + c] = (uint64_t)(h + TILED_DUMMY + copy_rank[sp] * TILED_COPIES + c);
+      return 1 + TILED_COPIES;
+    };
+    std::vector<int32_t> placed(n);
+    std::vector<char> flipped(n, 0);   // the record's reverse reaction takes the forward role
+    std::vector<std::array<uint64_t, 4>> labs(n);
+    const auto t_s0 = std::chrono::steady_clock::now();
+    if (schedule) {
+      // a candidate: per field of the record the banks its label options cover, mod 16 and mod 32 (0: field unused)
+      struct Cand { int32_t p; uint16_t m16[4]; uint32_t m32[4]; int64_t hard; bool sides; int cls; };
+      auto make_cand = [&](int32_t p) {
+        Cand c{p, {0, 0, 0, 0}, {0, 0, 0, 0}, 0, false, cls(p)};
+        for (int j = 0; j < 4; j++) {
+          uint64_t opt[1 + TILED_COPIES];
+          const int no = options(p, j, opt);
+          for (int o = 0; o < no; o++) { c.m16[j] |= (uint16_t)(1u << (opt[o] & 15)); c.m32[j] |= 1u << (opt[o] & 31); }
+          if (no > 0) c.hard = std::max(c.hard, cnt[recs[p].f[j]]);
+        }
+        // forward and reverse reaction of a pair may change roles where that keeps the record's class
+        c.sides = recs[p].kr >= 0 && (recs[p].f[1] >= 0) == (recs[p].f[3] >= 0);
+        return c;
+      };
+      // orientation o: bit 0 = the two reactant fields swapped, bit 1 = the two product fields swapped, bit 2 = the
+      // sides swapped (the reverse reaction becomes the record's forward one); src[j] = the record field that goes to j
+      auto sources = [](int o, int* src) {
+        const int s0 = (o & 4) ? 2 : 0, s1 = (o & 4) ? 0 : 2;
+        src[0] = s0 + (o & 1); src[1] = s0 + ((o & 1) ^ 1);
+        src[2] = s1 + ((o >> 1) & 1); src[3] = s1 + (((o >> 1) & 1) ^ 1);
+      };
+      bool present[8] = {false, false, false, false, false, false, false, false};
+      for (int32_t x = 0; x < n; x++) present[kind(seg[t][x]) | cls(seg[t][x])] = true;
+      // a record may also ride in the wavefronts of a class that has all its fields (they execute the instructions of the
+      // fields it lacks anyway, on dummy entries): what cannot be placed without a conflict at the end of a class's run -
+      // when the candidates run out, the last lanes of a group rarely find their one free bank - waits for the next such run
+      auto later_home = [&](int x, int c, int kd) {   // (among the runs of the same kind)
+        for (int c2 = c + 1; c2 < 4; c2++) if (present[kd | c2] && (x & ~c2) == 0) return true;
+        return false;
+      };
+      std::vector<Cand> deferred;
+      uint32_t used[4] = {0, 0, 0, 0}, used32[4] = {0, 0, 0, 0};
+      int32_t i = 0;
+      for (int32_t a = 0; a < n;) {
+        int32_t b = a;
+        const int c_run = cls(seg[t][a]), k_run = kind(seg[t][a]);
+        while (b < n && cls(seg[t][b]) == c_run && kind(seg[t][b]) == k_run) b++;
+        const bool live[4] = {true, (c_run & 1) != 0, true, (c_run & 2) != 0};
+        // the candidates in sight: a reservoir that is topped up in the caller's reaction order (the conversion of rate
+        // constants to the library order then gathers from a narrow range per wavefront)
+        std::vector<Cand> pool;
+        pool.reserve(SCAN + deferred.size());
+        for (size_t d = 0; d < deferred.size();)
+          if ((deferred[d].cls & ~c_run) == 0 && kind(deferred[d].p) == k_run) { pool.push_back(deferred[d]); deferred[d] = deferred.back(); deferred.pop_back(); }
+          else d++;
+        int32_t next = a;
+        size_t cur = 0;
+        for (;;) {
+          while (pool.size() < (size_t)SCAN && next < b) pool.push_back(make_cand(seg[t][next++]));
+          if (pool.empty()) break;
+          if ((i & 15) == 0) used[0] = used[1] = used[2] = used[3] = 0;
+          if ((i & 31) == 0) used32[0] = used32[1] = used32[2] = used32[3] = 0;
+          // Among them, in any orientation, one that finds a free bank in every field - for the ds_add_f64 of its 16-lane
+          // group first (weight 4), for the ds_read_b64 of its 32-lane half second; of the first few that do, the one with
+          // the most referenced species (the hubs' records are the hard ones to place).
+          uint32_t fr[4], fr32[4];
+          for (int j = 0; j < 4; j++) { fr[j] = ~used[j] & 0xffffu; fr32[j] = ~used32[j]; }
+          size_t best = cur % pool.size(); int best_cost = 1 << 20, best_or = 0, fits = 0; int64_t best_hard = -1;
+          const int enough = (i & 15) >= 12 ? 1 : 6;   // (the last lanes of a group take the first record that fits: few do)
+          for (size_t c = 0; c < pool.size() && fits < enough; c++) {
+            const size_t q = (cur + c) % pool.size();
+            const Cand& k = pool[q];
+            // (quick look: can anything of the record sit in fields 0 and 2 at all? most candidates fail here when the
+            // group is nearly full)
+            if (best_cost <= 4) {
+              const bool a0 = ((k.m16[0] | k.m16[1]) & fr[0]) != 0, a2 = ((k.m16[2] | k.m16[3]) & fr[2]) != 0;
+              const bool b0 = k.sides && ((k.m16[2] | k.m16[3]) & fr[0]) != 0, b2 = k.sides && ((k.m16[0] | k.m16[1]) & fr[2]) != 0;
+              if (!((a0 && a2) || (b0 && b2))) continue;
+            }
+            // (the cost separates: per side assignment, the better order of the reactant pair + the better order of the
+            // product pair)
+            auto field_cost = [&](int sj, int j) {
+              if (!k.m16[sj]) return (live[j] && !fr[j]) ? 4 : 0;
+              if (!(k.m16[sj] & fr[j])) return 4;
+              return (k.m32[sj] & fr32[j]) ? 0 : 1;
+            };
+            int q_cost = 1 << 20;
+            for (int sd = 0; sd < (k.sides ? 2 : 1); sd++) {
+              const int s0 = sd ? 2 : 0, s1 = sd ? 0 : 2;
+              int cr = field_cost(s0, 0) + field_cost(s0 + 1, 1), o_r = 0;
+              if (k.m16[s0 + 1] && cr > 0) { const int c2 = field_cost(s0 + 1, 0) + field_cost(s0, 1); if (c2 < cr) { cr = c2; o_r = 1; } }
+              int cp = field_cost(s1, 2) + field_cost(s1 + 1, 3), o_p = 0;
+              if (k.m16[s1 + 1] && cp > 0) { const int c2 = field_cost(s1 + 1, 2) + field_cost(s1, 3); if (c2 < cp) { cp = c2; o_p = 2; } }
+              const int cost = cr + cp;
+              q_cost = std::min(q_cost, cost);
+              if (cost < best_cost || (cost == best_cost && k.hard > best_hard)) { best_cost = cost; best = q; best_or = o_r | o_p | (sd ? 4 : 0); best_hard = k.hard; }
+            }
+            fits += q_cost == 0;
+          }
+          if (best_cost >= 4 && next == b) {
+            // the end of the run: whoever has a later home goes there
+            size_t kept = 0;
+            for (size_t q = 0; q < pool.size(); q++)
+              if (later_home(pool[q].cls, c_run, k_run)) deferred.push_back(pool[q]); else pool[kept++] = pool[q];
+            if (kept < pool.size()) { dbg_defer += pool.size() - kept; pool.resize(kept); cur = 0; continue; }
+          }
+          const int32_t p = pool[best].p;
+          int src[4];
+          sources(best_or, src);
+          for (int j = 0; j < 4; j++) {
+            uint64_t opt[TILED_DUMMY];
+            int no = options(p, src[j], opt);
+            if (no == 0) {
+              if (!live[j]) { labs[i][j] = (uint64_t)(h + (i & (TILED_DUMMY - 1))); continue; }
+              // a field the record lacks but its wavefront executes: any dummy entry on a free bank
+              for (int d = 0; d < TILED_DUMMY; d++) opt[d] = (uint64_t)(h + ((i + d) & (TILED_DUMMY - 1)));
+              no = TILED_DUMMY;
+            }
+            int pick = -1;
+            for (int o = 0; o < no && pick < 0; o++)
+              if (!(used[j] >> (opt[o] & 15) & 1u) && !(used32[j] >> (opt[o] & 31) & 1u)) pick = o;
+            for (int o = 0; o < no && pick < 0; o++) if (!(used[j] >> (opt[o] & 15) & 1u)) pick = o;
+            sched_slots++;
+            if (pick < 0) { pick = no > 1 ? i % no : 0; sched_conflicts++; }
+            labs[i][j] = opt[pick];
+            used[j] |= 1u << (opt[pick] & 15);
+            used32[j] |= 1u << (opt[pick] & 31);
+          }
+          flipped[i] = (best_or & 4) != 0;
+          placed[i++] = p;
+          pool[best] = pool.back();
+          pool.pop_back();
+          cur = best + 1;
+        }
+        a = b;
+      }
+    } else {
+      for (int32_t i = 0; i < n; i++) {
+        placed[i] = seg[t][i];
+        for (int j = 0; j < 4; j++) {
+          uint64_t opt[1 + TILED_COPIES];
+          const int no = options(placed[i], j, opt);
+          labs[i][j] = no == 0 ? (uint64_t)(h + (i & (TILED_DUMMY - 1))) : opt[no > 1 ? (i & 7) : 0];
+        }
+      }
+    }
+    dbg_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_s0).count();
+    seg[t] = placed;
+    // rate-constant slots: the first n2 records two each (n2 = the pairs, rounded up to whole wavefronts), the rest one
+    int32_t n_pairs = 0;
+    for (int32_t i = 0; i < n; i++) n_pairs += kind(seg[t][i]) == 0;
+    const int32_t n2 = compact ? std::min<int32_t>(n, (int32_t)ceil_div(n_pairs, 64) * 64) : n;
+    const int32_t koff = (int32_t)L.KL;
+    L.seg_k.push_back(koff); L.seg_k.push_back(n2);
+    L.KL += 2 * (int64_t)n2 + (n - n2);
+    if (L.KL & 1) L.pad_slots.push_back((int32_t)L.KL++);
+    L.has_singles = L.has_singles || n2 < n;
     std::vector<uint64_t> words(n);
     for (int32_t i = 0; i < n; i++) {
       const Rec& q = recs[seg[t][i]];
-      uint64_t lab[4];
-      for (int j = 0; j < 4; j++) {
-        const int32_t sp = q.f[j];
-        if (sp < 0) { lab[j] = (uint64_t)(h + (i & (TILED_DUMMY - 1))); continue; }
-        const int32_t li = L.lib_of_species[sp];
-        if (li < h) {
-          const int c = i & 7;
-          lab[j] = (copy_rank[sp] >= 0 && c > 0) ? (uint64_t)(h + TILED_DUMMY + copy_rank[sp] * TILED_COPIES + (c - 1)) : (uint64_t)li;
-        } else {
-          lab[j] = (uint64_t)(L.wbase + (li - L.win_off[t]));
-        }
-      }
+      const uint64_t* lab = labs[i].data();
       words[i] = lab[0] | (lab[1] << 14) | (lab[2] << 28) | (lab[3] << 42);
-      L.kf.push_back(q.kf); L.kr.push_back(q.kr);
-      L.slot_of_reaction[q.kf] = 2 * (base + i);
-      if (q.kr >= 0) L.slot_of_reaction[q.kr] = 2 * (base + i) + 1;
+      const int32_t rf = flipped[i] ? q.kr : q.kf, rr = flipped[i] ? q.kf : q.kr;
+      L.kf.push_back(rf); L.kr.push_back(rr);
+      const int32_t slot = koff + (i < n2 ? 2 * i : n2 + i);
+      L.slot_of_reaction[rf] = slot;
+      if (rr >= 0) {
+        if (i >= n2) { L.why = "internal: a pair among the single-slot records"; return L; }
+        L.slot_of_reaction[rr] = slot + 1;
+      }
+      L.kslot.push_back(i < n2 ? slot : ~slot);
     }
     // flags of a 64-record group (one wavefront's records of a row) = OR over its records: a group of one kind skips
     // the unused fields, a mixed group sends them to the dummy entries
@@ -253,13 +439,17 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
     const int32_t rows = (int32_t)ceil_div(n, bs);
     // (at least one group of iteration rows, also for a window without records: the kernel's producer relies on it)
     const int32_t rows_pad = std::max<int32_t>(TILED_MIN_ROWS, (int32_t)ceil_div(rows, L.row_quantum) * L.row_quantum);
-    L.seginfo.push_back(base); L.seginfo.push_back(n); L.seginfo.push_back(rows_pad); L.seginfo.push_back(0);
+    L.seginfo.push_back(base); L.seginfo.push_back(n); L.seginfo.push_back(rows_pad); L.seginfo.push_back(n2);
     for (int32_t i = 0; i < rows_pad; i++) {
       L.rowtab.push_back(i < rows ? base + i * bs : -1);
       L.rowtab.push_back(i < rows ? std::min(bs, n - i * bs) : 0);
     }
     L.seg_q.push_back((int32_t)(L.rowtab.size() / 2));
   }
+  L.sched_slots = sched_slots; L.sched_conflicts = sched_conflicts;
+  if (getenv("KIN_TILED_DEBUG")) fprintf(stderr, "[tiled] %d records, %d segments: %lld of %lld label slots share a bank with an earlier lane of their group\n",
+                                         P, T, (long long)sched_conflicts, (long long)sched_slots),
+    fprintf(stderr, "[tiled] %lld records moved to the wavefronts of a later class, %.3f s in the record order\n", (long long)dbg_defer, dbg_sec);
   L.ok = true;
   return L;
 }

@@ -13,9 +13,12 @@
 // not decompose is reported as not tileable and keeps the hub / net-rate-scratch kernel (kernels.hip: sweep_big_kernel).
 // A state that fits LDS entirely (N <= 10 000) is the special case h = N, one segment, species order = the caller's.
 //
-// Rate constants in library order: k_lib[2 p] / k_lib[2 p + 1] = forward / reverse rate constant of record p (0 where a
-// reaction has no reverse). The rate-table kernel writes this layout directly; Arrhenius parameters are stored in it too
-// for the sweep that forms its rate constants itself from the states' temperatures (SURVEY 8(d) M1').
+// Rate constants in library order: per segment, the first n2 records (its pairs, filled up to whole wavefronts with single
+// reactions) have two slots each - forward / reverse rate constant, 0 where a reaction has no reverse - and the remaining
+// records, all without a reverse, one: record i of a segment that starts at slot koff has its forward constant at
+// koff + 2 i (i < n2) or koff + n2 + i (i >= n2). A network with (nearly) all its pairs has n2 = all records everywhere:
+// k_lib[2 p] / k_lib[2 p + 1] for record p. The rate-table kernel writes this layout directly; Arrhenius parameters are
+// stored per record for the sweep that forms its rate constants itself from the states' temperatures (SURVEY 8(d) M1').
 #pragma once
 #include <cstdint>
 #include <string>
@@ -56,8 +59,14 @@ struct TiledHost {
   std::vector<int32_t> slot_of_reaction;   // R: position of reaction r's rate constant in a k_lib row
   std::vector<int32_t> rowtab;     // 2 per iteration row: first record of the row (-1: padding row), records in it
   std::vector<int32_t> seg_q;      // T + 1: iteration rows [seg_q[s], seg_q[s + 1]) belong to segment s (multiples of row_quantum)
-  std::vector<int32_t> seginfo;    // 4 per segment: first record, records, iteration rows (>= TILED_MIN_ROWS), 0 - what the kernel reads
-  int64_t k_len() const { return 2 * (int64_t)P; }
+  std::vector<int32_t> seginfo;    // 4 per segment: first record, records, iteration rows (>= TILED_MIN_ROWS), n2 - what the kernel reads
+  std::vector<int32_t> seg_k;      // 2 per segment: koff = slot of its first record's forward constant (even), n2 = records with two slots
+  std::vector<int32_t> kslot;      // P: slot of the record's forward constant (reverse: the next one); ~slot for a one-slot record
+  int64_t KL = 0;                  // slots of a k_lib row (even)
+  std::vector<int32_t> pad_slots;  // slots no record owns (a segment with an odd number of one-slot records ends in one): always 0
+  bool has_singles = false;        // some segment has one-slot records (the kernel's SINGLES instantiation runs the layout)
+  int64_t sched_slots = 0, sched_conflicts = 0;   // label slots placed / of those, on a bank an earlier lane of the 16-lane group uses
+  int64_t k_len() const { return KL; }
 };
 
 // `bs`: workgroup size (256 / 512 / 1024). `h_force` > 0 fixes the hub count (tests).

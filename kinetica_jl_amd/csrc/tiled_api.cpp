@@ -12,7 +12,10 @@ using namespace kin;
 namespace {
 
 // workgroup size: 10 staged doubles per thread must cover the LDS entries (tiled_kernels.hip)
-int tiled_block_size(int64_t N) { return N <= 2300 ? 256 : (N <= 4850 ? 512 : 1024); }
+int tiled_block_size(int64_t N) {
+  if (const char* e = getenv("KIN_TILED_BS")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 1024) return b; }
+  return N <= 2300 ? 256 : (N <= 4850 ? 512 : 1024);
+}
 
 // builds and uploads the library order once per handle; throws ERR_UNSUPPORTED when the network is not tileable
 void ensure_tiled(kin_network* h) {
@@ -28,7 +31,7 @@ void ensure_tiled(kin_network* h) {
       for (int32_t r = 0; r < L.R; r++) if (L.slot_of_reaction[r] >= 0) rxn_of_slot[L.slot_of_reaction[r]] = r;
       h->t_rec.upload(L.rec, s);
       h->t_copy.upload(L.copy_src, s);
-      h->t_kf.upload(L.kf, s); h->t_kr.upload(L.kr, s); h->t_rxn_of_slot.upload(rxn_of_slot, s);
+      h->t_kf.upload(L.kf, s); h->t_kr.upload(L.kr, s); h->t_rxn_of_slot.upload(rxn_of_slot, s); h->t_kslot.upload(L.kslot, s);
       h->t_spec_of_lib.upload(L.species_of_lib, s); h->t_lib_of_spec.upload(L.lib_of_species, s);
       KIN_HIP(hipStreamSynchronize(s));
     }
@@ -54,12 +57,14 @@ void ensure_params(kin_network* h, hipStream_t) {
 TiledView view_of(kin_network* h) {
   const TiledHost& L = h->tiled;
   TiledView v{};
+  v.KL = L.KL; v.has_singles = L.has_singles ? 1 : 0;
   v.N = L.N; v.P = L.P; v.h = L.h; v.n_copy = L.n_copy; v.wbase = L.wbase; v.E = L.E; v.T = L.T;
   v.win_cnt_max = 0;
   for (int32_t c : L.win_cnt) v.win_cnt_max = std::max(v.win_cnt_max, c);
   v.rec = (const uint2*)h->t_rec.p;
   for (int32_t t = 0; t < L.T; t++) {
-    v.seginfo[t] = make_int4(L.seginfo[4 * t], L.seginfo[4 * t + 1], L.seginfo[4 * t + 2], 0);
+    v.seginfo[t] = make_int4(L.seginfo[4 * t], L.seginfo[4 * t + 1], L.seginfo[4 * t + 2], L.seginfo[4 * t + 3]);
+    v.segk[t] = L.seg_k[2 * t];
     v.win_off[t] = L.win_off[t]; v.win_cnt[t] = L.win_cnt[t];
   }
   v.copy_src = h->t_copy.p;
@@ -101,14 +106,15 @@ int kin_lib_layout(kin_network* h, int index_base, int64_t* k_len, int64_t* spec
 int kin_lib_layout_host(int64_t n_species, int64_t n_reactions, const int64_t* reac_ptr, const int64_t* reac_idx,
                         const int64_t* reac_sto, const int64_t* prod_ptr, const int64_t* prod_idx, const int64_t* prod_sto,
                         int index_base, int hubs, int64_t* info, int64_t* species_of_lib, int64_t* slot_of_reaction,
-                        uint64_t* rec, int32_t* rowtab, int32_t* seg_q, int32_t* win_off, int32_t* win_cnt, int32_t* copy_src) {
+                        uint64_t* rec, int32_t* rowtab, int32_t* seg_q, int32_t* win_off, int32_t* win_cnt, int32_t* copy_src,
+                        int32_t* seg_k) {
   try {
     const NetworkHost H = compile_network(n_species, n_reactions, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto, index_base);
     const TiledHost L = build_tiled(H, tiled_block_size(H.N), hubs);
     if (!L.ok) return KIN_ERR_UNSUPPORTED;
     if (info) {
       info[0] = L.h; info[1] = L.T; info[2] = L.P; info[3] = L.E; info[4] = L.n_copy; info[5] = L.BS; info[6] = L.wbase;
-      info[7] = L.seg_q.back();
+      info[7] = L.seg_q.back(); info[8] = L.k_len(); info[9] = L.has_singles ? 1 : 0;
     }
     if (species_of_lib) for (int32_t j = 0; j < L.N; j++) species_of_lib[j] = L.species_of_lib[j];
     if (slot_of_reaction) for (int32_t r = 0; r < L.R; r++) slot_of_reaction[r] = L.slot_of_reaction[r];
@@ -118,6 +124,7 @@ int kin_lib_layout_host(int64_t n_species, int64_t n_reactions, const int64_t* r
     if (win_off) std::copy(L.win_off.begin(), L.win_off.end(), win_off);
     if (win_cnt) std::copy(L.win_cnt.begin(), L.win_cnt.end(), win_cnt);
     if (copy_src) std::copy(L.copy_src.begin(), L.copy_src.end(), copy_src);
+    if (seg_k) std::copy(L.seg_k.begin(), L.seg_k.end(), seg_k);
   } catch (const KinError& e) {
     return e.code;
   } catch (const std::exception&) {
@@ -160,7 +167,9 @@ int kin_rate_table_lib_dev(kin_network* h, const double* T, int64_t n_stops, dou
   ensure_tiled(h);
   ensure_params(h, h->stream);
   h->T_stops.upload(T, n_stops, h->stream);
-  launch_rate_table_lib(h->tiled.P, n_stops, h->t_par.p, h->has_kmax, h->k_max, h->T_stops.p, d_out, h->stream);
+  TiledPadSlots pads{};
+  for (int32_t q : h->tiled.pad_slots) pads.slot[pads.n++] = q;
+  launch_rate_table_lib(h->tiled.P, h->tiled.KL, n_stops, h->t_par.p, h->t_kslot.p, pads, h->has_kmax, h->k_max, h->T_stops.p, d_out, h->stream);
   KIN_HIP(hipStreamSynchronize(h->stream));
   KIN_CATCH(h)
 }

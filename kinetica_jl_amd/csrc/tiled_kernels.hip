@@ -45,7 +45,9 @@ __device__ __forceinline__ Labels decode(uint2 w) {
 
 // UN = doubles per thread of the staged-in set (the hubs, or one window) that travel HBM -> registers ahead of their
 // use: 5 when hubs and windows have at most 5 BS entries each (the windowed layouts), else 10 (a state that fits LDS whole)
-template <int BS, bool TMODE, int UN>
+// SINGLES: the layout has records with one rate-constant slot at the end of its segments (tiled.hpp); without them the
+// record at position p reads k_lib[2 p], k_lib[2 p + 1] and none of the extra address arithmetic is compiled in
+template <int BS, bool TMODE, int UN, bool SINGLES>
 __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, const double* __restrict__ u,
                                                          const double* __restrict__ k_lib, const double* __restrict__ Tb,
                                                          double* __restrict__ du) {
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   const double* tab_s = lds + 2 * v.E;
   const int tid = threadIdx.x;
   const int N = v.N, h = v.h, wbase = v.wbase, T = v.T;
-  const size_t KL = 2 * (size_t)v.P;
+  const size_t KL = (size_t)v.KL;
 
   for (int i = tid; i < v.E; i += BS) du_s[i] = 0.0;
   if (tid < TILED_DUMMY) u_s[h + tid] = 1.0;
@@ -110,11 +112,13 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
   using BatchT = Batch<TMODE, NB>;
   static_assert(TILED_MIN_ROWS >= 2 * NB && (UN > 5 ? 2 : 4) % NB == 0, "segments are padded to whole batches, two at least");
   int pb = blockIdx.x, ps = 0, pi = 0;   // state, segment, iteration row inside the segment of the next request
-  int4 pa = v.seginfo[0], pn = v.seginfo[T > 1 ? 1 : 0];   // x = first record, y = records, z = iteration rows
+  int4 pa = v.seginfo[0], pn = v.seginfo[T > 1 ? 1 : 0];   // x = first record, y = records, z = iteration rows, w = two-slot records
+  int pak = SINGLES ? v.segk[0] : 0, pnk = SINGLES ? v.segk[T > 1 ? 1 : 0] : 0;   // slot of the segment's first record
   asm volatile("" : "+s"(pa.x), "+s"(pa.y), "+s"(pa.z), "+s"(pn.x), "+s"(pn.y), "+s"(pn.z));
+  if constexpr (SINGLES) asm volatile("" : "+s"(pa.w), "+s"(pn.w), "+s"(pak), "+s"(pnk));
   auto load_batch = [&](BatchT& G) {
     if (pi >= pa.z) {
-      pi = 0; pa = pn;
+      pi = 0; pa = pn; pak = pnk;
       if (++ps == T) { ps = 0; pb += gridDim.x; }
     }
     const bool live = pb < B;
@@ -128,12 +132,29 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       G.w[x].x = ok ? w.x : EMPTY.x;
       G.w[x].y = ok ? w.y : EMPTY.y;
       if constexpr (TMODE) G.p[x] = v.par[p];
-      else G.k[x] = *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
+      else if constexpr (!SINGLES) G.k[x] = *reinterpret_cast<const double2*>(kb + 2 * (size_t)p);
+      else {
+        // a wavefront's 64 records are all of one kind (n2 is a multiple of 64 wherever one-slot records follow): two
+        // neighbouring one-slot records share a 16-byte load, the same instruction as for the two-slot records
+        const bool one = (off & ~63) >= pa.w;
+        const size_t e = !ok ? 0 : (one ? (size_t)(pak + pa.w) + (size_t)(off & ~1) : (size_t)pak + 2 * (size_t)off);
+        const double2 kk = *reinterpret_cast<const double2*>(kb + e);
+        // (selects on the 32-bit halves: a select between the two components of one double2 value becomes an indexed
+        // element access and sends the whole queue to scratch memory)
+        const bool odd = one && (off & 1);
+        const int lo = odd ? __double2loint(kk.y) : __double2loint(kk.x), hi = odd ? __double2hiint(kk.y) : __double2hiint(kk.x);
+        const int rlo = one ? 0 : __double2loint(kk.y), rhi = one ? 0 : __double2hiint(kk.y);
+        G.k[x].x = __hiloint2double(hi, lo);
+        G.k[x].y = __hiloint2double(rhi, rlo);
+      }
     }
     pi += NB;
   };
 
   double RT = 1.0, inv_RT = 1.0;
+#if defined(KIN_TILED_PROBE)
+  double probe_acc = 0.0;
+#endif
   // Rows of a batch are processed two at a time: the pair's eight LDS reads in flight together, both net rates formed,
   // then the pair's atomics back to back - nothing waits between them, and the next pair's reads queue up behind them
   // (the LDS executes a wave's operations in order). An all-padding row has EMPTY records: rate constants times
@@ -158,6 +179,8 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
         const double u2v = u_s[L.l2];
         if (fl[y] & 2u) u3v = u_s[L.l3];
         const double uf = u0v * u1v, ur = u2v * u3v;
+#elif defined(KIN_TILED_PROBE) && (KIN_TILED_PROBE == 1 || KIN_TILED_PROBE == 3)   // timing only (wrong results): no LDS operand reads
+        const double uf = 1.0 + (double)L.l0, ur = 1.0 + (double)L.l2;
 #else
         const double uf = u_s[L.l0] * u_s[L.l1];
         const double ur = u_s[L.l2] * u_s[L.l3];
@@ -175,6 +198,10 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       for (int y = 0; y < SUB; y++) {
         if (fl[y] & 4u) continue;
         const Labels L = decode(G.w[x0 + y]);
+#if defined(KIN_TILED_PROBE)   // timing only (wrong results): no LDS atomics, the net rate kept alive in a register
+        probe_acc += net[y];
+        continue;
+#endif
         __hip_atomic_fetch_add(du_s + L.l0, -net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (fl[y] & 1u) __hip_atomic_fetch_add(du_s + L.l1, -net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(du_s + L.l2, net[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -196,6 +223,27 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
     double* dub = du + (size_t)b * N;
     const int bn = b + gridDim.x;
     if (TMODE) { RT = 8.314462618 * Tn; inv_RT = 1.0 / RT; }
+#if defined(KIN_TILED_PROBE) && KIN_TILED_PROBE == 3   // timing only: the record / k queue alone, no staging, barriers or write-out
+    for (int s = 0; s < T; s++) {
+      pn = v.seginfo[ps + 1 == T ? 0 : ps + 1];
+      if constexpr (SINGLES) pnk = v.segk[ps + 1 == T ? 0 : ps + 1];
+      int rows = v.seginfo[s].z;
+      asm volatile("" : "+s"(pn.x), "+s"(pn.y), "+s"(pn.z), "+s"(rows));
+      int q = 0;
+      for (; q + 2 * NB <= rows; q += 2 * NB) { consume(G0); load_batch(G0); consume(G1); load_batch(G1); }
+      if (q < rows) {
+        consume(G0);
+#pragma unroll
+        for (int x = 0; x < NB; x++) {
+          G0.w[x].x = G1.w[x].x; G0.w[x].y = G1.w[x].y;
+          if constexpr (TMODE) { G0.p[x].x = G1.p[x].x; G0.p[x].y = G1.p[x].y; G0.p[x].z = G1.p[x].z; G0.p[x].w = G1.p[x].w; }
+          else { G0.k[x].x = G1.k[x].x; G0.k[x].y = G1.k[x].y; }
+        }
+        load_batch(G1);
+      }
+    }
+    if (b >= 0) continue;
+#endif
     store_hubs();
     if (csrc >= 0) u_s[h + TILED_DUMMY + tid] = ucn;
     // the state's first window is not prefetched (the registers carry the hubs across the state boundary): one exposed
@@ -208,10 +256,12 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       const bool last = s == T - 1;
       if (last) load_hubs(bn); else load_window(b, s + 1);
       pn = v.seginfo[ps + 1 == T ? 0 : ps + 1];
+      if constexpr (SINGLES) pnk = v.segk[ps + 1 == T ? 0 : ps + 1];
       int rows = v.seginfo[s].z;
       // the scalar loads above are waited for HERE, behind the barrier: left to the compiler, the wait (lgkmcnt(0), which
       // also drains the wave's LDS queue) lands on the join inside the record loop, once per batch
       asm volatile("" : "+s"(pn.x), "+s"(pn.y), "+s"(pn.z), "+s"(rows));
+      if constexpr (SINGLES) asm volatile("" : "+s"(pn.w), "+s"(pnk));
       int q = 0;
       for (; q + 2 * NB <= rows; q += 2 * NB) {
         consume(G0);
@@ -251,6 +301,9 @@ __global__ __launch_bounds__(BS) void tiled_sweep_kernel(TiledView v, int B, con
       // (after the last segment the next state's head is stored at the top of the loop, before its barrier)
     }
   }
+#if defined(KIN_TILED_PROBE)
+  if (probe_acc == 12345.678) du[0] = probe_acc;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -282,9 +335,11 @@ __global__ __launch_bounds__(256) void tiled_params_kernel(int P, const int32_t*
   par[p] = o;
 }
 
-// rate table in library order: table[s][2 p], table[s][2 p + 1] = forward / reverse rate constant of record p at T[s]
-__global__ __launch_bounds__(256) void rate_table_lib_kernel(int P, int n_stops, const double4* __restrict__ par, int has_kmax,
-                                                             double inv_kmax, const double* __restrict__ T, double* __restrict__ table) {
+// rate table in library order: table[s][slot], table[s][slot + 1] = forward / reverse rate constant of record p at T[s]
+// (kslot[p] >= 0: a two-slot record; ~slot: a one-slot record, forward constant only; KL = slots per row)
+__global__ __launch_bounds__(256) void rate_table_lib_kernel(int P, int64_t KL, int n_stops, const double4* __restrict__ par,
+                                                             const int32_t* __restrict__ kslot, TiledPadSlots pads, int has_kmax, double inv_kmax,
+                                                             const double* __restrict__ T, double* __restrict__ table) {
   constexpr int ROWS = 32;
   __shared__ double rt_s[ROWS], irt_s[ROWS];
   __shared__ double tab_s[512];
@@ -298,13 +353,21 @@ __global__ __launch_bounds__(256) void rate_table_lib_kernel(int P, int n_stops,
   }
   __syncthreads();
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < pads.n) for (int s = s0; s < s1; s++) table[(size_t)s * KL + pads.slot[p]] = 0.0;
   if (p >= P) return;
   const double4 q = par[p];
+  const int32_t ks = kslot[p];
+  const bool two = ks >= 0;
+  const size_t slot = (size_t)(two ? ks : ~ks);
   for (int s = s0; s < s1; s++) {
     const double RT = rt_s[s - s0], inv_RT = irt_s[s - s0];
     const double kf = arrhenius_fast(q.x, q.y, q.y, RT, inv_RT, has_kmax, inv_kmax, tab_s);
-    const double kr = arrhenius_fast(q.z, q.w, q.w, RT, inv_RT, has_kmax, inv_kmax, tab_s);
-    *reinterpret_cast<double2*>(table + ((size_t)s * P + p) * 2) = make_double2(kf, kr);
+    if (two) {
+      const double kr = arrhenius_fast(q.z, q.w, q.w, RT, inv_RT, has_kmax, inv_kmax, tab_s);
+      *reinterpret_cast<double2*>(table + (size_t)s * KL + slot) = make_double2(kf, kr);
+    } else {
+      table[(size_t)s * KL + slot] = kf;
+    }
   }
 }
 
@@ -323,20 +386,20 @@ void launch_tiled_params(int P, const int32_t* kf, const int32_t* kr, const doub
   KIN_HIP(hipGetLastError());
 }
 
-void launch_rate_table_lib(int P, int64_t n_stops, const void* par, int has_kmax, double k_max, const double* T, double* table,
-                           hipStream_t s) {
+void launch_rate_table_lib(int P, int64_t KL, int64_t n_stops, const void* par, const int32_t* kslot, const TiledPadSlots& pads,
+                           int has_kmax, double k_max, const double* T, double* table, hipStream_t s) {
   if (P == 0 || n_stops == 0) return;
   dim3 grid((unsigned)ceil_div(P, 256), (unsigned)ceil_div(n_stops, 32));
-  hipLaunchKernelGGL(rate_table_lib_kernel, grid, dim3(256), 0, s, P, (int)n_stops, (const double4*)par, has_kmax, 1.0 / k_max, T, table);
+  hipLaunchKernelGGL(rate_table_lib_kernel, grid, dim3(256), 0, s, P, KL, (int)n_stops, (const double4*)par, kslot, pads, has_kmax, 1.0 / k_max, T, table);
   KIN_HIP(hipGetLastError());
 }
 
-template <int BS, bool TMODE, int UN>
+template <int BS, bool TMODE, int UN, bool SINGLES>
 static void launch_tiled_t(const TiledView& v, int grid, size_t smem, int B, const double* u, const double* k_lib, const double* Tb,
                            double* du, hipStream_t s) {
   // per launch, not cached: the attribute belongs to the (function, device) pair and costs ~1 us
-  KIN_HIP(hipFuncSetAttribute((const void*)tiled_sweep_kernel<BS, TMODE, UN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL((tiled_sweep_kernel<BS, TMODE, UN>), dim3(grid), dim3(BS), smem, s, v, B, u, k_lib, Tb, du);
+  KIN_HIP(hipFuncSetAttribute((const void*)tiled_sweep_kernel<BS, TMODE, UN, SINGLES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((tiled_sweep_kernel<BS, TMODE, UN, SINGLES>), dim3(grid), dim3(BS), smem, s, v, B, u, k_lib, Tb, du);
 }
 
 void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const double* u, const double* k_lib, const double* Tb,
@@ -347,12 +410,15 @@ void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const d
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / bs, (160 * 1024) / smem));
   const int grid = (int)std::min<int64_t>(B, (int64_t)n_cu * per_cu);
   const bool un5 = std::max(v.h, v.win_cnt_max) <= 5 * bs;
-#define KIN_TILED_GO(BSZ)                                                                      \
-  do {                                                                                         \
-    if (tmode) { if (un5) launch_tiled_t<BSZ, true, 5>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);      \
-                 else launch_tiled_t<BSZ, true, 10>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }       \
-    else { if (un5) launch_tiled_t<BSZ, false, 5>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);           \
-           else launch_tiled_t<BSZ, false, 10>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }            \
+  const bool singles = !tmode && v.has_singles;   // (the temperature form reads no rate constants: one instantiation)
+#define KIN_TILED_GO(BSZ)                                                                                  \
+  do {                                                                                                     \
+    if (tmode) { if (un5) launch_tiled_t<BSZ, true, 5, false>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);           \
+                 else launch_tiled_t<BSZ, true, 10, false>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }            \
+    else if (singles) { if (un5) launch_tiled_t<BSZ, false, 5, true>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);    \
+                        else launch_tiled_t<BSZ, false, 10, true>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }     \
+    else { if (un5) launch_tiled_t<BSZ, false, 5, false>(v, grid, smem, (int)B, u, k_lib, Tb, du, s);                \
+           else launch_tiled_t<BSZ, false, 10, false>(v, grid, smem, (int)B, u, k_lib, Tb, du, s); }                 \
   } while (0)
   if (bs == 256) KIN_TILED_GO(256);
   else if (bs == 512) KIN_TILED_GO(512);

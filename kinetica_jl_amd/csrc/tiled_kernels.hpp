@@ -7,18 +7,22 @@ namespace kin {
 
 struct TiledView {   // passed to the kernel by value
   int N, P, h, n_copy, wbase, E, T, win_cnt_max;
+  int64_t KL;              // rate-constant slots of a k_lib row
+  int has_singles;         // some segment ends in one-slot records (tiled.hpp)
   const uint2* rec;
   const int32_t* copy_src;
   // per segment, inside the kernel arguments (read with scalar loads from the kernarg segment, never through the
-  // vector memory path): first record, records, iteration rows (>= TILED_GROUP, a multiple of it), 0; the window
+  // vector memory path): first record, records, iteration rows (>= TILED_GROUP, a multiple of it), two-slot records;
+  // slot of the segment's first record; the window
   int4 seginfo[TILED_MAX_SEG];
+  int32_t segk[TILED_MAX_SEG];
   int32_t win_off[TILED_MAX_SEG], win_cnt[TILED_MAX_SEG];
   const double4* par;      // Arrhenius parameters per record (TMODE and the library-order rate table)
   int has_kmax;
   double inv_kmax;
 };
 
-// Exactly one of k_lib (B x 2P rate constants in library order) and Tb (B temperatures, device) is non-null.
+// Exactly one of k_lib (B x KL rate constants in library order) and Tb (B temperatures, device) is non-null.
 // u, du: B x N in library species order. n_cu: compute units of the device the stream belongs to.
 void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const double* u, const double* k_lib, const double* Tb,
                         double* du, hipStream_t s);
@@ -26,7 +30,8 @@ void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const d
 void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* map, const double* src, double* dst, hipStream_t s);
 void launch_tiled_params(int P, const int32_t* kf, const int32_t* kr, const double* Ea, const double* A, int has_kmax,
                          double t_mult, void* par, hipStream_t s);
-void launch_rate_table_lib(int P, int64_t n_stops, const void* par, int has_kmax, double k_max, const double* T, double* table,
-                           hipStream_t s);
+struct TiledPadSlots { int n; int32_t slot[TILED_MAX_SEG]; };   // slots of a k_lib row that no record owns
+void launch_rate_table_lib(int P, int64_t KL, int64_t n_stops, const void* par, const int32_t* kslot, const TiledPadSlots& pads,
+                           int has_kmax, double k_max, const double* T, double* table, hipStream_t s);
 
 }  // namespace kin

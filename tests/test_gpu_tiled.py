@@ -266,3 +266,55 @@ def test_full_size_c3_elementwise_and_c5_tiled_sweep():
             bound = (2 * (Ea.max() / (R_GAS * T[b])) + 16) * 2.0 ** -53
             assert np.all(np.abs(duT[b] - on.rhs(k, U[b])) <= (bound + TOL) * on.abs_rhs(k, U[b]) + 1e-300), (n, b)
         h.close()
+
+
+@pytest.mark.parametrize("entries", [None, "1400"], ids=["one_window", "windows"])
+def test_one_slot_records_after_the_low_k_cutoff(monkeypatch, entries):
+    """A network that lost 30 % of its reactions (apply_low_k_cutoff!, solve_utils.jl:213-245): the records without a reverse
+    take one rate-constant slot each at the end of their window - the kernel's SINGLES instantiation. k-stream form through
+    the layout conversions, the library-order rate table against the plain one, the temperature form, all against the oracle;
+    the plain two-slot layout of the same network (KIN_TILED_SINGLES=0) passes the same check."""
+    if entries:
+        monkeypatch.setenv("KIN_TILED_ENTRIES", entries)
+    n, r, B = 3000, 15000, 37
+    net0, Ea0, A0 = synthetic_crn(n, r)
+    keep = np.sort(np.random.default_rng(21).choice(r, int(0.7 * r), replace=False))
+    net, Ea, A = net0.subset(keep), Ea0[keep], A0[keep]
+    R2 = net.n_reactions
+    U = _states(B, n, 3)
+    K = 10.0 ** np.random.default_rng(4).uniform(-3, 3, (B, R2))
+    h = capi.HipNetwork.from_flat(net)
+    du, lay = _tiled_k(h, U, K)
+    assert R2 <= lay["k_len"] < R2 + 130 * lay["windows"] and lay["k_len"] < 2 * lay["records"]
+    assert (lay["windows"] > 1) == bool(entries)
+    _check_against_oracle(net, du, U, K, range(B))
+    # rate table in library order = the plain table, permuted; the sweep fed with it against the temperature form
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    T = np.linspace(600.0, 1400.0, B)
+    d_tl = torch.full((B, lay["k_len"]), float("nan"), dtype=torch.float64, device="cuda")
+    d_t = torch.empty((B, R2), dtype=torch.float64, device="cuda")
+    _sync()
+    h.rate_table_lib_dev(T, d_tl.data_ptr())
+    _sync()
+    h.rate_table_dev(T, d_t.data_ptr())
+    tl, t = d_tl.cpu().numpy(), d_t.cpu().numpy()
+    assert np.array_equal(tl[:, lay["slot_of_reaction"]], t)
+    unowned = np.ones(lay["k_len"], bool); unowned[lay["slot_of_reaction"]] = False
+    assert np.all(tl[:, unowned] == 0.0)                     # missing reverses and padding slots: written, zero
+    d_ul = _dev(U[:, lay["species_of_lib"]])
+    d_a, d_b, d_T = torch.full_like(d_ul, float("nan")), torch.full_like(d_ul, float("nan")), _dev(T)
+    _sync()
+    h.rhs_tiled_dev(B, d_ul.data_ptr(), d_a.data_ptr(), d_k_lib=d_tl.data_ptr())
+    h.rhs_tiled_dev(B, d_ul.data_ptr(), d_b.data_ptr(), d_T=d_T.data_ptr())
+    torch.cuda.synchronize()
+    on = orc.OracleNetwork.from_flat(net)
+    scale = np.stack([on.abs_rhs(t[b], U[b]) for b in range(B)])[:, lay["species_of_lib"]]
+    assert np.all(np.abs(d_a.cpu().numpy() - d_b.cpu().numpy()) <= 2e-13 * scale + 1e-300)
+    h.close()
+    # the two-slot layout of the same network
+    monkeypatch.setenv("KIN_TILED_SINGLES", "0")
+    h2 = capi.HipNetwork.from_flat(net)
+    du2, lay2 = _tiled_k(h2, U, K)
+    assert lay2["k_len"] == 2 * lay2["records"] and lay2["records"] == lay["records"]
+    _check_against_oracle(net, du2, U, K, range(B))
+    h2.close()

@@ -21,7 +21,7 @@ def _check(net, seed=0, hubs=0):
     sp = L["species_of_lib"]
     assert sorted(sp) == list(range(N))
     slots = L["slot_of_reaction"]
-    assert len(set(slots)) == R and slots.min() >= 0 and slots.max() < 2 * L["P"]
+    assert len(set(slots)) == R and slots.min() >= 0 and slots.max() < L["k_len"] <= 2 * L["P"] + 2 * L["T"]
     assert L["win_cnt"].sum() + L["h"] == N
     assert all(q % 2 == 0 for q in L["seg_q"]) and all(b - a >= 8 for a, b in zip(L["seg_q"][:-1], L["seg_q"][1:]))
     du_lib = replay(L, u[sp], k_to_lib(L, k))
@@ -58,10 +58,20 @@ def test_windows_on_a_small_network(monkeypatch):
     # every record of a segment touches no other window: implied by the replay (foreign entries are NaN there)
 
 
-def test_low_k_cutoff_leftovers_stay_tileable():
+def test_low_k_cutoff_leftovers_stay_tileable(monkeypatch):
+    """What apply_low_k_cutoff! (solve_utils.jl:213-245) leaves behind: many reactions without their reverse. They come last
+    in their window and take one rate-constant slot each, so the k row is (nearly) as long as the reactions are many."""
     net, _, _ = synthetic_crn(1000, 5000)
     keep = np.sort(np.random.default_rng(5).choice(5000, 3500, replace=False))
-    _check(net.subset(keep), seed=2)
+    L = _check(net.subset(keep), seed=2)
+    n_single = 2 * L["P"] - 3500              # records without a reverse
+    assert L["has_singles"] and n_single > 500
+    assert 3500 <= L["k_len"] <= 3500 + 2 * 64 * L["T"]
+    assert np.all(L["seg_k"][:, 1] % 64 == 0)
+    # the plain layout (two slots for every record) on request: same records, longer row
+    monkeypatch.setenv("KIN_TILED_SINGLES", "0")
+    L0 = _check(net.subset(keep), seed=2)
+    assert not L0["has_singles"] and L0["k_len"] == 2 * L0["P"] and L0["P"] == L["P"]
 
 
 def test_c5_size_layout():
@@ -83,3 +93,51 @@ def test_window_capacity_follows_the_rounded_window_base(monkeypatch, cap, hubs)
     assert L["T"] > 1
     assert L["wbase"] % 2 == 0 and L["E"] % 2 == 0
     assert L["wbase"] + int(L["win_cnt"].max()) <= L["E"] <= cap
+
+
+def _group_cycles(L):
+    """LDS cycles per (16-lane group, field) of the records' ds_add_f64 under the bank rule tools/lds_group_probe.hip
+    measures: labels of one group that share a bank (label mod 16) serialise."""
+    w = L["rec"].astype(np.uint64)
+    fl = ((w >> np.uint64(56)) & np.uint64(7)).astype(np.int64)
+    sq, rt = L["seg_q"], L["rowtab"]
+    cycles = groups = 0
+    for s in range(len(sq) - 1):
+        base, n = int(rt[sq[s]][0]), int(rt[sq[s]:sq[s + 1], 1].sum())
+        for j, sh in enumerate((0, 14, 28, 42)):
+            lab = ((w[base:base + n] >> np.uint64(sh)) & np.uint64(0x3fff)).astype(np.int64)
+            f = fl[base:base + n]
+            use = (f & 4) == 0
+            if j == 1:
+                use &= (f & 1) != 0
+            if j == 3:
+                use &= (f & 2) != 0
+            for g in range(0, n, 16):
+                b = lab[g:g + 16][use[g:g + 16]] % 16
+                if len(b):
+                    cycles += np.bincount(b, minlength=16).max()
+                    groups += 1
+    return cycles / groups
+
+
+def test_record_order_spreads_a_lane_groups_labels_over_the_banks(monkeypatch):
+    """The library order places the records (and picks reactant / product order, the forward role of a pair and the split
+    hubs' accumulator entries) so that the 16 lanes of a group hit different LDS banks: 3 cycles per group and field in the
+    plain order of the synthetic CRN, about half of that scheduled. Both orders replay to the oracle's RHS."""
+    net, _, _ = synthetic_crn(10000, 50000)
+    L1 = _check(net, seed=7)
+    monkeypatch.setenv("KIN_TILED_SCHEDULE", "0")
+    L0 = _check(net, seed=7)
+    c1, c0 = _group_cycles(L1), _group_cycles(L0)
+    assert c0 > 2.7 and c1 < 1.75, (c0, c1)
+    # the same records, reordered: every reaction keeps exactly one rate-constant slot
+    assert L0["P"] == L1["P"] and sorted(L0["slot_of_reaction"]) == sorted(L1["slot_of_reaction"])
+
+
+def test_scheduled_order_with_windows_and_unpaired_reactions(monkeypatch):
+    monkeypatch.setenv("KIN_TILED_ENTRIES", "1400")
+    net, _, _ = synthetic_crn(3000, 15000)
+    keep = np.sort(np.random.default_rng(11).choice(15000, 10500, replace=False))
+    L = _check(net.subset(keep), seed=8)
+    assert L["T"] > 1
+    assert _group_cycles(L) < 2.0

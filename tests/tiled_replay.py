@@ -8,7 +8,7 @@ import numpy as np
 
 
 def replay(L, u_lib, k_lib):
-    """du_lib for one state. L = capi.lib_layout_host(net); u_lib[N], k_lib[2 P] in library order."""
+    """du_lib for one state. L = capi.lib_layout_host(net); u_lib[N], k_lib[k_len] in library order."""
     h, T, E, wbase, BS, n_copy = L["h"], L["T"], L["E"], L["wbase"], L["BS"], L["n_copy"]
     N = len(u_lib)
     du_lib = np.full(N, np.nan)
@@ -21,6 +21,9 @@ def replay(L, u_lib, k_lib):
     rec = L["rec"]
     for s in range(T):
         off, cnt = int(L["win_off"][s]), int(L["win_cnt"][s])
+        koff, n2 = int(L["seg_k"][s, 0]), int(L["seg_k"][s, 1])
+        seg_first = int(L["rowtab"][int(L["seg_q"][s]), 0])
+        assert koff % 2 == 0 and (n2 % 64 == 0 or seg_first < 0 or n2 == int(L["rowtab"][int(L["seg_q"][s]):int(L["seg_q"][s + 1]), 1].sum()))
         u_s[wbase:wbase + cnt] = u_lib[off:off + cnt]
         for q in range(int(L["seg_q"][s]), int(L["seg_q"][s + 1])):
             first, n = int(L["rowtab"][q, 0]), int(L["rowtab"][q, 1])
@@ -39,8 +42,12 @@ def replay(L, u_lib, k_lib):
             # a record that uses a field lies in a group whose flag for it is set
             uf = u_s[l[0]] * np.where(has1, u_s[l[1]], 1.0)
             ur = u_s[l[2]] * np.where(has3, u_s[l[3]], 1.0)
-            p = first + np.arange(n)
-            net = k_lib[2 * p] * uf - k_lib[2 * p + 1] * ur
+            # rate constants: two slots per record below n2 (position in the segment), one from there on (tiled.hpp)
+            i = first - seg_first + np.arange(n)
+            two = i < n2
+            kf = k_lib[koff + np.where(two, 2 * i, n2 + i)]
+            kr = np.where(two, k_lib[np.minimum(koff + 2 * i + 1, len(k_lib) - 1)], 0.0)
+            net = kf * uf - kr * ur
             assert np.all(np.isfinite(net))
             np.add.at(du_s, l[0], -net)
             np.add.at(du_s, l[1][has1], -net[has1])
@@ -58,6 +65,6 @@ def replay(L, u_lib, k_lib):
 
 
 def k_to_lib(L, k):
-    out = np.zeros(2 * L["P"])
+    out = np.zeros(L["k_len"])
     out[L["slot_of_reaction"]] = k
     return out
