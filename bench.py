@@ -464,6 +464,47 @@ def main():
             return res
         guarded(out, "tiled_sweep", tiled_all)
 
+        def post_cutoff_leg():
+            # what apply_low_k_cutoff! (solve_utils.jl:213-245) leaves behind: the C3 CRN without a random 30 % of its reactions
+            # - pairs broken, the records without a reverse at one rate-constant slot in library order. Algorithmic bytes of the
+            # network that is left; the caller's layouts (kin::sweep_gen_kernel) and the library order next to each other.
+            keep = np.sort(np.random.default_rng(0).choice(R, int(0.7 * R), replace=False))
+            net_p = net.subset(keep)
+            Rp = net_p.n_reactions
+            hp = capi.HipNetwork.from_flat(net_p)
+            try:
+                hp.set_arrhenius(Ea[keep], A[keep], k_max=1e12)
+                lay = hp.lib_layout()
+                k_p = torch.rand((B, Rp), dtype=torch.float64, device=dev, generator=g) + 0.5
+                du_p = torch.empty_like(d_u)
+                kl_p = torch.empty((B, lay["k_len"]), dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()
+                hp.rate_table_lib_dev(T.cpu().numpy(), kl_p.data_ptr())
+                alg = 20 * Rp + B * (8 * Rp + 16 * N)
+
+                def ev(fn, reps=10):
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(reps):
+                        fn()
+                    b.record(); torch.cuda.synchronize()
+                    return a.elapsed_time(b) / reps
+                ms_c = ev(lambda: hp.rhs_batched_dev(B, d_u.data_ptr(), k_p.data_ptr(), du_p.data_ptr(), stream))
+                # (the states in the library's species order: the caller's at this size)
+                ms_l = ev(lambda: hp.rhs_tiled_dev(B, d_u.data_ptr(), du_p.data_ptr(), d_k_lib=kl_p.data_ptr(), stream=stream))
+                del k_p, du_p, kl_p
+                return {"network": "C3 CRN minus a random 30 % of its reactions", "species": N, "reactions": Rp, "states": B,
+                        "records": lay["records"], "k_len": lay["k_len"], "algorithmic_GB": alg / 1e9,
+                        "callers_layouts": {"kernel": "kin::sweep_gen_kernel", "ms": ms_c, "frac_of_8TBps": alg / (ms_c * 1e-3) / 8e12},
+                        "library_order": {"kernel": "kin::tiled_sweep_kernel, one-slot records", "ms": ms_l,
+                                          "frac_of_8TBps": alg / (ms_l * 1e-3) / 8e12}}
+            finally:
+                hp.close()
+        guarded(out, "post_cutoff_sweep", post_cutoff_leg)
+
     # ---- ONE trajectory's RHS with the reactions split over the ranks and an all-reduce of du (N doubles):
     # measured at N > 1 so that the cost of the single-trajectory decomposition is a number, not an argument
     if world > 1:

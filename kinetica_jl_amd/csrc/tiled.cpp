@@ -230,7 +230,7 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   // labels differ mod 16, 9-11 ns for random labels, 8.4 ns for two lanes of a group on one address; lanes of different
   // groups never conflict). Unscheduled, the labels of the synthetic CRNs cost 3.0 LDS cycles per group and field; with the
   // schedule 1.2-1.5 (the bank loads of a class are not uniform, so some conflicts must stay). SQ_LDS_BANK_CONFLICT of the
-  // C5 sweep: 78 M -> 18 M cycles per launch, LDS-active cycles 202 M -> 101 M (profiles/r04_c5_tiled_pmc.json).
+  // C5 sweep: 78 M -> 23 M cycles per launch, LDS-active cycles 202 M -> 107 M (profiles/r04_c5_tiled_pmc.json).
   // KIN_TILED_SCHEDULE=0 keeps the plain order (A/B), KIN_TILED_SCAN sets the number of candidates in sight: 256 keeps the
   // library order close to the caller's reaction order (kin_rates_to_lib_dev gathers from a narrow range per wavefront) and
   // is as fast in the sweep as 2 048.

@@ -58,9 +58,16 @@ def build():
         add("tiled sweep", f"{cfg} ({ts[cfg]['species']} / {ts[cfg]['reactions']}, B = {ts[cfg]['states']}), k-stream form",
             f"{k['ms']:.3f} ms = {k['frac_of_8TBps']:.3f} of 8 TB/s", f"{src_b} `tiled_sweep.{cfg}.k_stream`")
         add("tiled sweep", f"{cfg}, temperature form (no k)", f"{t['ms']:.3f} ms = {t['evals_per_s'] / 1e6:.2f} M evals/s", f"{src_b} `tiled_sweep.{cfg}.temperature_form`")
-    t5 = load("r03_c5_tiled_pmc.json")
-    if "traffic_over_algorithmic" in t5:
-        add("tiled sweep", "C5 k-stream, PMC traffic / algorithmic (kernel unchanged since round 3)", f"{t5['traffic_over_algorithmic']:.3f}", "r03_c5_tiled_pmc.json")
+    pc = b.get("post_cutoff_sweep")
+    if pc and "library_order" in pc:
+        add("post-cutoff sweep", f"{pc['network']} ({pc['reactions']} reactions, {pc['records']} records, k row {pc['k_len']} doubles): caller's layouts / library order",
+            f"{pc['callers_layouts']['ms']:.3f} ms = {pc['callers_layouts']['frac_of_8TBps']:.3f} / {pc['library_order']['ms']:.3f} ms = {pc['library_order']['frac_of_8TBps']:.3f} of 8 TB/s",
+            f"{src_b} `post_cutoff_sweep`")
+    for cfg in ("c3", "c5"):
+        dv = load(f"{TAG}_{cfg}_tiled_pmc.json")["derived"]
+        add("tiled sweep", f"{cfg.upper()} k-stream under rocprofv3: PMC traffic / algorithmic; LDS bank-conflict cycles per launch, plain → bank-aware record order; LDS-active cycles",
+            f"{dv['k_stream_traffic_over_algorithmic']:.3f}; {dv['lds_bank_conflict_cycles'][0] / 1e6:.0f} M → {dv['lds_bank_conflict_cycles'][1] / 1e6:.0f} M; "
+            f"{dv['lds_active_cycles'][0] / 1e6:.0f} M → {dv['lds_active_cycles'][1] / 1e6:.0f} M", f"{TAG}_{cfg}_tiled_pmc.json `derived`")
 
     ct = load(f"{TAG}_c5_table_pmc.json")
     for kr in ct["kernels"]:
