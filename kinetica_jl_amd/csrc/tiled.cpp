@@ -228,12 +228,12 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   // executed in four groups of 16 contiguous lanes over 16 banks of 8 bytes (bank = label mod 16), a ds_read_b64 in two
   // halves of 32 lanes over 32 banks (tools/lds_group_probe.hip: ds_add_f64 3.4 ns per wave instruction when a group's
   // labels differ mod 16, 9-11 ns for random labels, 8.4 ns for two lanes of a group on one address; lanes of different
-  // groups never conflict). Unscheduled, the labels of the synthetic CRNs cost 3.0 LDS cycles per group and field; with the
-  // schedule 1.2-1.5 (the bank loads of a class are not uniform, so some conflicts must stay). SQ_LDS_BANK_CONFLICT of the
-  // C5 sweep: 78 M -> 23 M cycles per launch, LDS-active cycles 202 M -> 107 M (profiles/r04_c5_tiled_pmc.json).
-  // KIN_TILED_SCHEDULE=0 keeps the plain order (A/B), KIN_TILED_SCAN sets the number of candidates in sight: 256 keeps the
-  // library order close to the caller's reaction order (kin_rates_to_lib_dev gathers from a narrow range per wavefront) and
-  // is as fast in the sweep as 2 048.
+  // groups never conflict). Unscheduled, the labels of the synthetic CRNs cost 3.0 LDS cycles per group and field; placed
+  // from a reservoir of 256-2 048 candidates 1.2-1.5, placed inside chunks of 64 records (the default) 2.0. The sweeps are as
+  // fast with the one as with the other (profiles/r04_tiled_schedule_ab.txt: after the first third of the conflicts is gone
+  // the kernel no longer waits for the LDS), and the chunked order keeps kin_rates_to_lib_dev's gathers as local as the plain
+  // order does (C3: 0.79 ms plain, 0.82 chunked, 1.13 with the reservoir of 256).
+  // KIN_TILED_SCHEDULE=0 keeps the plain order (A/B), KIN_TILED_SCAN sets the number of candidates in sight.
   const bool schedule = !(getenv("KIN_TILED_SCHEDULE") && atoi(getenv("KIN_TILED_SCHEDULE")) == 0);
   // Records without a reverse reaction (what the low-k cutoff leaves of a pair, solve_utils.jl:213-245) come last in their
   // segment and take ONE rate-constant slot there; the records before them - all pairs, filled up to whole wavefronts with
@@ -243,8 +243,12 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   for (const Rec& q : recs) n_single += q.kr < 0;
   const bool compact = n_single * 20 >= (int64_t)P && !(getenv("KIN_TILED_SINGLES") && atoi(getenv("KIN_TILED_SINGLES")) == 0);
   auto kind = [&](int32_t p) { return compact && recs[p].kr < 0 ? 4 : 0; };
-  int SCAN = 256;          // candidates in sight per position
+  int SCAN = 64;           // candidates in sight per position
   if (const char* e = getenv("KIN_TILED_SCAN")) SCAN = std::max(16, atoi(e));
+  // chunked (default): the candidates are the next SCAN records in the caller's reaction order and all of them are placed before
+  // the next SCAN come in sight - the library order is the caller's, permuted inside chunks of one wavefront's records;
+  // KIN_TILED_CHUNKED=0: a reservoir that is topped up after every placement (fewer conflicts, a wider scramble)
+  const bool chunked = !(getenv("KIN_TILED_CHUNKED") && atoi(getenv("KIN_TILED_CHUNKED")) == 0);
   int64_t sched_slots = 0, sched_conflicts = 0, dbg_defer = 0;
   double dbg_sec = 0.0;
   for (int t = 0; t < T; t++) {
@@ -304,8 +308,8 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
         const int c_run = cls(seg[t][a]), k_run = kind(seg[t][a]);
         while (b < n && cls(seg[t][b]) == c_run && kind(seg[t][b]) == k_run) b++;
         const bool live[4] = {true, (c_run & 1) != 0, true, (c_run & 2) != 0};
-        // the candidates in sight: a reservoir that is topped up in the caller's reaction order (the conversion of rate
-        // constants to the library order then gathers from a narrow range per wavefront)
+        // the candidates in sight, taken in the caller's reaction order (the conversion of rate constants to the library order
+        // then gathers from a narrow range per wavefront)
         std::vector<Cand> pool;
         pool.reserve(SCAN + deferred.size());
         for (size_t d = 0; d < deferred.size();)
@@ -314,7 +318,7 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
         int32_t next = a;
         size_t cur = 0;
         for (;;) {
-          while (pool.size() < (size_t)SCAN && next < b) pool.push_back(make_cand(seg[t][next++]));
+          if (!chunked || pool.empty()) while (pool.size() < (size_t)SCAN && next < b) pool.push_back(make_cand(seg[t][next++]));
           if (pool.empty()) break;
           if ((i & 15) == 0) used[0] = used[1] = used[2] = used[3] = 0;
           if ((i & 31) == 0) used32[0] = used32[1] = used32[2] = used32[3] = 0;

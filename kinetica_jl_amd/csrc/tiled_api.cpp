@@ -156,7 +156,13 @@ int kin_rates_to_lib_dev(kin_network* h, int64_t B, const double* d_k, double* d
   KIN_TRY(h)
   require(B > 0 && d_k && d_k_lib && d_k != d_k_lib, ERR_INVALID_ARG, "bad arguments");
   ensure_tiled(h);
-  launch_gather_rows(h->tiled.k_len(), h->host.R, B, h->t_rxn_of_slot.p, d_k, d_k_lib, stream ? (hipStream_t)stream : h->stream);
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const TiledHost& L = h->tiled;
+  // record-wise (one 16-byte load per adjacent pair) when every record has two slots and the rows allow 16-byte accesses
+  if (L.KL == 2 * (int64_t)L.P && h->host.R % 2 == 0 && ((((uintptr_t)d_k) | ((uintptr_t)d_k_lib)) & 15) == 0)
+    launch_rates_to_lib_pairs(L.P, h->host.R, B, h->t_kf.p, h->t_kr.p, d_k, d_k_lib, s);
+  else
+    launch_gather_rows(L.k_len(), h->host.R, B, h->t_rxn_of_slot.p, d_k, d_k_lib, s);
   KIN_CATCH(h)
 }
 

@@ -318,6 +318,35 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n_dst, int64_t
   for (int b = blockIdx.y; b < B; b += gridDim.y) dst[(size_t)b * n_dst + j] = m >= 0 ? src[(size_t)b * n_src + m] : 0.0;
 }
 
+// k_lib[b][2 p], k_lib[b][2 p + 1] = k[b][kf[p]], k[b][kr[p]] for a layout whose records all have two slots (k_lib row = 2 P):
+// one thread per record. Where the caller keeps a reaction and its reverse next to each other at an even position - the
+// usual case - the pair travels as ONE 16-byte load (swapped when the library made the reverse the record's forward
+// reaction); otherwise two 8-byte gathers. The record order is the caller's reaction order scrambled within a few hundred
+// records (tiled.cpp), so a wavefront's loads fall into a few kB: the slot-wise gather above issues two instructions of 64
+// scattered 8-byte lanes for what is one instruction of 64 16-byte lanes here (C3: 1.13 -> see profiles, C5: 1.63 ->).
+__global__ __launch_bounds__(256) void rates_to_lib_pairs_kernel(int P, int64_t R, int B, const int32_t* __restrict__ kf,
+                                                                 const int32_t* __restrict__ kr, const double* __restrict__ src,
+                                                                 double* __restrict__ dst) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int f = kf[p], r = kr[p];
+  const bool straight = r == f + 1 && (f & 1) == 0, flipped = f == r + 1 && (r & 1) == 0;
+  const size_t lo = (size_t)(straight ? f : (flipped ? r : 0));
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const double* sb = src + (size_t)b * R;
+    double2 v;
+    if (straight || flipped) {
+      const double2 w = *reinterpret_cast<const double2*>(sb + lo);
+      v.x = flipped ? w.y : w.x;
+      v.y = flipped ? w.x : w.y;
+    } else {
+      v.x = sb[f];
+      v.y = r >= 0 ? sb[r] : 0.0;
+    }
+    *reinterpret_cast<double2*>(dst + ((size_t)b * P + p) * 2) = v;
+  }
+}
+
 // par[p] = (Ea_f, X_f, Ea_r, X_r), X = 1 / (A N_A t_mult) when the calculator caps its rate constants (the sweep and the
 // table kernel evaluate 1 / (1/k_max + X e^q)), else A N_A t_mult. A missing reverse: a constant that makes k = 0.
 __global__ __launch_bounds__(256) void tiled_params_kernel(int P, const int32_t* __restrict__ kf, const int32_t* __restrict__ kr,
@@ -375,6 +404,14 @@ void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* 
   if (n_dst == 0 || B == 0) return;
   dim3 grid((unsigned)ceil_div(n_dst, 256), (unsigned)std::min<int64_t>(B, 1024));
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, s, n_dst, n_src, (int)B, map, src, dst);
+  KIN_HIP(hipGetLastError());
+}
+
+void launch_rates_to_lib_pairs(int P, int64_t R, int64_t B, const int32_t* kf, const int32_t* kr, const double* src, double* dst,
+                               hipStream_t s) {
+  if (P == 0 || B == 0) return;
+  dim3 grid((unsigned)ceil_div(P, 256), (unsigned)std::min<int64_t>(B, 1024));
+  hipLaunchKernelGGL(rates_to_lib_pairs_kernel, grid, dim3(256), 0, s, P, R, (int)B, kf, kr, src, dst);
   KIN_HIP(hipGetLastError());
 }
 

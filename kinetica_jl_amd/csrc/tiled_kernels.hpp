@@ -28,6 +28,10 @@ void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const d
                         double* du, hipStream_t s);
 // dst[b][j] = map[j] >= 0 ? src[b][map[j]] : 0 for b < B (rows of n_dst / n_src doubles): the layout conversions
 void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* map, const double* src, double* dst, hipStream_t s);
+// k_lib[b][2 p .. 2 p + 1] = k[b][kf[p]], k[b][kr[p]] (0 without a reverse): layouts whose records all have two slots; src rows of R
+// doubles, R even and src 16-byte aligned
+void launch_rates_to_lib_pairs(int P, int64_t R, int64_t B, const int32_t* kf, const int32_t* kr, const double* src, double* dst,
+                               hipStream_t s);
 void launch_tiled_params(int P, const int32_t* kf, const int32_t* kr, const double* Ea, const double* A, int has_kmax,
                          double t_mult, void* par, hipStream_t s);
 struct TiledPadSlots { int n; int32_t slot[TILED_MAX_SEG]; };   // slots of a k_lib row that no record owns

@@ -123,13 +123,16 @@ def _group_cycles(L):
 def test_record_order_spreads_a_lane_groups_labels_over_the_banks(monkeypatch):
     """The library order places the records (and picks reactant / product order, the forward role of a pair and the split
     hubs' accumulator entries) so that the 16 lanes of a group hit different LDS banks: 3 cycles per group and field in the
-    plain order of the synthetic CRN, about half of that scheduled. Both orders replay to the oracle's RHS."""
+    plain order of the synthetic CRN, 2 scheduled inside chunks of 64 records (the default), 1.5 from a reservoir. Both orders replay to the oracle's RHS."""
     net, _, _ = synthetic_crn(10000, 50000)
     L1 = _check(net, seed=7)
     monkeypatch.setenv("KIN_TILED_SCHEDULE", "0")
     L0 = _check(net, seed=7)
     c1, c0 = _group_cycles(L1), _group_cycles(L0)
-    assert c0 > 2.7 and c1 < 1.75, (c0, c1)
+    assert c0 > 2.7 and c1 < 2.25, (c0, c1)
+    # a reservoir of candidates instead of chunks of 64 records: fewer conflicts still (and a wider scramble of the order)
+    monkeypatch.setenv("KIN_TILED_SCHEDULE", "1"); monkeypatch.setenv("KIN_TILED_CHUNKED", "0"); monkeypatch.setenv("KIN_TILED_SCAN", "256")
+    assert _group_cycles(_check(net, seed=7)) < 1.75
     # the same records, reordered: every reaction keeps exactly one rate-constant slot
     assert L0["P"] == L1["P"] and sorted(L0["slot_of_reaction"]) == sorted(L1["slot_of_reaction"])
 
@@ -140,4 +143,4 @@ def test_scheduled_order_with_windows_and_unpaired_reactions(monkeypatch):
     keep = np.sort(np.random.default_rng(11).choice(15000, 10500, replace=False))
     L = _check(net.subset(keep), seed=8)
     assert L["T"] > 1
-    assert _group_cycles(L) < 2.0
+    assert _group_cycles(L) < 2.4

@@ -65,9 +65,10 @@ def build():
             f"{src_b} `post_cutoff_sweep`")
     for cfg in ("c3", "c5"):
         dv = load(f"{TAG}_{cfg}_tiled_pmc.json")["derived"]
-        add("tiled sweep", f"{cfg.upper()} k-stream under rocprofv3: PMC traffic / algorithmic; LDS bank-conflict cycles per launch, plain → bank-aware record order; LDS-active cycles",
-            f"{dv['k_stream_traffic_over_algorithmic']:.3f}; {dv['lds_bank_conflict_cycles'][0] / 1e6:.0f} M → {dv['lds_bank_conflict_cycles'][1] / 1e6:.0f} M; "
-            f"{dv['lds_active_cycles'][0] / 1e6:.0f} M → {dv['lds_active_cycles'][1] / 1e6:.0f} M", f"{TAG}_{cfg}_tiled_pmc.json `derived`")
+        bc, ac = dv["lds_bank_conflict_cycles"], dv["lds_active_cycles"]
+        add("tiled sweep", f"{cfg.upper()} k-stream under rocprofv3: PMC traffic / algorithmic; LDS bank-conflict cycles per launch, plain order → bank-aware inside chunks of 64 records (default) → from a reservoir of 256; LDS-active cycles",
+            f"{dv['k_stream_traffic_over_algorithmic']:.3f}; {bc[0] / 1e6:.0f} M → {bc[1] / 1e6:.0f} M → {bc[2] / 1e6:.0f} M; "
+            f"{ac[0] / 1e6:.0f} M → {ac[1] / 1e6:.0f} M → {ac[2] / 1e6:.0f} M", f"{TAG}_{cfg}_tiled_pmc.json `derived`")
 
     ct = load(f"{TAG}_c5_table_pmc.json")
     for kr in ct["kernels"]:
