@@ -321,9 +321,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n_dst, int64_t
 // k_lib[b][2 p], k_lib[b][2 p + 1] = k[b][kf[p]], k[b][kr[p]] for a layout whose records all have two slots (k_lib row = 2 P):
 // one thread per record. Where the caller keeps a reaction and its reverse next to each other at an even position - the
 // usual case - the pair travels as ONE 16-byte load (swapped when the library made the reverse the record's forward
-// reaction); otherwise two 8-byte gathers. The record order is the caller's reaction order scrambled within a few hundred
-// records (tiled.cpp), so a wavefront's loads fall into a few kB: the slot-wise gather above issues two instructions of 64
-// scattered 8-byte lanes for what is one instruction of 64 16-byte lanes here (C3: 1.13 -> see profiles, C5: 1.63 ->).
+// reaction); otherwise two 8-byte gathers. The record order is the caller's reaction order permuted inside chunks of 64
+// records (tiled.cpp), so a wavefront's loads fall into one kB: the slot-wise gather above issues two instructions of 64
+// scattered 8-byte lanes for what is one instruction of 64 16-byte lanes here (with the wider scramble of a 256-record
+// reservoir: C3 1.13 -> 1.06 ms, C5 1.63 -> 1.58 ms; with the chunked default 0.82 / 1.45 ms).
 __global__ __launch_bounds__(256) void rates_to_lib_pairs_kernel(int P, int64_t R, int B, const int32_t* __restrict__ kf,
                                                                  const int32_t* __restrict__ kr, const double* __restrict__ src,
                                                                  double* __restrict__ dst) {
