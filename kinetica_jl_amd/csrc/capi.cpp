@@ -8,6 +8,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -367,9 +368,14 @@ kin_network* clone_for_solves(kin_network* h) {
   return c.release();
 }
 
+int replica_threads_max();
+int64_t replica_members_max() {
+  if (const char* e = getenv("KIN_ENSEMBLE_THREADS_K")) return std::max<int64_t>(0, atoll(e));
+  return (int64_t)replica_threads_max();
+}
 int replica_threads_max() {
-  static const int v = getenv("KIN_ENSEMBLE_THREADS") ? atoi(getenv("KIN_ENSEMBLE_THREADS")) : 12;
-  return v;
+  const char* e = getenv("KIN_ENSEMBLE_THREADS");   // (read per call: tests change it)
+  return std::max(1, e ? atoi(e) : 12);
 }
 
 // A SMALL ensemble of a LARGE network: K independent kin_solve calls on K host threads, one solve-only copy of the handle each.
@@ -394,14 +400,21 @@ void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
       for (int i = 0; i < n; i++) { hipStream_t d = nullptr; if (hipStreamCreateWithFlags(&d, hipStreamNonBlocking) != hipSuccess) (void)hipGetLastError(); }
     });
   }
-  while ((int64_t)h->replicas.size() < K) {
+  // Tn threads, member m on thread m mod Tn (a thread solves its members one after the other on its own replica): K <= the
+  // thread limit gives every member its own thread, more members share the threads evenly
+  const int64_t per = ceil_div(K, (int64_t)replica_threads_max());
+  const int64_t Tn = ceil_div(K, per);
+  while ((int64_t)h->replicas.size() < Tn) {
     h->replicas.push_back(clone_for_solves(h));
-    h->replicas.back()->lu_budget_mb = (size_t)(200 * 1024) / (size_t)std::max<int64_t>(K, 6);   // K LU caches share ~200 GB of the 288
+    h->replicas.back()->lu_budget_mb = (size_t)(200 * 1024) / (size_t)std::max<int64_t>(Tn, 6);   // the LU caches share ~200 GB of the 288
   }
   KIN_HIP(hipStreamSynchronize(h->stream));
-  std::vector<std::string> errs((size_t)K);
+  std::vector<std::string> errs((size_t)Tn);
   std::vector<std::thread> th;
-  for (int64_t t = 0; t < K; t++)
+  // the save times are the members' common grid: those of the member that got furthest (the first of them)
+  std::mutex grid_mu;
+  int64_t grid_n = -1;
+  for (int64_t t = 0; t < Tn; t++)
     th.emplace_back([&, t] {
       try {
         kin_network* c = h->replicas[(size_t)t];
@@ -413,32 +426,34 @@ void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
           KIN_HIP(hipMemcpyAsync(c->A.p, h->A.p, (size_t)R * sizeof(double), hipMemcpyDeviceToDevice, s));
           c->has_arrhenius = true; c->has_kmax = h->has_kmax; c->k_max = h->k_max; c->t_mult = h->t_mult;
         }
-        if (n_stops == 0) {
-          if (k) KIN_HIP(hipMemcpyAsync(c->k.p, k + t * R, (size_t)R * sizeof(double), hipMemcpyHostToDevice, s));
-          else if (T) launch_arrhenius(R, c->Ea.p, c->A.p, c->has_kmax, c->k_max, c->t_mult, T[t], c->k.p, s);
-          else KIN_HIP(hipMemcpyAsync(c->k.p, h->k.p, (size_t)R * sizeof(double), hipMemcpyDeviceToDevice, s));
-          c->has_rates = true; c->k_pending = false;
+        for (int64_t m = t; m < K; m += Tn) {
+          if (n_stops == 0) {
+            if (k) KIN_HIP(hipMemcpyAsync(c->k.p, k + m * R, (size_t)R * sizeof(double), hipMemcpyHostToDevice, s));
+            else if (T) launch_arrhenius(R, c->Ea.p, c->A.p, c->has_kmax, c->k_max, c->t_mult, T[m], c->k.p, s);
+            else KIN_HIP(hipMemcpyAsync(c->k.p, h->k.p, (size_t)R * sizeof(double), hipMemcpyDeviceToDevice, s));
+            c->has_rates = true; c->k_pending = false;
+          }
+          KIN_HIP(hipStreamSynchronize(s));
+          kin_stats st{};
+          const int rc = solve_entry(c, p, u0 + m * N, tstops, T_stops, k_table, n_stops, &st);
+          if (retcodes) retcodes[m] = rc;
+          if (stats) stats[m] = st;
+          const int64_t ns = std::min<int64_t>(c->n_saved, cap);
+          if (n_saved) n_saved[m] = ns;
+          if (out_u && ns > 0) c->d_sol_u.download(out_u + (size_t)m * cap * N, (size_t)ns * N, s);
+          KIN_HIP(hipStreamSynchronize(s));
+          if (out_t) {
+            std::lock_guard<std::mutex> lock(grid_mu);
+            if (ns > grid_n) {
+              grid_n = ns;
+              for (int64_t i = 0; i < ns && i < (int64_t)c->sol_t.size(); i++) out_t[i] = c->sol_t[(size_t)i];
+            }
+          }
         }
-        KIN_HIP(hipStreamSynchronize(s));
-        kin_stats st{};
-        const int rc = solve_entry(c, p, u0 + t * N, tstops, T_stops, k_table, n_stops, &st);
-        if (retcodes) retcodes[t] = rc;
-        if (stats) stats[t] = st;
-        const int64_t ns = std::min<int64_t>(c->n_saved, cap);
-        if (n_saved) n_saved[t] = ns;
-        if (out_u && ns > 0) c->d_sol_u.download(out_u + (size_t)t * cap * N, (size_t)ns * N, s);
-        if (out_t && t == 0) { for (int64_t i = 0; i < ns && i < (int64_t)c->sol_t.size(); i++) out_t[i] = c->sol_t[(size_t)i]; }
-        KIN_HIP(hipStreamSynchronize(s));
       } catch (const std::exception& e) { errs[(size_t)t] = e.what(); }
     });
   for (auto& x : th) x.join();
   for (auto& e : errs) if (!e.empty()) throw KinError(ERR_DEVICE, "ensemble member failed: " + e);
-  // the save times are the members' common grid: member 0's, or - if it stopped early - those of the member that got furthest
-  if (out_t && n_saved) {
-    int64_t best = 0;
-    for (int64_t t = 1; t < K; t++) if (n_saved[t] > n_saved[best]) best = t;
-    if (best != 0) { const auto& tt = h->replicas[(size_t)best]->sol_t; for (int64_t i = 0; i < n_saved[best] && i < (int64_t)tt.size(); i++) out_t[i] = tt[(size_t)i]; }
-  }
 }
 
 }  // namespace
@@ -460,9 +475,18 @@ int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, cons
     // networks whose trajectory fits one compute unit: one workgroup per member, one launch (resident.cpp); larger ones:
     // lockstep rounds of batched launches (ensemble.cpp). KIN_ENSEMBLE_BATCHED=1 forces the second form.
     const bool force_batched = getenv("KIN_ENSEMBLE_BATCHED") && atoi(getenv("KIN_ENSEMBLE_BATCHED")) != 0;
-    if (!force_batched && resident_fits(h))
+    const char* route = getenv("KIN_ENSEMBLE_ROUTE");   // resident | threads | lockstep: A/B runs (tools/ensemble_route_crossover.py)
+    if (route && !strcmp(route, "threads"))
+      replica_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
+    else if (route && !strcmp(route, "lockstep"))
+      batched_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
+    else if (!force_batched && resident_fits(h))
       resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
-    else if (!force_batched && K <= replica_threads_max())      // few members of a large network: K kin_solve calls on K threads
+    // few members of a network too large for a compute unit: kin_solve calls on host threads, one member per thread up to the
+    // thread limit (KIN_ENSEMBLE_THREADS_K raises the member count that takes this route: the threads then take several
+    // members each - measured, profiles/r04_ensemble_route_crossover.jsonl: from 16 members on the lockstep rounds are ahead
+    // at 3 000 and 10 000 species)
+    else if (!force_batched && K <= replica_members_max())
       replica_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
     else
       batched_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);

@@ -279,6 +279,25 @@ def test_few_members_of_a_large_network_are_kin_solve_calls_on_threads():
     h.close()
 
 
+def test_threads_take_several_members_each_beyond_the_thread_limit(monkeypatch):
+    """KIN_ENSEMBLE_ROUTE=threads with more members than threads (5 members, 2 threads: member m on thread m mod 2, one after
+    the other on the thread's replica of the handle): still bit for bit kin_solve per member, in the members' order."""
+    monkeypatch.setenv("KIN_ENSEMBLE_ROUTE", "threads")
+    monkeypatch.setenv("KIN_ENSEMBLE_THREADS", "2")
+    net, Ea, A = synthetic_crn(2000, 10000)
+    h = capi.HipNetwork.from_flat(net)
+    h.set_arrhenius(Ea, A, k_max=1e12)
+    u0 = np.zeros(2000); u0[0] = 1.0
+    T = np.array([950.0, 1000.0, 1050.0, 1100.0, 1150.0])
+    t, u, ns, rcs, sts = h.solve_ensemble(kp(2e-3), np.tile(u0, (5, 1)), T=T)
+    assert (rcs == 0).all() and (ns == 3).all()
+    for i in range(5):
+        h.rates_at(float(T[i]))
+        ts, us, rc, st, _ = h.solve(kp(2e-3), u0)
+        assert rc == 0 and np.array_equal(ts, t) and np.array_equal(us, u[i]) and st["n_steps"] == sts[i]["n_steps"]
+    h.close()
+
+
 def test_lockstep_ensemble_of_a_large_network(monkeypatch):
     """kin_solve_ensemble beyond the resident kernel's size (ensemble.cpp): members advance in lockstep rounds of batched
     launches, each with the controller the resident kernel runs. At C3 size against solo kin_solve runs of the same inputs
