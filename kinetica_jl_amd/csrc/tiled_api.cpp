@@ -2,6 +2,7 @@
 #include "../../include/kinetica_hip.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 
 #include "handle.hpp"
@@ -111,7 +112,10 @@ int kin_lib_layout_host(int64_t n_species, int64_t n_reactions, const int64_t* r
   try {
     const NetworkHost H = compile_network(n_species, n_reactions, reac_ptr, reac_idx, reac_sto, prod_ptr, prod_idx, prod_sto, index_base);
     const TiledHost L = build_tiled(H, tiled_block_size(H.N), hubs);
-    if (!L.ok) return KIN_ERR_UNSUPPORTED;
+    if (!L.ok) {
+      if (getenv("KIN_TILED_DEBUG")) fprintf(stderr, "[tiled] no layout: %s\n", L.why.c_str());
+      return KIN_ERR_UNSUPPORTED;
+    }
     if (info) {
       info[0] = L.h; info[1] = L.T; info[2] = L.P; info[3] = L.E; info[4] = L.n_copy; info[5] = L.BS; info[6] = L.wbase;
       info[7] = L.seg_q.back(); info[8] = L.k_len(); info[9] = L.has_singles ? 1 : 0;

@@ -268,15 +268,16 @@ def test_full_size_c3_elementwise_and_c5_tiled_sweep():
         h.close()
 
 
-@pytest.mark.parametrize("entries", [None, "1400"], ids=["one_window", "windows"])
-def test_one_slot_records_after_the_low_k_cutoff(monkeypatch, entries):
+@pytest.mark.parametrize("n,entries", [(3000, None), (3000, "1400"), (1000, None), (6000, None), (6000, "2600")],
+                         ids=["one_window_bs512", "windows_bs512", "bs256", "bs1024", "windows_bs1024"])
+def test_one_slot_records_after_the_low_k_cutoff(monkeypatch, n, entries):
     """A network that lost 30 % of its reactions (apply_low_k_cutoff!, solve_utils.jl:213-245): the records without a reverse
     take one rate-constant slot each at the end of their window - the kernel's SINGLES instantiation. k-stream form through
     the layout conversions, the library-order rate table against the plain one, the temperature form, all against the oracle;
     the plain two-slot layout of the same network (KIN_TILED_SINGLES=0) passes the same check."""
     if entries:
         monkeypatch.setenv("KIN_TILED_ENTRIES", entries)
-    n, r, B = 3000, 15000, 37
+    r, B = 5 * n, 37
     net0, Ea0, A0 = synthetic_crn(n, r)
     keep = np.sort(np.random.default_rng(21).choice(r, int(0.7 * r), replace=False))
     net, Ea, A = net0.subset(keep), Ea0[keep], A0[keep]

@@ -144,3 +144,47 @@ def test_scheduled_order_with_windows_and_unpaired_reactions(monkeypatch):
     L = _check(net.subset(keep), seed=8)
     assert L["T"] > 1
     assert _group_cycles(L) < 2.4
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_networks_through_every_layout_variant(monkeypatch, seed):
+    """Random small networks with every reaction shape the record format takes (A -> B, A -> 2B, A -> B + C, 2A -> ..., A + B ->
+    ..., no products, colliders, duplicates), a random share of their reverses present, Zipf-like species popularity: the library
+    order in all its variants (windows or not, bank-aware order from chunks / from a reservoir / plain, one- or two-slot records)
+    replays to the oracle's RHS."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(40, 400))
+    nr = int(rng.integers(n, 6 * n))
+    w = 1.0 / np.arange(1, n + 1) ** 1.1
+    w /= w.sum()
+    pick = lambda k: [int(x) for x in rng.choice(n, size=k, replace=False, p=w)]   # noqa: E731
+    reacs, prods = [], []
+    p_rev = rng.uniform(0.2, 1.0)
+    while len(reacs) < nr:
+        shape = rng.integers(0, 8)
+        a, b, c, d = pick(4)
+        lhs, rhs = {0: ([(a, 1)], [(b, 1)]), 1: ([(a, 1)], [(b, 2)]), 2: ([(a, 1)], [(b, 1), (c, 1)]), 3: ([(a, 2)], [(b, 1)]),
+                    4: ([(a, 2)], [(b, 1), (c, 1)]), 5: ([(a, 1), (b, 1)], [(c, 1)]), 6: ([(a, 1), (b, 1)], [(c, 1), (d, 1)]),
+                    7: ([(a, 1)], [])}[int(shape)]
+        if rng.random() < 0.05 and int(shape) == 0:                       # a collider on both sides (A + M -> B + M)
+            lhs, rhs = lhs + [(d, 1)], rhs + [(d, 1)]
+        reacs.append(lhs); prods.append(rhs)
+        if rhs and sum(c_ for _, c_ in rhs) <= 2 and rng.random() < p_rev:
+            reacs.append(rhs); prods.append(lhs)
+        if rng.random() < 0.03:                                           # an exact duplicate
+            reacs.append(lhs); prods.append(rhs)
+    net = from_lists(n, reacs, prods)
+    variants = [{}, {"KIN_TILED_ENTRIES": "320"}, {"KIN_TILED_CHUNKED": "0", "KIN_TILED_SCAN": "200"}, {"KIN_TILED_SCHEDULE": "0"},
+                {"KIN_TILED_SINGLES": "0", "KIN_TILED_ENTRIES": "320"}]
+    done = 0
+    for env in variants:
+        for k_ in ("KIN_TILED_ENTRIES", "KIN_TILED_CHUNKED", "KIN_TILED_SCAN", "KIN_TILED_SCHEDULE", "KIN_TILED_SINGLES"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        try:
+            _check(net, seed=seed)
+            done += 1
+        except capi.KineticaHipError as e:     # (a tail that does not decompose into windows of 100-odd entries: reported, not wrong)
+            assert e.code == capi.KIN_ERR_UNSUPPORTED and "KIN_TILED_ENTRIES" in env
+    assert done >= 3
