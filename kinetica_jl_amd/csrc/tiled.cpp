@@ -28,6 +28,197 @@ struct UnionFind {
 
 struct Rec { int32_t f[4]; int32_t kf, kr; };   // species per field (-1: unused): reactant instances, product instances
 
+
+// ---- placement of one segment's records (build_tiled below) ---------------------------------------------------------
+struct SegCtx {
+  const std::vector<Rec>& recs;
+  const std::vector<int64_t>& cnt;              // references per species
+  const std::vector<int32_t>& lib_of_species;
+  const std::vector<int32_t>& copy_rank;        // split hubs: rank of the species among them, else -1
+  int32_t h, wbase, win_off;                    // hubs, first window entry, first library species of this segment's window
+  bool compact;                                 // records without a reverse get one rate-constant slot at the segment's end
+  int scan;                                     // candidates in sight
+  bool chunked;                                 // ... taken chunk by chunk instead of topped up after every placement
+};
+struct Placement {
+  std::vector<int32_t> order;                   // record ids in library order
+  std::vector<std::array<uint64_t, 4>> labs;    // their four LDS labels
+  std::vector<char> flipped;                    // the record's reverse reaction takes the forward role
+  int64_t slots = 0, conflicts = 0, deferred = 0;
+};
+inline int cls_of(const Rec& q) { return (q.f[1] >= 0 ? 1 : 0) | (q.f[3] >= 0 ? 2 : 0); }
+inline int kind_of(const SegCtx& cx, const Rec& q) { return cx.compact && q.kr < 0 ? 4 : 0; }
+// label options of field j of record p: a window entry, a hub entry, or a split hub's eight entries
+int label_options(const SegCtx& cx, int32_t p, int j, uint64_t* opt) {
+  const int32_t sp = cx.recs[p].f[j];
+  if (sp < 0) return 0;
+  const int32_t li = cx.lib_of_species[sp];
+  if (li >= cx.h) { opt[0] = (uint64_t)(cx.wbase + (li - cx.win_off)); return 1; }
+  opt[0] = (uint64_t)li;
+  if (cx.copy_rank[sp] < 0) return 1;
+  for (int c = 0; c < TILED_COPIES; c++) opt[1 + c] = (uint64_t)(cx.h + TILED_DUMMY + cx.copy_rank[sp] * TILED_COPIES + c);
+  return 1 + TILED_COPIES;
+}
+
+// the plain order: as sorted (kind, class, then the caller's reaction order), a split hub's entries by position
+Placement place_plain(const SegCtx& cx, const std::vector<int32_t>& sorted) {
+  const int32_t n = (int32_t)sorted.size(), h = cx.h;
+  Placement pl;
+  pl.order = sorted; pl.labs.resize(n); pl.flipped.assign(n, 0);
+  for (int32_t i = 0; i < n; i++)
+    for (int j = 0; j < 4; j++) {
+      uint64_t opt[1 + TILED_COPIES];
+      const int no = label_options(cx, sorted[i], j, opt);
+      pl.labs[i][j] = no == 0 ? (uint64_t)(h + (i & (TILED_DUMMY - 1))) : opt[no > 1 ? (i & 7) : 0];
+    }
+  return pl;
+}
+
+// the bank-aware order (see build_tiled): `sorted` = the segment's records by (kind, class, caller's reaction order)
+Placement place_bank_aware(const SegCtx& cx, const std::vector<int32_t>& sorted) {
+  const std::vector<Rec>& recs = cx.recs;
+  const std::vector<int64_t>& cnt = cx.cnt;
+  const int32_t n = (int32_t)sorted.size(), h = cx.h;
+  const int SCAN = cx.scan;
+  const bool chunked = cx.chunked;
+  Placement pl;
+  pl.order.resize(n); pl.labs.resize(n); pl.flipped.assign(n, 0);
+  std::vector<int32_t>& placed = pl.order;
+  std::vector<std::array<uint64_t, 4>>& labs = pl.labs;
+  std::vector<char>& flipped = pl.flipped;
+  int64_t& sched_slots = pl.slots; int64_t& sched_conflicts = pl.conflicts; int64_t& dbg_defer = pl.deferred;
+  auto cls = [&](int32_t p) { return cls_of(recs[p]); };
+  auto kind = [&](int32_t p) { return kind_of(cx, recs[p]); };
+  auto options = [&](int32_t p, int j, uint64_t* opt) { return label_options(cx, p, j, opt); };
+  // a candidate: per field of the record the banks its label options cover, mod 16 and mod 32 (0: field unused)
+  struct Cand { int32_t p; uint16_t m16[4]; uint32_t m32[4]; int64_t hard; bool sides; int cls; };
+  auto make_cand = [&](int32_t p) {
+    Cand c{p, {0, 0, 0, 0}, {0, 0, 0, 0}, 0, false, cls(p)};
+    for (int j = 0; j < 4; j++) {
+      uint64_t opt[1 + TILED_COPIES];
+      const int no = options(p, j, opt);
+      for (int o = 0; o < no; o++) { c.m16[j] |= (uint16_t)(1u << (opt[o] & 15)); c.m32[j] |= 1u << (opt[o] & 31); }
+      if (no > 0) c.hard = std::max(c.hard, cnt[recs[p].f[j]]);
+    }
+    // forward and reverse reaction of a pair may change roles where that keeps the record's class
+    c.sides = recs[p].kr >= 0 && (recs[p].f[1] >= 0) == (recs[p].f[3] >= 0);
+    return c;
+  };
+  // orientation o: bit 0 = the two reactant fields swapped, bit 1 = the two product fields swapped, bit 2 = the
+  // sides swapped (the reverse reaction becomes the record's forward one); src[j] = the record field that goes to j
+  auto sources = [](int o, int* src) {
+    const int s0 = (o & 4) ? 2 : 0, s1 = (o & 4) ? 0 : 2;
+    src[0] = s0 + (o & 1); src[1] = s0 + ((o & 1) ^ 1);
+    src[2] = s1 + ((o >> 1) & 1); src[3] = s1 + (((o >> 1) & 1) ^ 1);
+  };
+  bool present[8] = {false, false, false, false, false, false, false, false};
+  for (int32_t x = 0; x < n; x++) present[kind(sorted[x]) | cls(sorted[x])] = true;
+  // a record may also ride in the wavefronts of a class that has all its fields (they execute the instructions of the
+  // fields it lacks anyway, on dummy entries): what cannot be placed without a conflict at the end of a class's run -
+  // when the candidates run out, the last lanes of a group rarely find their one free bank - waits for the next such run
+  auto later_home = [&](int x, int c, int kd) {   // (among the runs of the same kind)
+    for (int c2 = c + 1; c2 < 4; c2++) if (present[kd | c2] && (x & ~c2) == 0) return true;
+    return false;
+  };
+  std::vector<Cand> deferred;
+  uint32_t used[4] = {0, 0, 0, 0}, used32[4] = {0, 0, 0, 0};
+  int32_t i = 0;
+  for (int32_t a = 0; a < n;) {
+    int32_t b = a;
+    const int c_run = cls(sorted[a]), k_run = kind(sorted[a]);
+    while (b < n && cls(sorted[b]) == c_run && kind(sorted[b]) == k_run) b++;
+    const bool live[4] = {true, (c_run & 1) != 0, true, (c_run & 2) != 0};
+    // the candidates in sight, taken in the caller's reaction order (the conversion of rate constants to the library order
+    // then gathers from a narrow range per wavefront)
+    std::vector<Cand> pool;
+    pool.reserve(SCAN + deferred.size());
+    for (size_t d = 0; d < deferred.size();)
+      if ((deferred[d].cls & ~c_run) == 0 && kind(deferred[d].p) == k_run) { pool.push_back(deferred[d]); deferred[d] = deferred.back(); deferred.pop_back(); }
+      else d++;
+    int32_t next = a;
+    size_t cur = 0;
+    for (;;) {
+      if (!chunked || pool.empty()) while (pool.size() < (size_t)SCAN && next < b) pool.push_back(make_cand(sorted[next++]));
+      if (pool.empty()) break;
+      if ((i & 15) == 0) used[0] = used[1] = used[2] = used[3] = 0;
+      if ((i & 31) == 0) used32[0] = used32[1] = used32[2] = used32[3] = 0;
+      // Among them, in any orientation, one that finds a free bank in every field - for the ds_add_f64 of its 16-lane
+      // group first (weight 4), for the ds_read_b64 of its 32-lane half second; of the first few that do, the one with
+      // the most referenced species (the hubs' records are the hard ones to place).
+      uint32_t fr[4], fr32[4];
+      for (int j = 0; j < 4; j++) { fr[j] = ~used[j] & 0xffffu; fr32[j] = ~used32[j]; }
+      size_t best = cur % pool.size(); int best_cost = 1 << 20, best_or = 0, fits = 0; int64_t best_hard = -1;
+      const int enough = (i & 15) >= 12 ? 1 : 6;   // (the last lanes of a group take the first record that fits: few do)
+      for (size_t c = 0; c < pool.size() && fits < enough; c++) {
+        const size_t q = (cur + c) % pool.size();
+        const Cand& k = pool[q];
+        // (quick look: can anything of the record sit in fields 0 and 2 at all? most candidates fail here when the
+        // group is nearly full)
+        if (best_cost <= 4) {
+          const bool a0 = ((k.m16[0] | k.m16[1]) & fr[0]) != 0, a2 = ((k.m16[2] | k.m16[3]) & fr[2]) != 0;
+          const bool b0 = k.sides && ((k.m16[2] | k.m16[3]) & fr[0]) != 0, b2 = k.sides && ((k.m16[0] | k.m16[1]) & fr[2]) != 0;
+          if (!((a0 && a2) || (b0 && b2))) continue;
+        }
+        // (the cost separates: per side assignment, the better order of the reactant pair + the better order of the
+        // product pair)
+        auto field_cost = [&](int sj, int j) {
+          if (!k.m16[sj]) return (live[j] && !fr[j]) ? 4 : 0;
+          if (!(k.m16[sj] & fr[j])) return 4;
+          return (k.m32[sj] & fr32[j]) ? 0 : 1;
+        };
+        int q_cost = 1 << 20;
+        for (int sd = 0; sd < (k.sides ? 2 : 1); sd++) {
+          const int s0 = sd ? 2 : 0, s1 = sd ? 0 : 2;
+          int cr = field_cost(s0, 0) + field_cost(s0 + 1, 1), o_r = 0;
+          if (k.m16[s0 + 1] && cr > 0) { const int c2 = field_cost(s0 + 1, 0) + field_cost(s0, 1); if (c2 < cr) { cr = c2; o_r = 1; } }
+          int cp = field_cost(s1, 2) + field_cost(s1 + 1, 3), o_p = 0;
+          if (k.m16[s1 + 1] && cp > 0) { const int c2 = field_cost(s1 + 1, 2) + field_cost(s1, 3); if (c2 < cp) { cp = c2; o_p = 2; } }
+          const int cost = cr + cp;
+          q_cost = std::min(q_cost, cost);
+          if (cost < best_cost || (cost == best_cost && k.hard > best_hard)) { best_cost = cost; best = q; best_or = o_r | o_p | (sd ? 4 : 0); best_hard = k.hard; }
+        }
+        fits += q_cost == 0;
+      }
+      if (best_cost >= 4 && next == b) {
+        // the end of the run: whoever has a later home goes there
+        size_t kept = 0;
+        for (size_t q = 0; q < pool.size(); q++)
+          if (later_home(pool[q].cls, c_run, k_run)) deferred.push_back(pool[q]); else pool[kept++] = pool[q];
+        if (kept < pool.size()) { dbg_defer += pool.size() - kept; pool.resize(kept); cur = 0; continue; }
+      }
+      const int32_t p = pool[best].p;
+      int src[4];
+      sources(best_or, src);
+      for (int j = 0; j < 4; j++) {
+        uint64_t opt[TILED_DUMMY];
+        int no = options(p, src[j], opt);
+        if (no == 0) {
+          if (!live[j]) { labs[i][j] = (uint64_t)(h + (i & (TILED_DUMMY - 1))); continue; }
+          // a field the record lacks but its wavefront executes: any dummy entry on a free bank
+          for (int d = 0; d < TILED_DUMMY; d++) opt[d] = (uint64_t)(h + ((i + d) & (TILED_DUMMY - 1)));
+          no = TILED_DUMMY;
+        }
+        int pick = -1;
+        for (int o = 0; o < no && pick < 0; o++)
+          if (!(used[j] >> (opt[o] & 15) & 1u) && !(used32[j] >> (opt[o] & 31) & 1u)) pick = o;
+        for (int o = 0; o < no && pick < 0; o++) if (!(used[j] >> (opt[o] & 15) & 1u)) pick = o;
+        sched_slots++;
+        if (pick < 0) { pick = no > 1 ? i % no : 0; sched_conflicts++; }
+        labs[i][j] = opt[pick];
+        used[j] |= 1u << (opt[pick] & 15);
+        used32[j] |= 1u << (opt[pick] & 31);
+      }
+      flipped[i] = (best_or & 4) != 0;
+      placed[i++] = p;
+      pool[best] = pool.back();
+      pool.pop_back();
+      cur = best + 1;
+    }
+    a = b;
+  }
+  return pl;
+}
+
 }  // namespace
 
 TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
@@ -254,158 +445,13 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   for (int t = 0; t < T; t++) {
     std::stable_sort(seg[t].begin(), seg[t].end(), [&](int32_t a, int32_t b) { return (kind(a) | cls(a)) < (kind(b) | cls(b)); });
     const int32_t base = (int32_t)L.kf.size(), n = (int32_t)seg[t].size();
-    // label options of field j of record p: a window entry, a hub entry, or a split hub's eight entries
-    auto options = [&](int32_t p, int j, uint64_t* opt) -> int {
-      const int32_t sp = recs[p].f[j];
-      if (sp < 0) return 0;
-      const int32_t li = L.lib_of_species[sp];
-      if (li >= h) { opt[0] = (uint64_t)(L.wbase + (li - L.win_off[t])); return 1; }
-      opt[0] = (uint64_t)li;
-      if (copy_rank[sp] < 0) return 1;
-      for (int c = 0; c < TILED_COPIES; c++) opt[1 + c] = (uint64_t)(h + TILED_DUMMY + copy_rank[sp] * TILED_COPIES + c);
-      return 1 + TILED_COPIES;
-    };
-    std::vector<int32_t> placed(n);
-    std::vector<char> flipped(n, 0);   // the record's reverse reaction takes the forward role
-    std::vector<std::array<uint64_t, 4>> labs(n);
+    const SegCtx cx{recs, cnt, L.lib_of_species, copy_rank, h, L.wbase, L.win_off[t], compact, SCAN, chunked};
     const auto t_s0 = std::chrono::steady_clock::now();
-    if (schedule) {
-      // a candidate: per field of the record the banks its label options cover, mod 16 and mod 32 (0: field unused)
-      struct Cand { int32_t p; uint16_t m16[4]; uint32_t m32[4]; int64_t hard; bool sides; int cls; };
-      auto make_cand = [&](int32_t p) {
-        Cand c{p, {0, 0, 0, 0}, {0, 0, 0, 0}, 0, false, cls(p)};
-        for (int j = 0; j < 4; j++) {
-          uint64_t opt[1 + TILED_COPIES];
-          const int no = options(p, j, opt);
-          for (int o = 0; o < no; o++) { c.m16[j] |= (uint16_t)(1u << (opt[o] & 15)); c.m32[j] |= 1u << (opt[o] & 31); }
-          if (no > 0) c.hard = std::max(c.hard, cnt[recs[p].f[j]]);
-        }
-        // forward and reverse reaction of a pair may change roles where that keeps the record's class
-        c.sides = recs[p].kr >= 0 && (recs[p].f[1] >= 0) == (recs[p].f[3] >= 0);
-        return c;
-      };
-      // orientation o: bit 0 = the two reactant fields swapped, bit 1 = the two product fields swapped, bit 2 = the
-      // sides swapped (the reverse reaction becomes the record's forward one); src[j] = the record field that goes to j
-      auto sources = [](int o, int* src) {
-        const int s0 = (o & 4) ? 2 : 0, s1 = (o & 4) ? 0 : 2;
-        src[0] = s0 + (o & 1); src[1] = s0 + ((o & 1) ^ 1);
-        src[2] = s1 + ((o >> 1) & 1); src[3] = s1 + (((o >> 1) & 1) ^ 1);
-      };
-      bool present[8] = {false, false, false, false, false, false, false, false};
-      for (int32_t x = 0; x < n; x++) present[kind(seg[t][x]) | cls(seg[t][x])] = true;
-      // a record may also ride in the wavefronts of a class that has all its fields (they execute the instructions of the
-      // fields it lacks anyway, on dummy entries): what cannot be placed without a conflict at the end of a class's run -
-      // when the candidates run out, the last lanes of a group rarely find their one free bank - waits for the next such run
-      auto later_home = [&](int x, int c, int kd) {   // (among the runs of the same kind)
-        for (int c2 = c + 1; c2 < 4; c2++) if (present[kd | c2] && (x & ~c2) == 0) return true;
-        return false;
-      };
-      std::vector<Cand> deferred;
-      uint32_t used[4] = {0, 0, 0, 0}, used32[4] = {0, 0, 0, 0};
-      int32_t i = 0;
-      for (int32_t a = 0; a < n;) {
-        int32_t b = a;
-        const int c_run = cls(seg[t][a]), k_run = kind(seg[t][a]);
-        while (b < n && cls(seg[t][b]) == c_run && kind(seg[t][b]) == k_run) b++;
-        const bool live[4] = {true, (c_run & 1) != 0, true, (c_run & 2) != 0};
-        // the candidates in sight, taken in the caller's reaction order (the conversion of rate constants to the library order
-        // then gathers from a narrow range per wavefront)
-        std::vector<Cand> pool;
-        pool.reserve(SCAN + deferred.size());
-        for (size_t d = 0; d < deferred.size();)
-          if ((deferred[d].cls & ~c_run) == 0 && kind(deferred[d].p) == k_run) { pool.push_back(deferred[d]); deferred[d] = deferred.back(); deferred.pop_back(); }
-          else d++;
-        int32_t next = a;
-        size_t cur = 0;
-        for (;;) {
-          if (!chunked || pool.empty()) while (pool.size() < (size_t)SCAN && next < b) pool.push_back(make_cand(seg[t][next++]));
-          if (pool.empty()) break;
-          if ((i & 15) == 0) used[0] = used[1] = used[2] = used[3] = 0;
-          if ((i & 31) == 0) used32[0] = used32[1] = used32[2] = used32[3] = 0;
-          // Among them, in any orientation, one that finds a free bank in every field - for the ds_add_f64 of its 16-lane
-          // group first (weight 4), for the ds_read_b64 of its 32-lane half second; of the first few that do, the one with
-          // the most referenced species (the hubs' records are the hard ones to place).
-          uint32_t fr[4], fr32[4];
-          for (int j = 0; j < 4; j++) { fr[j] = ~used[j] & 0xffffu; fr32[j] = ~used32[j]; }
-          size_t best = cur % pool.size(); int best_cost = 1 << 20, best_or = 0, fits = 0; int64_t best_hard = -1;
-          const int enough = (i & 15) >= 12 ? 1 : 6;   // (the last lanes of a group take the first record that fits: few do)
-          for (size_t c = 0; c < pool.size() && fits < enough; c++) {
-            const size_t q = (cur + c) % pool.size();
-            const Cand& k = pool[q];
-            // (quick look: can anything of the record sit in fields 0 and 2 at all? most candidates fail here when the
-            // group is nearly full)
-            if (best_cost <= 4) {
-              const bool a0 = ((k.m16[0] | k.m16[1]) & fr[0]) != 0, a2 = ((k.m16[2] | k.m16[3]) & fr[2]) != 0;
-              const bool b0 = k.sides && ((k.m16[2] | k.m16[3]) & fr[0]) != 0, b2 = k.sides && ((k.m16[0] | k.m16[1]) & fr[2]) != 0;
-              if (!((a0 && a2) || (b0 && b2))) continue;
-            }
-            // (the cost separates: per side assignment, the better order of the reactant pair + the better order of the
-            // product pair)
-            auto field_cost = [&](int sj, int j) {
-              if (!k.m16[sj]) return (live[j] && !fr[j]) ? 4 : 0;
-              if (!(k.m16[sj] & fr[j])) return 4;
-              return (k.m32[sj] & fr32[j]) ? 0 : 1;
-            };
-            int q_cost = 1 << 20;
-            for (int sd = 0; sd < (k.sides ? 2 : 1); sd++) {
-              const int s0 = sd ? 2 : 0, s1 = sd ? 0 : 2;
-              int cr = field_cost(s0, 0) + field_cost(s0 + 1, 1), o_r = 0;
-              if (k.m16[s0 + 1] && cr > 0) { const int c2 = field_cost(s0 + 1, 0) + field_cost(s0, 1); if (c2 < cr) { cr = c2; o_r = 1; } }
-              int cp = field_cost(s1, 2) + field_cost(s1 + 1, 3), o_p = 0;
-              if (k.m16[s1 + 1] && cp > 0) { const int c2 = field_cost(s1 + 1, 2) + field_cost(s1, 3); if (c2 < cp) { cp = c2; o_p = 2; } }
-              const int cost = cr + cp;
-              q_cost = std::min(q_cost, cost);
-              if (cost < best_cost || (cost == best_cost && k.hard > best_hard)) { best_cost = cost; best = q; best_or = o_r | o_p | (sd ? 4 : 0); best_hard = k.hard; }
-            }
-            fits += q_cost == 0;
-          }
-          if (best_cost >= 4 && next == b) {
-            // the end of the run: whoever has a later home goes there
-            size_t kept = 0;
-            for (size_t q = 0; q < pool.size(); q++)
-              if (later_home(pool[q].cls, c_run, k_run)) deferred.push_back(pool[q]); else pool[kept++] = pool[q];
-            if (kept < pool.size()) { dbg_defer += pool.size() - kept; pool.resize(kept); cur = 0; continue; }
-          }
-          const int32_t p = pool[best].p;
-          int src[4];
-          sources(best_or, src);
-          for (int j = 0; j < 4; j++) {
-            uint64_t opt[TILED_DUMMY];
-            int no = options(p, src[j], opt);
-            if (no == 0) {
-              if (!live[j]) { labs[i][j] = (uint64_t)(h + (i & (TILED_DUMMY - 1))); continue; }
-              // a field the record lacks but its wavefront executes: any dummy entry on a free bank
-              for (int d = 0; d < TILED_DUMMY; d++) opt[d] = (uint64_t)(h + ((i + d) & (TILED_DUMMY - 1)));
-              no = TILED_DUMMY;
-            }
-            int pick = -1;
-            for (int o = 0; o < no && pick < 0; o++)
-              if (!(used[j] >> (opt[o] & 15) & 1u) && !(used32[j] >> (opt[o] & 31) & 1u)) pick = o;
-            for (int o = 0; o < no && pick < 0; o++) if (!(used[j] >> (opt[o] & 15) & 1u)) pick = o;
-            sched_slots++;
-            if (pick < 0) { pick = no > 1 ? i % no : 0; sched_conflicts++; }
-            labs[i][j] = opt[pick];
-            used[j] |= 1u << (opt[pick] & 15);
-            used32[j] |= 1u << (opt[pick] & 31);
-          }
-          flipped[i] = (best_or & 4) != 0;
-          placed[i++] = p;
-          pool[best] = pool.back();
-          pool.pop_back();
-          cur = best + 1;
-        }
-        a = b;
-      }
-    } else {
-      for (int32_t i = 0; i < n; i++) {
-        placed[i] = seg[t][i];
-        for (int j = 0; j < 4; j++) {
-          uint64_t opt[1 + TILED_COPIES];
-          const int no = options(placed[i], j, opt);
-          labs[i][j] = no == 0 ? (uint64_t)(h + (i & (TILED_DUMMY - 1))) : opt[no > 1 ? (i & 7) : 0];
-        }
-      }
-    }
+    Placement pl = schedule ? place_bank_aware(cx, seg[t]) : place_plain(cx, seg[t]);
+    sched_slots += pl.slots; sched_conflicts += pl.conflicts; dbg_defer += pl.deferred;
+    const std::vector<int32_t>& placed = pl.order;
+    const std::vector<std::array<uint64_t, 4>>& labs = pl.labs;
+    const std::vector<char>& flipped = pl.flipped;
     dbg_sec += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_s0).count();
     seg[t] = placed;
     // rate-constant slots: the first n2 records two each (n2 = the pairs, rounded up to whole wavefronts), the rest one
