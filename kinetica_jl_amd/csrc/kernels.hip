@@ -622,7 +622,14 @@ __global__ __launch_bounds__(BS) void sweep_gen_kernel(int N, int R, int P, int 
 #pragma unroll
       for (int x = 0; x < ILP; x++) {
         const uint32_t l0 = w[x].x & 0xffffu, l1 = w[x].x >> 16, l2 = w[x].y & 0xffffu, l3 = w[x].y >> 16;
+#if defined(KIN_SWEEP_PROBE)   // timing only (wrong results): =1 no LDS work at all, =2 no LDS atomics
+        const double net = KIN_SWEEP_PROBE == 1 ? kf[x] * (1.0 + (double)(l0 + l1)) - kr[x] * (1.0 + (double)(l2 + l3))
+                                                : kf[x] * (u_s[l0] * u_s[l1]) - kr[x] * (u_s[l2] * u_s[l3]);
+        if (net == 12345.678) du_s[l0] = net;
+        continue;
+#else
         const double net = kf[x] * (u_s[l0] * u_s[l1]) - kr[x] * (u_s[l2] * u_s[l3]);
+#endif
         __hip_atomic_fetch_add(du_s + l0, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(du_s + l1, -net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(du_s + l2, net, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
