@@ -127,13 +127,17 @@ struct Solver {
       if (const char* e = getenv("KIN_LU_DRIFT")) lu_drift_max = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
+      if (const char* e = getenv("KIN_LU_ABSBAND")) lu_absband = atof(e);
+      if (const char* e = getenv("KIN_LU_PAIR")) lu_pair = atoi(e) != 0;
+      if (const char* e = getenv("KIN_LU_PAIR_MIN_M")) lu_pair_min_m = atoi(e);
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
       if (h->lu_budget_mb > 0) budget_mb = std::min(budget_mb, h->lu_budget_mb);   // a replica's share (capi.cpp: replica_ensemble)
       const size_t fit = std::max<size_t>(1, budget_mb * 1024 * 1024 / std::max<size_t>(1, lu.slot_bytes()));
       lu_slots = (int)std::min<size_t>(std::min<size_t>((size_t)want, fit), (size_t)LU_MAX_SLOTS);
       d_jdiag.upload(H.j_diag, s);
-      d_drift.alloc(LU_MAX_SLOTS);
-      KIN_HIP(hipHostMalloc((void**)&h_drift, LU_MAX_SLOTS * sizeof(double), hipHostMallocDefault));
+      d_drift.alloc(LU_MAX_SLOTS + 1);
+      KIN_HIP(hipHostMalloc((void**)&h_drift, (LU_MAX_SLOTS + 1) * sizeof(double), hipHostMallocDefault));
+      h_drift[LU_MAX_SLOTS] = 0.0;
       lu_band = lu_slots > 1 ? band : 0.0;
       if (lu_slots == 1 && getenv("KIN_LU_BAND")) lu_band = band;   // single slot with a reuse band: CVODE's own scheme
     }
@@ -297,12 +301,18 @@ struct Solver {
         launch_slot_drift(N, n_checked, jv.p, d_jdiag.p, a, d_drift.p, s);
         KIN_HIP(hipMemcpyAsync(h_drift, d_drift.p, (size_t)n_checked * sizeof(double), hipMemcpyDeviceToHost, s));
       }
+      if (lu_band > 0.0 && lu_absband > 0.0) {   // the Jacobian's scale for the absolute reuse rule: rides on the same synchronisation
+        launch_jac_diag_absmax(N, jv.p, d_jdiag.p, d_drift.p + LU_MAX_SLOTS, s);
+        KIN_HIP(hipMemcpyAsync(h_drift + LU_MAX_SLOTS, d_drift.p + LU_MAX_SLOTS, sizeof(double), hipMemcpyDeviceToHost, s));
+        jnorm_pending = true;
+      }
     }
     rhs(y.p, f0.p);
     launch_bdf_norms(N, y.p, f0.p, nullptr, atol, rtol, ctrl.p, s);
     sync_ctrl();
     for (int i = 0; i < n_checked; i++)
       if (lu.slots[i].valid && !(h_drift[i] <= lu_drift_max)) { lu.slots[i].valid = false; st.n_lu_dropped++; }
+    if (jnorm_pending) { jnorm = 2.0 * h_drift[LU_MAX_SLOTS]; jnorm_pending = false; }
     if (hc->nonfinite) return false;
     const double interval = std::fabs(t_bound - t0);
     const double d0 = hc->scratch[0], d1 = hc->scratch[1];
@@ -455,7 +465,9 @@ struct Solver {
     else launch_rates_skip(h->host.R, h->k.p, y.p, h->x0.p, h->x1.p, h->rate.p, skip, s);
     launch_segsum(resid_plan.view(), SEG_COEF_BDF, h->rate.p, q.W.p, ex, s);
     // a factorisation made for another c: the update is scaled by 2 / (1 + c / c_fact)
-    const double upd = q.c_fact != c ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
+    // (a slot taken under the absolute rule, outside the ratio band: no scaling - it belongs to the stiff limit, where the
+    // matrix is c J, and the absolute rule only admits slots whose matrix and this attempt's are both close to the identity)
+    const double upd = (q.c_fact != c && std::fabs(c / q.c_fact - 1.0) <= lu_band) ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
     const double rate_max = (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0;
     const double crate0 = carry_rate ? q.crate : 1.0, tol_first = ((spec_it && carry_rate) || crate_fresh(q)) ? newton_tol : -1.0;
     const bool from_ctrl = spec_it && carry_rate;
@@ -537,7 +549,11 @@ struct Solver {
       // a slot may be at most 50 accepted steps old (CVODE's bound on the age of its Jacobian)
       if (pre_attempt && st.n_steps - q.step_stamp > 50) continue;
       const double r = std::fabs(std::log(c / q.c_fact));
-      if (r < bd && std::fabs(c / q.c_fact - 1.0) <= lu_band) { bd = r; best = i; }
+      // ... or - KIN_LU_ABSBAND - close to c in ABSOLUTE terms on the Jacobian's scale: the corrector with the matrix of c_fact
+      // contracts by about |c - c_fact| rho(J), whatever the ratio of the two (while c rho(J) << 1 the matrix is nearly the
+      // identity for every c: the first chunk of a solve from a pure initial state climbs through seven decades of such c)
+      const bool ok = std::fabs(c / q.c_fact - 1.0) <= lu_band || (lu_absband > 0.0 && jnorm > 0.0 && std::fabs(c - q.c_fact) * jnorm <= lu_absband);
+      if (r < bd && ok) { bd = r; best = i; }
     }
     return best;
   }
@@ -576,7 +592,62 @@ struct Solver {
   // needs c J_ii ~ 1 on an autocatalytic species and practically never happens by itself)
   int64_t inject_bad_pivot_at = -1, attempt_no = 0;
   bool trace = false;   // KIN_TRACE_CHUNK=n: one line per corrector attempt of chunk n (diagnostic)
+  // ---- two step-size bands per factorisation (KIN_LU_PAIR=1; experiment). While the step size climbs - after
+  // every restart, i.e. at every chunk start - the factorisation that follows this one is for about twice its c, from almost
+  // the same Jacobian: the dense inverses of the two are ONE chain of launches (280 us per matrix instead of 460,
+  // launch_gauss_jordan_batched), so the second band's matrix is made now, into a slot of its own, whenever this factorisation
+  // was asked for because c grew. A vanished pivot in the second matrix goes unnoticed until the slot is used (the
+  // corrector then fails and the slot is dropped like any other that does not converge).
+  double lu_absband = 0.0, jnorm = 0.0;   // KIN_LU_ABSBAND: |c - c_fact| * (2 max |J_ii|) a slot may be away from c; jnorm = that scale, measured at restarts
+  bool jnorm_pending = false;
+  bool lu_pair = false;
+  int lu_pair_min_m = 600;
+  double last_factor_c = 0.0;      // c of the last factorisation since the restart (0: none yet)
+  int64_t last_factor_restart = -1;
+  DevBuf<double> pair_pinv;
+  DevBuf<int> pair_bad;
+  int64_t n_paired = 0;
+  void stamp_slot(int slot) {
+    lu.slots[slot].last_use = ++use_clock;
+    lu.slots[slot].jac_stamp = jac_stamp_now;
+    lu.slots[slot].step_stamp = st.n_steps - steps_since_jac;
+    if (lu_band > 0.0) {
+      lu.slots[slot].jd.alloc(N);
+      launch_jac_diag(N, jv.p, d_jdiag.p, lu.slots[slot].jd.p, s);
+    }
+  }
+  bool factor_pair(int slot, double c) {
+    if (getenv("KIN_LU_PAIR_DEBUG")) fprintf(stderr, "[factor] restart %lld step %lld c %.4e ratio %.3f\n", (long long)st.n_restarts, (long long)st.n_steps, c, last_factor_c > 0 ? c / last_factor_c : 0.0);
+    const bool climbing = last_factor_restart != st.n_restarts || c > last_factor_c;
+    last_factor_c = c; last_factor_restart = st.n_restarts;
+    if (!lu_pair || lu_band <= 0.0 || lu.m < lu_pair_min_m || !climbing) return false;
+    const double c2 = c * (1.0 + lu_band) / (1.0 - lu_band) * 0.97;     // the band next to this one, with a little overlap
+    if (nearest_slot(c2) >= 0) return false;                          // already there
+    lu.factor_sparse_into(c, jv.p, lu.slots[slot], &ctrl.p->lu_bad, s);
+    lu.slots[slot].last_use = ++use_clock;                            // (victim_slot below must not pick it)
+    const int slot2 = victim_slot();
+    if (slot2 == slot) { lu.slots[slot].sinv = launch_gauss_jordan(lu.slots[slot].W.p + lu.off_S, lu.slots[slot].S2.p, lu.mpad, lu.pinv.p, &ctrl.p->lu_bad, s); return true; }
+    pair_pinv.alloc((size_t)2 * 2 * 32 * 32); pair_bad.alloc(1);
+    lu.factor_sparse_into(c2, jv.p, lu.slots[slot2], pair_bad.p, s);
+    double* S[2] = {lu.slots[slot].W.p + lu.off_S, lu.slots[slot2].W.p + lu.off_S};
+    double* S2[2] = {lu.slots[slot].S2.p, lu.slots[slot2].S2.p};
+    int* bad[2] = {&ctrl.p->lu_bad, pair_bad.p};
+    const int where = launch_gauss_jordan_batched(2, S, S2, lu.mpad, pair_pinv.p, bad, s);
+    lu.slots[slot].sinv = where ? S2[0] : S[0];
+    lu.slots[slot2].sinv = where ? S2[1] : S[1];
+    stamp_slot(slot2);
+    lu.slots[slot2].last_use = use_clock - 1 > 0 ? use_clock - 1 : 0;   // (the slot in use stays the most recent one)
+    st.n_factor++;
+    n_paired++;
+    return true;
+  }
   void factor_into(int slot, double c) {
+    if (factor_pair(slot, c)) {
+      stamp_slot(slot);
+      cur_slot = slot;
+      st.n_factor++;
+      return;
+    }
     lu.factor(c, jv.p, slot, &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;
     lu.slots[slot].jac_stamp = jac_stamp_now;

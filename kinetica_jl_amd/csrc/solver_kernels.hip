@@ -99,6 +99,27 @@ __global__ __launch_bounds__(1024) void slot_drift_kernel(int N, const double* _
   }
 }
 
+// out[0] = max_i |J[i][i]| (one workgroup): the scale of the Jacobian behind the LU cache's absolute reuse rule (solver.cpp)
+__global__ __launch_bounds__(1024) void jac_diag_absmax_kernel(int N, const double* __restrict__ jv, const int32_t* __restrict__ j_diag,
+                                                               double* __restrict__ out) {
+  __shared__ double sh[16];
+  double worst = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) { const double v = fabs(jv[j_diag[i]]); worst = fmax(worst, v == v ? v : 1e300); }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) worst = fmax(worst, __shfl_down(worst, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double w = 0.0;
+    for (int i = 0; i < 16; i++) w = fmax(w, sh[i]);
+    out[0] = w;
+  }
+}
+void launch_jac_diag_absmax(int N, const double* jv, const int32_t* j_diag, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(jac_diag_absmax_kernel, dim3(1), dim3(1024), 0, s, N, jv, j_diag, out);
+  KIN_HIP(hipGetLastError());
+}
+
 void launch_jac_diag(int N, const double* jv, const int32_t* j_diag, double* jd, hipStream_t s) {
   hipLaunchKernelGGL(jac_diag_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, N, jv, j_diag, jd);
 }

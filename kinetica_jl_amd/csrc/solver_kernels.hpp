@@ -35,6 +35,7 @@ struct BdfCtrl {
 constexpr int LU_MAX_SLOTS = 128;
 struct SlotDriftArgs { const double* jd[LU_MAX_SLOTS]; double c[LU_MAX_SLOTS]; };
 void launch_jac_diag(int N, const double* jv, const int32_t* j_diag, double* jd, hipStream_t s);
+void launch_jac_diag_absmax(int N, const double* jv, const int32_t* j_diag, double* out, hipStream_t s);   // out[0] = max |J_ii|
 void launch_slot_drift(int N, int n_slots, const double* jv, const int32_t* j_diag, const SlotDriftArgs& a, double* out, hipStream_t s);
 
 void launch_bdf_predict(int N, int order, const double* D, const BdfCoef& cf, double atol, double rtol, double* y, double* psi,
