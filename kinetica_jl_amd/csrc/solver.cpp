@@ -130,6 +130,8 @@ struct Solver {
       if (const char* e = getenv("KIN_LU_ABSBAND")) lu_absband = atof(e);
       if (const char* e = getenv("KIN_LU_PAIR")) lu_pair = atoi(e) != 0;
       if (const char* e = getenv("KIN_LU_PAIR_MIN_M")) lu_pair_min_m = atoi(e);
+      if (const char* e = getenv("KIN_LU_PAIR_MAX_M")) lu_pair_max_m = atoi(e);
+      if (const char* e = getenv("KIN_LU_PAIR_FAST")) lu_pair_fast = std::max(1, std::min((int)GJ_BMAX, atoi(e)));
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
       if (h->lu_budget_mb > 0) budget_mb = std::min(budget_mb, h->lu_budget_mb);   // a replica's share (capi.cpp: replica_ensemble)
       const size_t fit = std::max<size_t>(1, budget_mb * 1024 * 1024 / std::max<size_t>(1, lu.slot_bytes()));
@@ -592,16 +594,25 @@ struct Solver {
   // needs c J_ii ~ 1 on an autocatalytic species and practically never happens by itself)
   int64_t inject_bad_pivot_at = -1, attempt_no = 0;
   bool trace = false;   // KIN_TRACE_CHUNK=n: one line per corrector attempt of chunk n (diagnostic)
-  // ---- two step-size bands per factorisation (KIN_LU_PAIR=1; experiment). While the step size climbs - after
-  // every restart, i.e. at every chunk start - the factorisation that follows this one is for about twice its c, from almost
-  // the same Jacobian: the dense inverses of the two are ONE chain of launches (280 us per matrix instead of 460,
-  // launch_gauss_jordan_batched), so the second band's matrix is made now, into a slot of its own, whenever this factorisation
-  // was asked for because c grew. A vanished pivot in the second matrix goes unnoticed until the slot is used (the
-  // corrector then fails and the slot is dropped like any other that does not converge).
+  // ---- two step-size bands per factorisation (KIN_LU_PAIR=1; off by default, see the end of this comment). While the step size climbs - after every
+  // restart, i.e. at every chunk start, and through the first chunk's transient - the factorisation that follows this one is
+  // for a predictable c (10 x this one while the step size grows by its cap, else the neighbouring band) from almost the same
+  // Jacobian, and the dense inverses of two matrices are ONE chain of launches (280 us per matrix instead of 460,
+  // launch_gauss_jordan_batched): the second band's matrix is made now, into a slot of its own, whenever this factorisation
+  // was asked for because c grew. Dense blocks of lu_pair_min_m ... lu_pair_max_m only: below, the networks run in the resident
+  // kernel; above, the inverse is bandwidth-bound and a second matrix costs what it costs alone (C5, m = 3 126: the 5-chunk
+  // solve 0.85 -> 0.94 s with it). Measured (profiles/r04_lu_pair_absband_ab.txt): the 100-chunk C3 solve 0.443 ->
+  // 0.421 s, its first 5 chunks 0.169 -> 0.155 s, the 48 runs of the 10k robustness sweep 19.5 -> 17.6 s with no retry (2
+  // before) and 28 % more corrector failures (a predicted matrix that does not fit is refactorised like any other). A
+  // vanished pivot in the second matrix goes unnoticed until the slot is used (the corrector then fails and the slot is
+  // dropped like any other that does not converge). NOT the default: the runs stay within their tolerance and the deviations
+  // from the C3 truths are the same on average (30 chunks: max 170 -> 157 units, rms 7.6 -> 6.8), but their maxima at single
+  // save points move by factors (37 -> 53-88 units after 5 chunks, 58-81 -> 95-146 with warm chunk starts), past the bounds
+  // tests/test_gpu_configs.py asserts; a speed-up of 5 % does not buy a looser parity bound.
   double lu_absband = 0.0, jnorm = 0.0;   // KIN_LU_ABSBAND: |c - c_fact| * (2 max |J_ii|) a slot may be away from c; jnorm = that scale, measured at restarts
   bool jnorm_pending = false;
   bool lu_pair = false;
-  int lu_pair_min_m = 600;
+  int lu_pair_min_m = 400, lu_pair_max_m = 1536, lu_pair_fast = 2;   // matrices per chain while the step size climbs by its cap
   double last_factor_c = 0.0;      // c of the last factorisation since the restart (0: none yet)
   int64_t last_factor_restart = -1;
   DevBuf<double> pair_pinv;
@@ -618,27 +629,42 @@ struct Solver {
   }
   bool factor_pair(int slot, double c) {
     if (getenv("KIN_LU_PAIR_DEBUG")) fprintf(stderr, "[factor] restart %lld step %lld c %.4e ratio %.3f\n", (long long)st.n_restarts, (long long)st.n_steps, c, last_factor_c > 0 ? c / last_factor_c : 0.0);
-    const bool climbing = last_factor_restart != st.n_restarts || c > last_factor_c;
+    const bool first = last_factor_restart != st.n_restarts;
+    const double ratio = (!first && last_factor_c > 0.0) ? c / last_factor_c : 0.0;
+    const bool climbing = first || ratio > 1.0;
     last_factor_c = c; last_factor_restart = st.n_restarts;
-    if (!lu_pair || lu_band <= 0.0 || lu.m < lu_pair_min_m || !climbing) return false;
-    const double c2 = c * (1.0 + lu_band) / (1.0 - lu_band) * 0.97;     // the band next to this one, with a little overlap
-    if (nearest_slot(c2) >= 0) return false;                          // already there
+    if (!lu_pair || lu_band <= 0.0 || lu.m < lu_pair_min_m || lu.m > lu_pair_max_m || !climbing) return false;
+    // the c of the factorisations to come: after a restart the step size climbs by its cap of 10 per selection until the error
+    // test bites (a factorisation at every one of those steps), later by the width of a band per factorisation
+    const double next_band = (1.0 + lu_band) / (1.0 - lu_band) * 0.97;     // the band next to this one, with a little overlap
+    const bool fast = first || ratio >= 3.0;
+    const double step = fast ? std::min(10.0, first ? 10.0 : ratio) : next_band;
+    const int want = fast ? lu_pair_fast : 2;
+    int slots_[GJ_BMAX]; double cs[GJ_BMAX]; int n = 1;
+    slots_[0] = slot; cs[0] = c;
     lu.factor_sparse_into(c, jv.p, lu.slots[slot], &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;                            // (victim_slot below must not pick it)
-    const int slot2 = victim_slot();
-    if (slot2 == slot) { lu.slots[slot].sinv = launch_gauss_jordan(lu.slots[slot].W.p + lu.off_S, lu.slots[slot].S2.p, lu.mpad, lu.pinv.p, &ctrl.p->lu_bad, s); return true; }
-    pair_pinv.alloc((size_t)2 * 2 * 32 * 32); pair_bad.alloc(1);
-    lu.factor_sparse_into(c2, jv.p, lu.slots[slot2], pair_bad.p, s);
-    double* S[2] = {lu.slots[slot].W.p + lu.off_S, lu.slots[slot2].W.p + lu.off_S};
-    double* S2[2] = {lu.slots[slot].S2.p, lu.slots[slot2].S2.p};
-    int* bad[2] = {&ctrl.p->lu_bad, pair_bad.p};
-    const int where = launch_gauss_jordan_batched(2, S, S2, lu.mpad, pair_pinv.p, bad, s);
-    lu.slots[slot].sinv = where ? S2[0] : S[0];
-    lu.slots[slot2].sinv = where ? S2[1] : S[1];
-    stamp_slot(slot2);
-    lu.slots[slot2].last_use = use_clock - 1 > 0 ? use_clock - 1 : 0;   // (the slot in use stays the most recent one)
-    st.n_factor++;
-    n_paired++;
+    pair_pinv.alloc((size_t)GJ_BMAX * 2 * 32 * 32); pair_bad.alloc(1);
+    for (int g = 1; g < want && n < GJ_BMAX; g++) {
+      const double cg = cs[n - 1] * step;
+      if (nearest_slot(cg) >= 0) break;                               // already there
+      const int sg = victim_slot();
+      bool taken = false;
+      for (int i = 0; i < n; i++) taken = taken || slots_[i] == sg;
+      if (taken) break;
+      lu.factor_sparse_into(cg, jv.p, lu.slots[sg], pair_bad.p, s);
+      lu.slots[sg].last_use = ++use_clock;
+      slots_[n] = sg; cs[n] = cg; n++;
+    }
+    if (n == 1) {
+      lu.slots[slot].sinv = launch_gauss_jordan(lu.slots[slot].W.p + lu.off_S, lu.slots[slot].S2.p, lu.mpad, lu.pinv.p, &ctrl.p->lu_bad, s);
+      return true;
+    }
+    double* S[GJ_BMAX]; double* S2[GJ_BMAX]; int* bad[GJ_BMAX];
+    for (int i = 0; i < n; i++) { S[i] = lu.slots[slots_[i]].W.p + lu.off_S; S2[i] = lu.slots[slots_[i]].S2.p; bad[i] = i == 0 ? &ctrl.p->lu_bad : pair_bad.p; }
+    const int where = launch_gauss_jordan_batched(n, S, S2, lu.mpad, pair_pinv.p, bad, s);
+    for (int i = 0; i < n; i++) lu.slots[slots_[i]].sinv = where ? S2[i] : S[i];
+    for (int i = 1; i < n; i++) { stamp_slot(slots_[i]); st.n_factor++; n_paired++; }
     return true;
   }
   void factor_into(int slot, double c) {
