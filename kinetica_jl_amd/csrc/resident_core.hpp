@@ -30,6 +30,15 @@ constexpr int RES_MAX_SLOTS = 64;   // one LU-cache slot per lane of a wavefront
 enum : int { RES_RET_SUCCESS = 0, RES_RET_MAXITERS = 1, RES_RET_DTLESSTHANMIN = 2, RES_RET_UNSTABLE = 3 };   // = KIN_RETCODE_*
 
 // what a solve needs besides the network (plain data; pointers are device pointers in the product, host pointers in the test)
+// largest power of ten <= h by exact IEEE operations only (solver.cpp: decade_floor)
+KIN_HD inline double res_decade_floor(double h) {
+  if (!(h > 0.0) || !(h < 1e300)) return h;
+  double p = 1.0;
+  while (p > h) p /= 10.0;
+  while (p * 10.0 <= h) p *= 10.0;
+  return p;
+}
+
 struct ResParams {
   double tspan0, tspan1, abstol, reltol, chunkstep, dtmin;
   int32_t solve_chunks, adaptive_tols, ban_negatives, save_hits_end;
@@ -43,7 +52,7 @@ struct ResParams {
   int64_t crate_max_age, lu_max_age;
   int32_t n_slots, carry_rate;
   int64_t sol_cap;                 // rows of the solution buffer
-  int32_t profile, pad_;           // device: fill ResResult::prof (KIN_RESIDENT_PROFILE)
+  int32_t profile, h0_decade;      // device: fill ResResult::prof (KIN_RESIDENT_PROFILE); first step on the decade grid (solver.cpp)
 };
 
 struct ResStats {
@@ -211,6 +220,7 @@ struct ResidentBdf {
     const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? floor_h : pow(0.01 / dm, 0.5);
     double hm = 100.0 * h0 < h1 ? 100.0 * h0 : h1;
     h_abs = hm < interval ? hm : interval;
+    if (P.h0_decade) h_abs = res_decade_floor(h_abs);   // (solver.cpp restart(): the first step rounded down to a power of ten)
     b.init_D(false, h_abs);
     order = 1; n_equal = 0; fail_score = 0.0;
     return true;

@@ -26,6 +26,8 @@ from __future__ import annotations
 import math
 import time
 
+import os
+
 import numpy as np
 import scipy.linalg as sla
 import scipy.sparse as sp
@@ -241,6 +243,15 @@ class OracleBDF:
         d2 = rms((f1 - f0) / scale) / h0
         h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.5
         self.h_abs = min(100 * h0, h1, interval)
+        # KIN_H0_DECADE=1: the first step rounded down to a power of ten, exact IEEE operations only (kinetica_jl_amd/csrc/solver.cpp: decade_floor)
+        # (not in SciPy mode: tests/test_oracle_bdf.py pins that mode to scipy.integrate.BDF's own step sequence)
+        if not self.scipy_newton and os.environ.get("KIN_H0_DECADE", "0") != "0" and self.h_abs > 0.0 and np.isfinite(self.h_abs):
+            p = 1.0
+            while p > self.h_abs:
+                p /= 10.0
+            while p * 10.0 <= self.h_abs:
+                p *= 10.0
+            self.h_abs = p
         self.D = np.zeros((MAX_ORDER + 3, self.n))
         self.D[0] = y0
         self.D[1] = f0 * self.h_abs

@@ -584,6 +584,15 @@ struct Bdf {
     const double d2 = rms_scaled(tmp.data(), scale.data()) / h0;
     const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 0.5);
     h_abs = std::min({100.0 * h0, h1, interval});
+    {   // KIN_H0_DECADE=1: the first step rounded down to a power of ten, exact IEEE operations only (kinetica_jl_amd/csrc/solver.cpp: decade_floor)
+      const char* e = getenv("KIN_H0_DECADE");
+      if (e && atoi(e) != 0 && h_abs > 0.0 && std::isfinite(h_abs)) {
+        double p = 1.0;
+        while (p > h_abs) p /= 10.0;
+        while (p * 10.0 <= h_abs) p *= 10.0;
+        h_abs = p;
+      }
+    }
     std::fill(D.begin(), D.end(), 0.0);
     for (int64_t i = 0; i < N; i++) { D[i] = y[i]; D[(size_t)N + i] = f[i] * h_abs; }
     order = 1; n_equal = 0;
