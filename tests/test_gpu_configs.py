@@ -279,24 +279,30 @@ def test_c3_thirty_chunks_chunkwise_and_complete_against_truth(golden_dir, c3):
     sel = [int(np.argmin(np.abs(t - tt))) for tt in z["t"]]
     np.testing.assert_allclose(t[sel], z["t"], rtol=0, atol=1e-16)
     e = units(u[sel], z["u"])
-    assert e.max() <= 250 and float(np.sqrt((e ** 2).mean(axis=1)).max()) <= 11
+    # Bounds of this test and the next: 1.3 x the largest of three runs with the LU reuse band at 0.32 / 0.35 / 0.38 - a
+    # perturbation that leaves the algorithm alone and moves these maxima over 10 000 species by 30 % and more
+    # (profiles/r04_truth_maxima_noise.txt; round 4 had them at twice ONE measurement, two of them inside that spread).
+    assert e.max() <= 225 and float(np.sqrt((e ** 2).mean(axis=1)).max()) <= 10             # 111-170 / 5.1-7.6
     assert e[1].max() <= 80                                     # the first 5 chunks: measured 37
     tc, uc, rcc, stc, status = h.solve(kp(0.03, 1e-3, save=5e-3, chunks=False, dtmin=1e-30), u0)
     assert status == capi.KIN_OK and rcc == 0 and stc["n_restarts"] == 1 and len(tc) == 7
     np.testing.assert_allclose(tc, z["t"], rtol=0, atol=1e-16)
     ec = units(uc, z["u"])
-    assert ec.max() <= 60 and float(np.sqrt((ec ** 2).mean(axis=1)).max()) <= 5.5
+    assert ec.max() <= 75 and float(np.sqrt((ec ** 2).mean(axis=1)).max()) <= 5.7           # 40-56 / 3.5-4.4
     # tolerance proportional: 10x tighter tolerances, chunkwise, in DEFAULT units (measured 30 / 3.2)
     t2, u2, rc2, _, _ = h.solve(kp(0.03, 1e-3, abstol=1e-11, reltol=1e-9, dtmin=1e-30), u0)
     e2 = units(u2[sel], z["u"])
-    assert rc2 == 0 and e2.max() <= 60 and float(np.sqrt((e2 ** 2).mean(axis=1)).max()) <= 5
+    assert rc2 == 0 and e2.max() <= 45 and float(np.sqrt((e2 ** 2).mean(axis=1)).max()) <= 4.7   # 30-34 / 3.2-3.6
     # EXTENSION kin_params.solve_chunks = 2: warm continuation across the chunk starts of this static solve (no rate update,
     # nothing happens at a chunk boundary): fewer steps, and closer to the truth than the re-initialising run
     tw, uw, rcw, stw, status = h.solve(kp(0.03, 1e-3, chunks=2), u0)
     assert status == capi.KIN_OK and rcw == 0 and stw["n_chunks"] == 30 and np.array_equal(tw, t)
     ew = units(uw[sel], z["u"])
     assert stw["n_steps"] < 0.8 * st["n_steps"] and stw["n_factor"] < 0.8 * st["n_factor"]     # measured 1 024 / 128 against 1 489 / 243
-    assert ew.max() <= 100 and ew.max() < e.max()                                                # measured 58 against 170
+    rms_w, rms_c = float(np.sqrt((ew ** 2).mean(axis=1)).max()), float(np.sqrt((e ** 2).mean(axis=1)).max())
+    # (the maximum of this run is the most erratic of all: 56-164 units over the three bands and two orders of the solves on the
+    # handle; its rms 3.3-4.3 against the re-initialising run's 5.1-7.6 is what the claim rests on)
+    assert ew.max() <= 225 and rms_w <= 5.7 and rms_w < rms_c
     h.close()
 
 
@@ -322,16 +328,16 @@ def test_c3_hundred_chunks_against_truth(golden_dir, c3):
     t, u, rc, st, status = h.solve(kp(0.1, 1e-3), u0)
     assert status == capi.KIN_OK and rc == 0 and st["n_chunks"] == 100 and st["n_retries"] == 0
     mx, rms, e = against_truth(t, u)
-    assert mx <= 750 and rms <= 20 and e[1].max() <= 100
+    assert mx <= 820 and rms <= 21 and e[1].max() <= 100                # 500-629 / 12.6-15.9 (bounds: see the 30-chunk test)
     t, u, rc, st, status = h.solve(kp(0.1, 1e-3, save=1e-2, chunks=False, dtmin=1e-30), u0)
     mx, rms, _ = against_truth(t, u)
-    assert rc == 0 and st["n_restarts"] == 1 and mx <= 140 and rms <= 6
+    assert rc == 0 and st["n_restarts"] == 1 and mx <= 140 and rms <= 5.7   # 54-106 / 3.4-4.4
     t, u, rc, st, status = h.solve(kp(0.1, 1e-3, chunks=2), u0)
     mx, rms, _ = against_truth(t, u)
-    assert rc == 0 and st["n_chunks"] == 100 and mx <= 200 and rms <= 6
+    assert rc == 0 and st["n_chunks"] == 100 and mx <= 200 and rms <= 6.8   # 138-151 / 4.0-5.2
     t, u, rc, st, status = h.solve(kp(0.1, 1e-3, abstol=1e-11, reltol=1e-9, dtmin=1e-30), u0)
     mx, rms, _ = against_truth(t, u)
-    assert rc == 0 and mx <= 80 and rms <= 5          # tolerance proportional, in DEFAULT units
+    assert rc == 0 and mx <= 65 and rms <= 4.7        # tolerance proportional, in DEFAULT units: 29-50 / 3.1-3.5
     h.close()
 
 
