@@ -405,8 +405,13 @@ void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
   const int64_t per = ceil_div(K, (int64_t)replica_threads_max());
   const int64_t Tn = ceil_div(K, per);
   while ((int64_t)h->replicas.size() < Tn) {
+    // LU-cache budget of a replica: its share of 70 % of what the device has FREE now, as if every thread of the limit were to get
+    // a replica (a later call with more members then finds the same share left for the replicas it adds; the budget is fixed when a
+    // replica's Solver is built, at its first solve)
+    size_t free_b = 0, total_b = 0;
+    KIN_HIP(hipMemGetInfo(&free_b, &total_b));
     h->replicas.push_back(clone_for_solves(h));
-    h->replicas.back()->lu_budget_mb = (size_t)(200 * 1024) / (size_t)std::max<int64_t>(Tn, 6);   // the LU caches share ~200 GB of the 288
+    h->replicas.back()->lu_budget_mb = std::max<size_t>(64, (size_t)((double)free_b * 0.7 / (1024.0 * 1024.0)) / (size_t)replica_threads_max());
   }
   KIN_HIP(hipStreamSynchronize(h->stream));
   std::vector<std::string> errs((size_t)Tn);
@@ -414,7 +419,9 @@ void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
   // the save times are the members' common grid: those of the member that got furthest (the first of them)
   std::mutex grid_mu;
   int64_t grid_n = -1;
-  for (int64_t t = 0; t < Tn; t++)
+  th.reserve((size_t)Tn);
+  std::string spawn_err;
+  for (int64_t t = 0; t < Tn && spawn_err.empty(); t++) try {
     th.emplace_back([&, t] {
       try {
         kin_network* c = h->replicas[(size_t)t];
@@ -452,7 +459,9 @@ void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
         }
       } catch (const std::exception& e) { errs[(size_t)t] = e.what(); }
     });
+  } catch (const std::exception& e) { spawn_err = e.what(); }   // (the threads that did start are joined below before anything is thrown)
   for (auto& x : th) x.join();
+  if (!spawn_err.empty()) throw KinError(ERR_DEVICE, "ensemble: could not start a member thread: " + spawn_err);
   for (auto& e : errs) if (!e.empty()) throw KinError(ERR_DEVICE, "ensemble member failed: " + e);
 }
 
@@ -480,13 +489,15 @@ int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, cons
       replica_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
     else if (route && !strcmp(route, "lockstep"))
       batched_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
-    else if (!force_batched && resident_fits(h))
+    else if (!force_batched && resident_ensemble_route(h, K))
       resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
     // few members of a network too large for a compute unit: kin_solve calls on host threads, one member per thread up to the
     // thread limit (KIN_ENSEMBLE_THREADS_K raises the member count that takes this route: the threads then take several
     // members each - measured, profiles/r04_ensemble_route_crossover.jsonl: from 16 members on the lockstep rounds are ahead
     // at 3 000 and 10 000 species)
-    else if (!force_batched && K <= replica_members_max())
+    // ... and ANY number of members when the lockstep form does not take the network's factorisation (it needs the fused solve
+    // with a dense Schur block; KIN_LU_FUSED=0 or a network without hubs has none): the threads then take several members each
+    else if (!force_batched && (K <= replica_members_max() || !ensemble_batched_supported(h, nullptr)))
       replica_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
     else
       batched_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);

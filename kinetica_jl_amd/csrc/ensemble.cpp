@@ -165,10 +165,14 @@ struct EnsembleSolver {
     const size_t part = (size_t)ens_reduce_doubles(N);
     const size_t per = al((size_t)BDF_D_ROWS * n) + 8 * al(n) + al((size_t)nnz) + al(r) + al(2 * r + 2) + al(r) + al(part);
     if (K_ != K) {
+      // (freed pointers are nulled and K forgotten first: an allocation below may throw, and neither the destructor nor the
+      // next call may find a dangling pointer or a K that matches buffers which are gone)
       if (h_ctrl) (void)hipHostFree(h_ctrl);
       if (h_bad) (void)hipHostFree(h_bad);
       if (h_ops) (void)hipHostFree(h_ops);
       if (h_drift) (void)hipHostFree(h_drift);
+      h_ctrl = nullptr; h_bad = nullptr; h_ops = nullptr; h_drift = nullptr; h_ctrl_dev = nullptr;
+      K = 0;
       KIN_HIP(hipHostMalloc((void**)&h_ctrl, (size_t)K_ * sizeof(BdfCtrl), hipHostMallocCoherent | hipHostMallocMapped));
       if (!h_seq) { KIN_HIP(hipHostMalloc((void**)&h_seq, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)); *h_seq = 0; }
       fast_sync = !(getenv("KIN_ENSEMBLE_FAST_SYNC") && atoi(getenv("KIN_ENSEMBLE_FAST_SYNC")) == 0) && !getenv("KIN_NO_FAST_SYNC");
@@ -183,6 +187,8 @@ struct EnsembleSolver {
     K = K_; n_slots = slots_; cap = cap_;
     state.alloc((size_t)K * per);
     sol.alloc((size_t)K * (size_t)cap * n);
+    // rows beyond a member's n_saved (a member that failed early) read as zeros in out_u, not as whatever the buffer held
+    KIN_HIP(hipMemsetAsync(sol.p, 0, (size_t)K * (size_t)cap * n * sizeof(double), s));
     d_ctrl.alloc(K); d_bad.alloc(K); d_reps.alloc(K); d_ops.alloc((size_t)3 * K); d_drift.alloc((size_t)K * LU_MAX_SLOTS);
     KIN_HIP(hipMemsetAsync(d_ctrl.p, 0, (size_t)K * sizeof(BdfCtrl), s));
     KIN_HIP(hipMemsetAsync(d_bad.p, 0, (size_t)K * sizeof(int), s));
@@ -597,7 +603,7 @@ struct MemberBackend {
     q.op.i0 = with_f1 ? 1 : 0; q.op.d0 = atol; q.op.d1 = rtol;
     run(q);
     const BdfCtrl& c = E.ctrl_of[t];
-    return ResNorms{c.scratch[0], c.scratch[1], c.scratch[2], c.nonfinite};
+    return ResNorms{c.scratch[0], c.scratch[1], c.scratch[2], c.scratch[3], c.nonfinite};
   }
   void init_D(bool from_ytmp, double hh) {
     pend_accept = false; pend_change = false;     // D is rebuilt: whatever was deferred on the old one is moot
@@ -748,22 +754,34 @@ static void batched_ensemble_block(kin_network* h, const kin_params& p, int64_t 
   std::vector<std::string> errs((size_t)K);
   std::vector<std::thread> th;
   E.start_gj_server();
-  for (int64_t t = 0; t < K; t++)
-    th.emplace_back([&, t] {
-      try {
-        (void)hipSetDevice(h->device);
-        MemberBackend b(E, (int)t, P, d_u0.p + (size_t)t * N, n_stops > 0 && k_table ? h->table.p : nullptr, T_stops);
-        ResidentBdf<MemberBackend> ctl(b, P);
-        res[t] = ctl.run();
-      } catch (const std::exception& e) {
-        errs[t] = e.what();
-        res[t] = ResResult{};
-        res[t].retcode = RES_RET_UNSTABLE;
-      }
-      E.member_done();
-    });
+  th.reserve((size_t)K);
+  std::string spawn_err;
+  for (int64_t t = 0; t < K; t++) {
+    try {
+      th.emplace_back([&, t] {
+        try {
+          (void)hipSetDevice(h->device);
+          MemberBackend b(E, (int)t, P, d_u0.p + (size_t)t * N, n_stops > 0 && k_table ? h->table.p : nullptr, T_stops);
+          ResidentBdf<MemberBackend> ctl(b, P);
+          res[t] = ctl.run();
+        } catch (const std::exception& e) {
+          errs[t] = e.what();
+          res[t] = ResResult{};
+          res[t].retcode = RES_RET_UNSTABLE;
+        }
+        E.member_done();
+      });
+    } catch (const std::exception& e) {
+      // the host refused another thread: the members that never started leave the rounds (or the started ones would wait for them
+      // for ever), the started ones are joined (a joinable std::thread that goes out of scope terminates the process)
+      spawn_err = e.what();
+      for (int64_t q = t; q < K; q++) { res[q] = ResResult{}; res[q].retcode = RES_RET_UNSTABLE; E.member_done(); }
+      break;
+    }
+  }
   for (auto& x : th) x.join();
   E.stop_gj_server();
+  if (!spawn_err.empty()) throw KinError(ERR_DEVICE, "ensemble: could not start a member thread: " + spawn_err);
   for (auto& e : errs) if (!e.empty()) throw KinError(ERR_DEVICE, "ensemble member failed: " + e);
   const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   if (out_u) E.sol.download(out_u, (size_t)K * (size_t)g.cap * N, s);

@@ -220,7 +220,27 @@ bool resident_eligible(kin_network* h, const kin_params& p, bool continuous, boo
   return RS->ok && RS->lu.m <= resident_max_dense_single();
 }
 
-bool resident_fits(kin_network* h) { return get_resident(h)->ok; }
+// the dynamic LDS is at least 8 (4 N + R) bytes whatever the factorisation looks like (resident_dyn_lds): a network beyond that
+// never fits, and is told so WITHOUT the symbolic analysis a ResidentSolver starts with (0.2-1.4 s and a second set of LU plans
+// on a 10k-50k species handle)
+static bool resident_can_fit(const kin_network* h) {
+  return (size_t)(4 * h->host.N + h->host.R) * sizeof(double) <= RES_LDS_BUDGET;
+}
+
+bool resident_fits(kin_network* h) { return resident_can_fit(h) && get_resident(h)->ok; }
+
+// Does an ensemble of K members take the one-launch form? Not beyond the kernel's limits, and not FEW members of a network at the
+// upper end of what the kernel takes: one workgroup per member lasts as long as its slowest member's resident solve, which from
+// ~700 species on is slower than the member's own kin_solve on the host-driven path (table DESIGN 0 "resident vs host-driven"),
+// so up to 32 members of such a network are faster as kin_solve calls on host threads / lockstep rounds
+// (profiles/r04_ensemble_route_crossover.jsonl: 1 000 species, 16 members 0.5 s against 0.34-1.1 s; from 64 members on the launch
+// is 3-4x ahead, at <= 700 species at every K).
+bool resident_ensemble_route(kin_network* h, int64_t K) {
+  if (!resident_can_fit(h)) return false;
+  static const int small_k = getenv("KIN_RESIDENT_ENSEMBLE_MIN_K") ? atoi(getenv("KIN_RESIDENT_ENSEMBLE_MIN_K")) : 32;
+  if (h->host.N > 700 && K < small_k) return false;
+  return get_resident(h)->ok;
+}
 
 int resident_solve(kin_network* h, const kin_params& p, const double* u0, const double* tstops, const double* T_stops,
                    const double* k_table, int64_t n_stops, kin_stats* stats) {

@@ -388,17 +388,28 @@ RES_PHASE ResNorms ph_norms(bool with_f1, double atol, double rtol) {
   const double* y = L_y();
   gcd_t* f0p = glob((const double*)g_cx.T.f0); gcd_t* f1p = glob((const double*)g_cx.T.f1);
   double v[4] = {0.0, 0.0, 0.0, 0.0};
+  double vm = 0.0;   // max |f0| / (0.1 |y| + w): the reciprocal of CVODE's upper bound on the first step (cvUpperBoundH0)
   for (int i = threadIdx.x; i < N; i += RES_WG) {
     const double y0 = y[i], f0 = f0p[i];
     const double sc = atol + rtol * fabs(y0);
     const double a = y0 / sc, b = f0 / sc;
     v[0] += a * a; v[1] += b * b;
+    vm = fmax(vm, fabs(f0) / (0.1 * fabs(y0) + sc));
     if (!isfinite(f0)) v[3] = 1.0;
     if (with_f1) { const double f1 = f1p[i]; const double c = (f1 - f0) / sc; v[2] += c * c; if (!isfinite(f1)) v[3] = 1.0; }
   }
   wg_reduce<4>(v);
+  // (a restart's reduction, not a step's: plain shuffles)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off, 64));
+  if ((threadIdx.x & 63) == 0) g_sh.red[threadIdx.x >> 6][0] = vm;
+  __syncthreads();
+  double dmax = 0.0;
+#pragma unroll
+  for (int w = 0; w < RES_WAVES; w++) dmax = fmax(dmax, g_sh.red[w][0]);
+  __syncthreads();
   const double Nd = (double)N;
-  return ResNorms{sqrt(v[0] / Nd), sqrt(v[1] / Nd), sqrt(v[2] / Nd), v[3] > 0.0 ? 1 : 0};
+  return ResNorms{sqrt(v[0] / Nd), sqrt(v[1] / Nd), sqrt(v[2] / Nd), dmax, v[3] > 0.0 ? 1 : 0};
 }
 
 RES_PHASE void ph_init_D(bool from_ytmp, double h) {

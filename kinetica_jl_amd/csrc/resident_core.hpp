@@ -52,7 +52,7 @@ struct ResParams {
   int64_t crate_max_age, lu_max_age;
   int32_t n_slots, carry_rate;
   int64_t sol_cap;                 // rows of the solution buffer
-  int32_t profile, h0_decade;      // device: fill ResResult::prof (KIN_RESIDENT_PROFILE); first step on the decade grid (solver.cpp)
+  int32_t profile, pad0;           // device: fill ResResult::prof (KIN_RESIDENT_PROFILE)
 };
 
 struct ResStats {
@@ -68,7 +68,8 @@ struct ResResult {
   int64_t prof[20];   // device only: 10 ns ticks per phase kind (resident.hip: ProfId), 0 in the CPU replay
 };
 
-struct ResNorms { double d0, d1, d2; int nonfinite; };
+// rms(y / w), rms(f0 / w), rms((f1 - f0) / w), max |f0| / (0.1 |y| + w) over the species, w = atol + rtol |y|
+struct ResNorms { double d0, d1, d2, dmax; int nonfinite; };
 struct ResSums { double s, se, sm, sp, neg; };   // update, error test of order / order - 1 / order + 1, negative entries
 
 KIN_HD inline double res_inf() { return HUGE_VAL; }
@@ -134,7 +135,8 @@ struct ResidentBdf {
   double t = 0, h_abs = 0, atol = 0, rtol = 0, newton_tol = 0, dtmin = 0, fail_score = 0;
   int order = 1, n_equal = 0, cur_slot = 0;
   bool lu_valid = false, jac_current = false, force_jac_refresh = false, force_fresh_lu = false, cache_suspended = false,
-       slot_is_fresh = false, pending_order_change = false;
+       slot_is_fresh = false, pending_order_change = false,
+       first_selection = false;   // the next step-size selection is the first since a (re)initialisation: growth cap 1e4 (CVODE's ETAMX1), 10 afterwards
   int64_t steps_since_jac = 0, jac_stamp_now = 0, use_clock = 0, iters_left = 0;
   double err_m = 0, err_p = 0, err_o = 0, safety_o = 0.9;
   ResStats st;
@@ -197,7 +199,14 @@ struct ResidentBdf {
     if (P.lu_band > 0.0 && P.lu_drift_max > 0.0) st.n_lu_dropped += b.drift_check(P.lu_drift_max);
   }
 
-  // (re)start at segment-local time 0 from the state in y: order 1, fresh initial step, fresh Jacobian (Solver::restart)
+  // (re)start at segment-local time 0 from the state in y: order 1, fresh initial step, fresh Jacobian (Solver::restart).
+  // Initial step = CVODE's (cvode.c: cvHin, cvUpperBoundH0, cvYddNorm - the documented solver of the reference,
+  // docs/src/getting-started.md:69, re-initialised at every chunk start and rate update, methods.jl:260, 819): the h with
+  // ||h^2 y'' / 2||_WRMS = 1, y'' from a difference quotient of f along the Euler direction, iterated (at most 4 evaluations)
+  // until two successive estimates agree within a factor of 2, halved (H_BIAS), kept inside [hlb, hub]: hlb = 100 ulp of the
+  // segment, hub = a tenth of the segment but no step over which ANY component moves by more than a tenth of itself plus its
+  // error weight (`dmax` of the norms). Then rounded DOWN to a power of ten: the step size climbs through the same values after
+  // every restart, so the iteration matrices of the previous segment's climb are found in the LU cache again.
   KIN_HD bool restart(double t_bound) {
     t = 0.0;
     st.n_restarts++;
@@ -207,22 +216,34 @@ struct ResidentBdf {
     b.rhs_y_to_f0(); st.n_rhs++;
     ResNorms n0 = b.norms(false, atol, rtol);
     if (n0.nonfinite) return false;
-    const double interval = fabs(t_bound);
-    double h0 = (n0.d0 < 1e-5 || n0.d1 < 1e-5) ? 1e-6 : 0.01 * n0.d0 / n0.d1;
-    h0 = h0 < interval ? h0 : interval;
-    b.ytmp_axpy(h0);
-    b.rhs_ytmp_to_f1(); st.n_rhs++;
-    ResNorms n1 = b.norms(true, atol, rtol);
-    if (n1.nonfinite) return false;
-    const double d1 = n1.d1, d2 = n1.d2 / h0;
-    const double dm = d1 > d2 ? d1 : d2;
-    const double floor_h = h0 * 1e-3 > 1e-6 ? h0 * 1e-3 : 1e-6;
-    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? floor_h : pow(0.01 / dm, 0.5);
-    double hm = 100.0 * h0 < h1 ? 100.0 * h0 : h1;
-    h_abs = hm < interval ? hm : interval;
-    if (P.h0_decade) h_abs = res_decade_floor(h_abs);   // (solver.cpp restart(): the first step rounded down to a power of ten)
+    const double tdist = fabs(t_bound);
+    const double hlb = 100.0 * 2.220446049250313e-16 * tdist;
+    double hub = 0.1 * tdist;
+    if (hub * n0.dmax > 1.0) hub = 1.0 / n0.dmax;
+    double hg = sqrt(hlb * hub), hnew = hg;
+    if (hub >= hlb) {
+      for (int count = 1; count <= 4; count++) {
+        b.ytmp_axpy(hg);
+        b.rhs_ytmp_to_f1(); st.n_rhs++;
+        ResNorms n1 = b.norms(true, atol, rtol);
+        if (n1.nonfinite) return false;
+        const double ydd = n1.d2 / hg;
+        hnew = ydd * hub * hub > 2.0 ? sqrt(2.0 / ydd) : sqrt(hg * hub);
+        if (count == 4) break;
+        const double hrat = hnew / hg;
+        if (hrat > 0.5 && hrat < 2.0) break;
+        if (count > 1 && hrat > 2.0) { hnew = hg; break; }
+        hg = hnew;
+      }
+    }
+    double h0 = 0.5 * hnew;
+    h0 = h0 < hlb ? hlb : h0;
+    h0 = h0 > hub ? hub : h0;
+    h0 = h0 < tdist ? h0 : tdist;
+    h_abs = res_decade_floor(h0);
     b.init_D(false, h_abs);
     order = 1; n_equal = 0; fail_score = 0.0;
+    first_selection = true;
     return true;
   }
 
@@ -352,6 +373,7 @@ struct ResidentBdf {
         change_D(order, eta);
         n_equal = 0; lu_valid = false;
         st.n_rejected++;
+        first_selection = false;   // (CVODE: any failed attempt sets etamax = 1, the first step's 1e4 is gone)
         if (converged) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
@@ -367,6 +389,7 @@ struct ResidentBdf {
         n_equal = 0;
         force_fresh_lu = band > 0.0;
         st.n_rejected++;
+        first_selection = false;
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
@@ -405,7 +428,9 @@ struct ResidentBdf {
     }
     order += arg - 1;
     const double f1 = safety_o * best;
-    const double factor = f1 < 10.0 ? f1 : 10.0;
+    const double cap = first_selection ? 1e4 : 10.0;
+    first_selection = false;
+    const double factor = f1 < cap ? f1 : cap;
     h_abs *= factor;
     change_D(order, factor);
     n_equal = 0;

@@ -62,7 +62,6 @@ inline void res_default_settings(ResParams& P, int n_slots_max) {
   P.crate_max_age = envi("KIN_CRATE_AGE", 10);
   P.lu_max_age = envi("KIN_LU_MAX_AGE", 50);
   P.carry_rate = envi("KIN_CARRY_RATE", 1) != 0 ? 1 : 0;
-  P.h0_decade = envi("KIN_H0_DECADE", 0) != 0 ? 1 : 0;
 }
 
 inline void res_fill_params(ResParams& P, const kin_params& p, const ResGrid& g) {

@@ -43,7 +43,7 @@ static inline double decade_floor(double h) {
 }
 
 namespace {
-constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
+constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0, FIRST_MAX_FACTOR = 1e4;
 const double KAPPA[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
 constexpr double INF = std::numeric_limits<double>::infinity();
 
@@ -139,7 +139,6 @@ struct Solver {
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
       if (const char* e = getenv("KIN_LU_ABSBAND")) lu_absband = atof(e);
       if (const char* e = getenv("KIN_LU_PAIR")) lu_pair = atoi(e) != 0;
-      if (const char* e = getenv("KIN_H0_DECADE")) h0_decade = atoi(e) != 0;
       if (const char* e = getenv("KIN_LU_PAIR_MIN_M")) lu_pair_min_m = atoi(e);
       if (const char* e = getenv("KIN_LU_PAIR_MAX_M")) lu_pair_max_m = atoi(e);
       if (const char* e = getenv("KIN_LU_PAIR_FAST")) lu_pair_fast = std::max(1, std::min((int)GJ_BMAX, atoi(e)));
@@ -328,27 +327,48 @@ struct Solver {
     if (jnorm_pending) { jnorm = 2.0 * h_drift[LU_MAX_SLOTS]; jnorm_pending = false; }
     if (hc->nonfinite) return false;
     const double interval = std::fabs(t_bound - t0);
-    const double d0 = hc->scratch[0], d1 = hc->scratch[1];
-    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-    h0 = std::min(h0, interval);
-    launch_axpy_out(N, y.p, h0, f0.p, ytmp.p, s);
-    rhs(ytmp.p, f1.p);
-    launch_bdf_norms(N, y.p, f0.p, f1.p, atol, rtol, ctrl.p, s);
-    sync_ctrl();
-    if (hc->nonfinite) return false;
-    const double d2 = hc->scratch[2] / h0;
-    // exponent 1 / (order + 1): the BDF starts at order 1, the explicit pair has error order 4 (SciPy select_initial_step)
-    const double ex = explicit_mode ? 0.2 : 0.5;
-    double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), ex);
-    h_abs = std::min({100.0 * h0, h1, interval});
-    // KIN_H0_DECADE=1 (off by default): the first step rounded DOWN to a power of ten. The step size then climbs through the same
-    // values after every restart (x10 per selection while the cap holds), so the matrices of the previous chunk's climb are
-    // found in the LU cache again instead of being made anew next to them: C3, 100 chunks 363 -> 269 factorisations, 0.455 ->
-    // 0.391 s. Against the truths the rms deviations do not move and the maxima move both ways (30 chunks 170 -> 137 units,
-    // 100 chunks 589 -> 627, at 10x tighter tolerances 41 -> 110; profiles/r04_h0_decade_ab.txt) - two of them past the bounds
-    // tests/test_gpu_configs.py asserts, which is why it is a switch and not the default. The same rule, under the same
-    // switch, in resident_core.hpp, oracle/cpu_bdf.cpp and oracle/bdf.py.
-    if (h0_decade && !explicit_mode) h_abs = decade_floor(h_abs);
+    if (explicit_mode) {
+      // the explicit pair keeps SciPy's select_initial_step (its oracle is SciPy's own RK45): exponent 1 / (error order + 1)
+      const double d0 = hc->scratch[0], d1 = hc->scratch[1];
+      double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+      h0 = std::min(h0, interval);
+      launch_axpy_out(N, y.p, h0, f0.p, ytmp.p, s);
+      rhs(ytmp.p, f1.p);
+      launch_bdf_norms(N, y.p, f0.p, f1.p, atol, rtol, ctrl.p, s);
+      sync_ctrl();
+      if (hc->nonfinite) return false;
+      const double d2 = hc->scratch[2] / h0;
+      const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 0.2);
+      h_abs = std::min({100.0 * h0, h1, interval});
+    } else {
+      // CVODE's initial step (cvode.c: cvHin / cvUpperBoundH0 / cvYddNorm; resident_core.hpp restart() has the description),
+      // rounded down to a power of ten: every restart's climb passes through the same step sizes, so the matrices of the
+      // previous segment's climb are found in the LU cache again (C3, 100 chunks: 363 -> 269 factorisations in round 4's A/B,
+      // profiles/r04_h0_decade_ab.txt; the rms deviations from the truths do not move)
+      const double hlb = 100.0 * std::numeric_limits<double>::epsilon() * std::max(std::fabs(t0), std::fabs(t_bound));
+      double hub = 0.1 * interval;
+      if (hub * hc->scratch[3] > 1.0) hub = 1.0 / hc->scratch[3];
+      double hg = std::sqrt(hlb * hub), hnew = hg;
+      if (hub >= hlb) {
+        for (int count = 1; count <= 4; count++) {
+          launch_axpy_out(N, y.p, hg, f0.p, ytmp.p, s);
+          rhs(ytmp.p, f1.p);
+          launch_bdf_norms(N, y.p, f0.p, f1.p, atol, rtol, ctrl.p, s);
+          sync_ctrl();
+          if (hc->nonfinite) return false;
+          const double ydd = hc->scratch[2] / hg;
+          hnew = ydd * hub * hub > 2.0 ? std::sqrt(2.0 / ydd) : std::sqrt(hg * hub);
+          if (count == 4) break;
+          const double hrat = hnew / hg;
+          if (hrat > 0.5 && hrat < 2.0) break;
+          if (count > 1 && hrat > 2.0) { hnew = hg; break; }
+          hg = hnew;
+        }
+      }
+      double h0 = 0.5 * hnew;
+      h0 = std::min(std::max(h0, hlb), hub);
+      h_abs = decade_floor(std::min(h0, interval));
+    }
     if (explicit_mode) {
       rk_K.alloc((size_t)7 * N); rk_yold.alloc(N); rk_ynew.alloc(N);
       KIN_HIP(hipMemcpyAsync(D.p, y.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));          // D[0] = current state
@@ -364,6 +384,7 @@ struct Solver {
     fail_score = 0.0;
     cf_recent = false;
     h_ceiling = INF;
+    first_selection = true;
     return true;
   }
 
@@ -631,7 +652,6 @@ struct Solver {
   double lu_absband = 0.0, jnorm = 0.0;   // KIN_LU_ABSBAND: |c - c_fact| * (2 max |J_ii|) a slot may be away from c; jnorm = that scale, measured at restarts
   bool jnorm_pending = false;
   bool lu_pair = false;
-  bool h0_decade = false;
   int lu_pair_min_m = 400, lu_pair_max_m = 1536, lu_pair_fast = 2;   // matrices per chain while the step size climbs by its cap
   double last_factor_c = 0.0;      // c of the last factorisation since the restart (0: none yet)
   int64_t last_factor_restart = -1;
@@ -934,6 +954,7 @@ struct Solver {
         n_equal = 0;
         lu_valid = false;
         st.n_rejected++;
+        first_selection = false;   // (CVODE: any failed attempt sets etamax = 1, the first step's 1e4 is gone)
         cf_recent = cf_recent || conv_failure;
         if (!conv_failure || cf_resets) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
@@ -953,6 +974,7 @@ struct Solver {
         // the new c); with the cache the retry gets a factorisation of its own
         force_fresh_lu = lu_band > 0.0;
         st.n_rejected++;
+        first_selection = false;
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
@@ -983,7 +1005,7 @@ struct Solver {
 
   // order / step-size selection after an accepted step (done after the dense-output saves,
   // which need the differences of the step just taken)
-  bool pending_order_change = false;
+  bool pending_order_change = false, first_selection = false;
   double err_m = 0, err_p = 0, err_o = 0, safety_o = 0.9;
   void select_order() {
     if (explicit_mode || !pending_order_change) return;
@@ -999,7 +1021,9 @@ struct Solver {
       if (f > best) { best = f; arg = i; }
     }
     order += arg - 1;
-    double factor = std::min(MAX_FACTOR, safety_o * best);
+    // growth cap 1e4 at the first selection after a (re)initialisation, 10 afterwards (CVODE: ETAMX1, ETAMX2 / ETAMX3)
+    double factor = std::min(first_selection ? FIRST_MAX_FACTOR : MAX_FACTOR, safety_o * best);
+    first_selection = false;
     if (cf_recent && cf_growth_cap > 0.0) factor = std::min(factor, cf_growth_cap);
     cf_recent = false;
     if (h_abs * factor > h_ceiling) factor = std::max(h_ceiling / h_abs, MIN_FACTOR);   // (never a cut below what a rejection would make)

@@ -1,5 +1,6 @@
 // BDF integrator + chunk/tstop driver behind kin_solve (solver.cpp, lu.cpp, solver_kernels.hip).
 #pragma once
+#include <string>
 #include "../../include/kinetica_hip.h"
 #include "handle.hpp"
 
@@ -29,6 +30,10 @@ void resident_ensemble(kin_network* h, const kin_params& p, int64_t K, const dou
                        double* out_t, double* out_u, int64_t* n_saved, int32_t* retcodes, kin_stats* stats);
 // does the network fit the resident kernel (its state, rates and solve vectors in one compute unit's LDS)?
 bool resident_fits(kin_network* h);
+// ... and does an ensemble of K members take the one-launch form (resident.cpp: not few members of a network at the kernel's upper end)?
+bool resident_ensemble_route(kin_network* h, int64_t K);
+// can the lockstep form (ensemble.cpp) take this network's factorisation? (fused solve with a dense Schur block)
+bool ensemble_batched_supported(kin_network* h, std::string* why);
 // K members of a network beyond that, advanced in lockstep rounds of batched launches (ensemble.cpp); same arguments
 void batched_ensemble(kin_network* h, const kin_params& p, int64_t K, const double* u0, const double* k, const double* T,
                       const double* tstops, const double* T_stops, const double* k_table, int64_t n_stops, int64_t* out_rows,

@@ -495,6 +495,23 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
   return sh[16];
 }
 
+// the same shape for a maximum of non-negative values (NaN entries are ignored: the callers report them separately)
+__device__ __forceinline__ double block_max_1024(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; i++) t = fmax(t, sh[i]);
+    sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
 __global__ __launch_bounds__(256) void bdf_predict_kernel(int N, int order, const double* __restrict__ D, BdfCoef cf,
                                                           double atol, double rtol, double* __restrict__ y,
                                                           double* __restrict__ psi, double* __restrict__ d,
@@ -1043,26 +1060,29 @@ __global__ __launch_bounds__(256) void axpy_out_kernel(int N, const double* __re
   if (i < N) out[i] = a[i] + s * b[i];
 }
 
-// norms for the initial step size: rms(y0/sc), rms(f0/sc), rms((f1-f0)/sc), sc = atol + rtol |y0|;
+// norms for the initial step size: rms(y0/sc), rms(f0/sc), rms((f1-f0)/sc), max |f0| / (0.1 |y0| + sc), sc = atol + rtol |y0|;
 // f1 may be null. Also reports non-finite f.
 __global__ __launch_bounds__(1024) void bdf_norms_kernel(int N, const double* __restrict__ y0, const double* __restrict__ f0,
                                                          const double* __restrict__ f1, double atol, double rtol, BdfCtrl* ctrl) {
   __shared__ double sh[17];
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, vm = 0.0;
   int bad = 0;
   for (int i = threadIdx.x; i < N; i += 1024) {
     const double sc = atol + rtol * fabs(y0[i]);
     const double a = y0[i] / sc, b = f0[i] / sc;
     s0 += a * a; s1 += b * b;
+    vm = fmax(vm, fabs(f0[i]) / (0.1 * fabs(y0[i]) + sc));
     if (!isfinite(f0[i])) bad = 1;
     if (f1) { const double c = (f1[i] - f0[i]) / sc; s2 += c * c; if (!isfinite(f1[i])) bad = 1; }
   }
   const double t0 = block_sum_1024(s0, sh), t1 = block_sum_1024(s1, sh), t2 = block_sum_1024(s2, sh);
   const double tb = block_sum_1024((double)bad, sh);
+  const double tm = block_max_1024(vm, sh);
   if (threadIdx.x == 0) {
     ctrl->scratch[0] = sqrt(t0 / (double)N);
     ctrl->scratch[1] = sqrt(t1 / (double)N);
     ctrl->scratch[2] = sqrt(t2 / (double)N);
+    ctrl->scratch[3] = tm;
     ctrl->nonfinite = tb > 0.0;
   }
 }

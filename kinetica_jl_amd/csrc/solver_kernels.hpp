@@ -23,7 +23,7 @@ struct BdfCtrl {
   double err_norm, err_m_norm, err_p_norm;
   double crate;        // contraction rate carried by the factorisation in use (CVODE's crate): set from the host's per-slot copy
                        // at iteration 0, updated by every later iteration, read back by the host with the step's result
-  double scratch[3];
+  double scratch[4];   // bdf_norms_kernel: rms(y / w), rms(f0 / w), rms((f1 - f0) / w), max |f0| / (0.1 |y| + w)
   int newton_done, converged, n_iter, nonfinite, any_negative;
   int ticket;   // arrival counter of the multi-workgroup reductions (back to 0 when a launch ends)
   int lu_bad;   // set by a factorisation that met a vanishing pivot (|multiplier| > 1e8); cleared by the host, NOT by the predictor

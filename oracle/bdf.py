@@ -37,6 +37,7 @@ MAX_ORDER = 5
 NEWTON_MAXITER = 4
 MIN_FACTOR = 0.2
 MAX_FACTOR = 10.0
+FIRST_MAX_FACTOR = 1e4     # growth cap of the first step-size selection after a (re)initialisation (CVODE: ETAMX1), MAX_FACTOR afterwards
 EPS = np.finfo(float).eps
 
 KAPPA = np.array([0, -0.1850, -1 / 9, -0.0823, -0.0415, 0])
@@ -107,6 +108,7 @@ class OracleBDF:
                           n_restarts=0, n_lu_reused=0)
         self.I = sp.identity(n, format="csc")
         self.iters_left = 0
+        self.first_selection = False
         self.pre_attempt = None   # continuous rates: called with the local time of every step attempt
 
     def set_tols(self, atol, rtol):
@@ -234,24 +236,51 @@ class OracleBDF:
             return False
         interval = abs(t_bound - t0)
         scale = self.atol + np.abs(y0) * self.rtol
-        d0, d1 = rms(y0 / scale), rms(f0 / scale)
-        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
-        h0 = min(h0, interval)
-        f1 = self._f(y0 + h0 * f0)
-        if not np.all(np.isfinite(f1)):
-            return False
-        d2 = rms((f1 - f0) / scale) / h0
-        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.5
-        self.h_abs = min(100 * h0, h1, interval)
-        # KIN_H0_DECADE=1: the first step rounded down to a power of ten, exact IEEE operations only (kinetica_jl_amd/csrc/solver.cpp: decade_floor)
-        # (not in SciPy mode: tests/test_oracle_bdf.py pins that mode to scipy.integrate.BDF's own step sequence)
-        if not self.scipy_newton and os.environ.get("KIN_H0_DECADE", "0") != "0" and self.h_abs > 0.0 and np.isfinite(self.h_abs):
+        if self.scipy_newton:
+            # SciPy mode (tests/test_oracle_bdf.py pins it to scipy.integrate.BDF's own step sequence): SciPy's select_initial_step
+            d0, d1 = rms(y0 / scale), rms(f0 / scale)
+            h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+            h0 = min(h0, interval)
+            f1 = self._f(y0 + h0 * f0)
+            if not np.all(np.isfinite(f1)):
+                return False
+            d2 = rms((f1 - f0) / scale) / h0
+            h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.5
+            self.h_abs = min(100 * h0, h1, interval)
+        else:
+            # CVODE's initial step (cvode.c: cvHin / cvUpperBoundH0 / cvYddNorm; oracle/cpu_bdf.cpp `cvhin` has the description),
+            # rounded DOWN to a power of ten by exact IEEE operations only (kinetica_jl_amd/csrc/solver.cpp: decade_floor)
+            hlb = 100.0 * EPS * max(abs(t0), abs(t_bound))
+            hub_inv = float(np.max(np.abs(f0) / (0.1 * np.abs(y0) + scale)))
+            hub = 0.1 * interval
+            if hub * hub_inv > 1.0:
+                hub = 1.0 / hub_inv
+            hg = hnew = math.sqrt(hlb * hub)
+            if hub >= hlb:
+                for count in range(1, 5):
+                    f1 = self._f(y0 + hg * f0)
+                    if not np.all(np.isfinite(f1)):
+                        return False
+                    ydd = rms((f1 - f0) / scale) / hg
+                    hnew = math.sqrt(2.0 / ydd) if ydd * hub * hub > 2.0 else math.sqrt(hg * hub)
+                    if count == 4:
+                        break
+                    hrat = hnew / hg
+                    if 0.5 < hrat < 2.0:
+                        break
+                    if count > 1 and hrat > 2.0:
+                        hnew = hg
+                        break
+                    hg = hnew
+            h0 = min(max(0.5 * hnew, hlb), hub)
+            h0 = min(h0, interval)
             p = 1.0
-            while p > self.h_abs:
+            while p > h0:
                 p /= 10.0
-            while p * 10.0 <= self.h_abs:
+            while p * 10.0 <= h0:
                 p *= 10.0
             self.h_abs = p
+        self.first_selection = not self.scipy_newton   # growth cap 1e4 at the first selection after a (re)initialisation (CVODE's ETAMX1)
         self.D = np.zeros((MAX_ORDER + 3, self.n))
         self.D[0] = y0
         self.D[1] = f0 * self.h_abs
@@ -370,6 +399,7 @@ class OracleBDF:
                 self.n_equal = 0
                 self.LU = None
                 self.stats["n_rejected"] += 1
+                self.first_selection = False   # (CVODE: any failed attempt sets etamax = 1, the first step's 1e4 is gone)
                 if converged:
                     self.fail_score += 1.0
                 if self.fail_score >= 3.0 and order > 1:
@@ -387,6 +417,7 @@ class OracleBDF:
                 # without the cache the matrix is kept for the retry; with it the retry gets a factorisation of its own
                 self.force_fresh_lu = self.lu_band > 0 and not self.cache_suspended
                 self.stats["n_rejected"] += 1
+                self.first_selection = False
                 self.fail_score += 1.0
                 if self.fail_score >= 3.0 and order > 1:
                     self._reset_history()
@@ -460,7 +491,8 @@ class OracleBDF:
             factors = norms ** (-1 / np.arange(self.order, self.order + 3))
         delta = int(np.argmax(factors)) - 1
         self.order += delta
-        factor = min(MAX_FACTOR, safety * np.max(factors))
+        factor = min(FIRST_MAX_FACTOR if self.first_selection else MAX_FACTOR, safety * np.max(factors))
+        self.first_selection = False
         self.h_abs *= factor
         change_D(self.D, self.order, factor)
         self.n_equal = 0

@@ -375,7 +375,7 @@ struct SparseLU {
 // BDF integrator: oracle/bdf.py (OracleBDF), statement for statement
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_ORDER = 5, NEWTON_MAXITER = 4;
-constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
+constexpr double MIN_FACTOR = 0.2, MAX_FACTOR = 10.0, FIRST_MAX_FACTOR = 1e4;   // growth cap: first selection after a (re)initialisation / later (CVODE: ETAMX1 / ETAMX2)
 const double KAPPA[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
 
 struct Stats {
@@ -574,25 +574,17 @@ struct Bdf {
     if (!finite(f.data())) return false;
     const double interval = std::fabs(t_bound - t0);
     for (int64_t i = 0; i < N; i++) scale[i] = atol + std::fabs(y[i]) * rtol;
-    const double d0 = rms_scaled(y.data(), scale.data()), d1 = rms_scaled(f.data(), scale.data());
-    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-    h0 = std::min(h0, interval);
-    for (int64_t i = 0; i < N; i++) tmp[i] = y[i] + h0 * f[i];
-    fun(tmp.data(), rhsv.data());
-    if (!finite(rhsv.data())) return false;
-    for (int64_t i = 0; i < N; i++) tmp[i] = rhsv[i] - f[i];
-    const double d2 = rms_scaled(tmp.data(), scale.data()) / h0;
-    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 0.5);
-    h_abs = std::min({100.0 * h0, h1, interval});
-    {   // KIN_H0_DECADE=1: the first step rounded down to a power of ten, exact IEEE operations only (kinetica_jl_amd/csrc/solver.cpp: decade_floor)
-      const char* e = getenv("KIN_H0_DECADE");
-      if (e && atoi(e) != 0 && h_abs > 0.0 && std::isfinite(h_abs)) {
-        double p = 1.0;
-        while (p > h_abs) p /= 10.0;
-        while (p * 10.0 <= h_abs) p *= 10.0;
-        h_abs = p;
-      }
+    // CVODE's initial step (cvhin below), rounded DOWN to a power of ten by exact IEEE operations (kinetica_jl_amd/csrc/solver.cpp:
+    // decade_floor - every restart's climb passes through the same step sizes, which is what the LU cache lives on)
+    {
+      const double hx = cvhin(std::max(std::fabs(t0), std::fabs(t_bound)), interval);
+      if (!(hx > 0.0)) return false;
+      double p = 1.0;
+      while (p > hx) p /= 10.0;
+      while (p * 10.0 <= hx) p *= 10.0;
+      h_abs = std::isfinite(hx) ? p : hx;
     }
+    first_selection = true;
     std::fill(D.begin(), D.end(), 0.0);
     for (int64_t i = 0; i < N; i++) { D[i] = y[i]; D[(size_t)N + i] = f[i] * h_abs; }
     order = 1; n_equal = 0;
@@ -600,6 +592,41 @@ struct Bdf {
     drift_check();
     jac_current = true; have_pending = false; fail_score = 0.0;
     return true;
+  }
+  // CVODE's initial step (cvode.c: cvHin / cvUpperBoundH0 / cvYddNorm - the solver the reference documents,
+  // docs/src/getting-started.md:69, re-initialised at every chunk start and rate update, src/solving/methods.jl:260, 819): the
+  // step h with ||h^2 y'' / 2||_WRMS = 1, y'' from a difference quotient of f along the Euler direction, iterated (at most 4
+  // evaluations) until two successive estimates agree within a factor of 2, halved (H_BIAS), and kept inside [hlb, hub]:
+  // hlb = 100 ulp of the segment's times, hub = a tenth of the segment but no step over which ANY component would move by more
+  // than a tenth of itself plus its error weight. y, f = f(y) and scale are current. Returns 0 when f is not finite on the way.
+  // The step-size selection that follows the first steps may grow the step by 1e4 (CVODE's ETAMX1), later ones by 10.
+  bool first_selection = false;
+  double cvhin(double tmax, double tdist) {
+    const double hlb = 100.0 * EPS * tmax;
+    double hub_inv = 0.0;
+    for (int64_t i = 0; i < N; i++) hub_inv = std::max(hub_inv, std::fabs(f[i]) / (0.1 * std::fabs(y[i]) + scale[i]));
+    double hub = 0.1 * tdist;
+    if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
+    double hg = std::sqrt(hlb * hub), hnew = hg;
+    if (hub >= hlb) {
+      for (int count = 1; count <= 4; count++) {
+        for (int64_t i = 0; i < N; i++) tmp[i] = y[i] + hg * f[i];
+        fun(tmp.data(), rhsv.data());
+        if (!finite(rhsv.data())) return 0.0;
+        for (int64_t i = 0; i < N; i++) tmp[i] = rhsv[i] - f[i];
+        const double ydd = rms_scaled(tmp.data(), scale.data()) / hg;
+        hnew = (ydd * hub * hub > 2.0) ? std::sqrt(2.0 / ydd) : std::sqrt(hg * hub);
+        if (count == 4) break;
+        const double hrat = hnew / hg;
+        if (hrat > 0.5 && hrat < 2.0) break;
+        if (count > 1 && hrat > 2.0) { hnew = hg; break; }
+        hg = hnew;
+      }
+    }
+    double h0 = 0.5 * hnew;
+    if (h0 < hlb) h0 = hlb;
+    if (h0 > hub) h0 = hub;
+    return std::min(h0, tdist);
   }
   void reset_history() {
     std::copy(D.begin(), D.begin() + N, tmp.begin());
@@ -764,6 +791,7 @@ struct Bdf {
         change_D(order, eta);
         n_equal = 0; lu_valid = false;
         st.n_rejected++;
+        first_selection = false;   // (CVODE: any failed attempt sets etamax = 1, the first step's 1e4 is gone)
         if (converged) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
@@ -779,6 +807,7 @@ struct Bdf {
         n_equal = 0;
         force_fresh_lu = lu_cache > 0 && !cache_suspended;
         st.n_rejected++;
+        first_selection = false;
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
@@ -827,7 +856,8 @@ struct Bdf {
       else fct = std::pow(pend[i], -1.0 / (order + i));
       if (fct > best) { best = fct; arg = i; }
     }
-    const double factor = std::min(MAX_FACTOR, pend[3] * best);
+    const double factor = std::min(first_selection ? FIRST_MAX_FACTOR : MAX_FACTOR, pend[3] * best);
+    first_selection = false;
     if (step_thresh > 0.0 && factor < step_thresh) return;   // not worth a new iteration matrix: looked at again next step
     order += arg - 1;
     h_abs *= factor;

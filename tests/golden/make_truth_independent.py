@@ -10,6 +10,7 @@ history, no LU cache) - and stores its deviation from the committed truth, in un
 
     python tests/golden/make_truth_independent.py c3      (35 minutes on one core; INDEP_TIGHT=1e-2: 5 minutes, 0.16 units)
     python tests/golden/make_truth_independent.py c4      (25 minutes)
+    python tests/golden/make_truth_independent.py c3_mid c4_long c5     (round 5: the longer truths; an hour or more each)
 """
 import os
 import sys
@@ -122,6 +123,89 @@ def c4():
                               f"10 ms), rtol {RELTOL * TIGHT:g}, atol {ABSTOL * TIGHT:g}")
 
 
+def c3_mid():
+    """truth_c3_mid.npz (30 default chunks, every 5th chunk end stored): the save points at 5 and 10 ms by ONE Radau integration
+    from t = 0 - no chunking, no BDF history, no LU cache. Tolerances x1e-2 (INDEP_TIGHT overrides): see c3()."""
+    path = os.path.join(HERE, "truth_c3_mid.npz")
+    tr = np.load(path)
+    tight = float(os.environ.get("INDEP_TIGHT", "1e-2"))
+    global TIGHT
+    TIGHT = tight
+    net, Ea, A = synthetic_crn(10000, 50000)
+    on = orc.OracleNetwork.from_flat(net)
+    k = orc.arrhenius(Ea, A, float(tr["T"]), k_max=1e12)
+    u0 = np.zeros(10000); u0[0] = 1.0
+    t0 = time.time()
+    n_pts = int(os.environ.get("INDEP_POINTS", "2"))
+    t_eval = tr["t"][1:1 + n_pts]
+    u, nfev, njev, nlu = radau(on, k, u0, 0.0, float(t_eval[-1]), t_eval, newton_tol=0.03)
+    dev = units(u, tr["u"][1:1 + n_pts])
+    print(f"c3_mid: Radau {nfev} rhs, {njev} jac, {nlu} lu, {time.time() - t0:.0f} s; deviation from the stored truth at t = {list(t_eval)}: "
+          f"max {dev.max():.3f} units, rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
+    update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
+           independent_points=np.asarray(t_eval),
+           independent_method=f"scipy Radau (SuperLU, MMD ordering), oracle rhs + analytic sparse Jacobian, rtol {RELTOL * TIGHT:g}, "
+                              f"atol {ABSTOL * TIGHT:g}, corrector tolerance 0.03, no chunking")
+
+
+def ramp_segments(path, n, r, n_seg, check_times, label):
+    """Zero-order hold of the rate constants, one Radau integration per interval between rate updates, from t = 0 through
+    `n_seg` intervals; deviation from the stored truth at `check_times`."""
+    tr = np.load(path)
+    net, Ea, A = synthetic_crn(n, r)
+    on = orc.OracleNetwork.from_flat(net)
+    tst, T = tr["tstops"], tr["T_stops"]
+    u = np.zeros(n); u[0] = 1.0
+    saves = {}
+    t0 = time.time()
+    for i in range(n_seg):
+        k = orc.arrhenius(Ea, A, float(T[i]), k_max=1e12)
+        y, nfev, njev, nlu = radau(on, k, u, 0.0, float(tst[i + 1] - tst[i]), [float(tst[i + 1] - tst[i])])
+        u = y[-1]
+        print(f"   {label} segment {i}: {nfev} rhs, {nlu} lu, {time.time() - t0:.0f} s", flush=True)
+        for ts in check_times:
+            if abs(tst[i + 1] - ts) < 1e-12:
+                saves[ts] = u.copy()
+    if os.environ.get("INDEP_DUMP"):      # the Radau states themselves (to be compared with a truth that is regenerated meanwhile)
+        np.savez_compressed(os.environ["INDEP_DUMP"], t=np.asarray(check_times), u=np.stack([saves[ts] for ts in check_times]))
+    dev = np.stack([units(saves[ts], tr["u"][int(np.argmin(np.abs(tr["t"] - ts)))]) for ts in check_times])
+    print(f"{label}: max deviation from the stored truth at t = {list(check_times)}: {dev.max():.3f} units, rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
+    update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
+           independent_points=np.asarray(check_times),
+           independent_method=f"scipy Radau (SuperLU, MMD ordering) per rate interval (zero-order hold), {n_seg} intervals from t = 0, "
+                              f"rtol {RELTOL * TIGHT:g}, atol {ABSTOL * TIGHT:g}")
+
+
+def c4_long():
+    """truth_c4_long.npz (20 chunks of the ramp, chunk ends stored): the first two chunk ends (10 and 20 ms, 20 rate intervals)."""
+    ramp_segments(os.path.join(HERE, "truth_c4_long.npz"), 10000, 50000, 20, (1e-2, 2e-2), "c4_long")
+
+
+def c5():
+    """truth_c5.npz (50k species, 2 chunks of the ramp): the state at the FIRST rate update (1 ms: the interval that starts from the
+    pure initial state with steps of 1e-22 s and holds most of the work; `u_early` of the truth file). A SuperLU factorisation
+    pair of Radau's takes 40 s at this size: one interval is ~2.5 hours, the ten of the first chunk would be a day."""
+    path = os.path.join(HERE, "truth_c5.npz")
+    tr = np.load(path)
+    net, Ea, A = synthetic_crn(50000, 250000)
+    on = orc.OracleNetwork.from_flat(net)
+    u0 = np.zeros(50000); u0[0] = 1.0
+    k = orc.arrhenius(Ea, A, float(tr["T_stops"][0]), k_max=1e12)
+    t0 = time.time()
+    y, nfev, njev, nlu = radau(on, k, u0, 0.0, float(tr["tstops"][1]), [float(tr["tstops"][1])])
+    print(f"c5: Radau over the first rate interval: {nfev} rhs, {nlu} lu, {time.time() - t0:.0f} s", flush=True)
+    if os.environ.get("INDEP_DUMP"):
+        np.savez_compressed(os.environ["INDEP_DUMP"], t=np.asarray([float(tr["tstops"][1])]), u=y[-1:])
+    if "u_early" not in tr.files:
+        print("truth_c5.npz has no u_early yet (regenerate it with make_truth_configs.py c5); the Radau state is in INDEP_DUMP", flush=True)
+        return
+    dev = units(y[-1], tr["u_early"][0])
+    print(f"c5: deviation from the stored truth at t = 1 ms: max {dev.max():.3f} units, rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
+    update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
+           independent_points=np.asarray([float(tr["tstops"][1])]),
+           independent_method=f"scipy Radau (SuperLU, MMD ordering) over the first rate interval, rtol {RELTOL * TIGHT:g}, atol {ABSTOL * TIGHT:g}")
+
+
 if __name__ == "__main__":
     for name in sys.argv[1:] or ["c3", "c4"]:
-        {"c3": c3, "c4": c4}[name]()
+        {"c3": c3, "c4": c4, "c3_mid": c3_mid, "c4_long": c4_long, "c5": c5}[name]()

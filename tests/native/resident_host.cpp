@@ -174,15 +174,16 @@ struct HostBackend {
     seg_run_host(SEG_COEF_SET, net.jac_plan, dr.data(), jv.data(), Ex{});
   }
   ResNorms norms(bool with_f1, double atol, double rtol) {
-    double s0 = 0, s1 = 0, s2 = 0; int bad = 0;
+    double s0 = 0, s1 = 0, s2 = 0, vm = 0; int bad = 0;
     for (int i = 0; i < N; i++) {
       const double sc = atol + rtol * std::fabs(y[i]);
       const double a = y[i] / sc, b = f0[i] / sc;
       s0 += a * a; s1 += b * b;
+      vm = std::fmax(vm, std::fabs(f0[i]) / (0.1 * std::fabs(y[i]) + sc));
       if (!std::isfinite(f0[i])) bad = 1;
       if (with_f1) { const double c = (f1[i] - f0[i]) / sc; s2 += c * c; if (!std::isfinite(f1[i])) bad = 1; }
     }
-    return ResNorms{std::sqrt(s0 / N), std::sqrt(s1 / N), std::sqrt(s2 / N), bad};
+    return ResNorms{std::sqrt(s0 / N), std::sqrt(s1 / N), std::sqrt(s2 / N), vm, bad};
   }
   void init_D(bool from_ytmp, double h) {
     const std::vector<double>& y0 = from_ytmp ? ytmp : y;

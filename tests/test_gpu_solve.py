@@ -57,17 +57,15 @@ def test_first_order_decay_chunkwise():
     h.close()
 
 
-def test_first_step_on_the_decade_grid_in_every_implementation(monkeypatch):
-    """KIN_H0_DECADE=1 (off by default): the first step after a restart rounded down to a power of ten - by exact IEEE
-    operations, so that the resident kernel, the host-driven integrator and the Python oracle take the same steps: same step
-    counts under the switch, and a different (longer) sequence than without it."""
+def test_restart_rules_take_the_same_steps_in_every_implementation(monkeypatch):
+    """The (re)initialisation rules - CVODE's initial step (cvHin) rounded down to a power of ten by exact IEEE operations, growth
+    cap 1e4 at the first step-size selection and 10 afterwards - are implemented four times: resident kernel /
+    lockstep controller (resident_core.hpp), host-driven integrator (solver.cpp), oracle/bdf.py, oracle/cpu_bdf.cpp. Same
+    problem, same step counts."""
+    from oracle import cpu_bdf
     net = from_lists(2, [[(0, 1)]], [[(1, 1)]])
     pars = kp((0.0, 1.0), True, 0.1, 0.05)
     odict = dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.1, save_interval=0.05)
-    h = capi.HipNetwork.from_flat(net); h.set_rates([3.0])
-    _, _, _, st_off, _ = h.solve(pars, [1.0, 0.0])
-    h.close()
-    monkeypatch.setenv("KIN_H0_DECADE", "1")
     counts = []
     for resident in ("1", "0"):
         monkeypatch.setenv("KIN_RESIDENT", resident)
@@ -77,7 +75,8 @@ def test_first_step_on_the_decade_grid_in_every_implementation(monkeypatch):
         counts.append(st["n_steps"])
         h.close()
     to, uo, rco, sto = oracle_solve(net, odict, [1.0, 0.0], k0=np.array([3.0]))
-    assert rco == 0 and counts[0] == counts[1] == sto["n_steps"] and counts[0] > st_off["n_steps"]
+    tc, uc, rcc, stc = cpu_bdf.CpuSolver(net).solve(odict, np.array([1.0, 0.0]), k0=np.array([3.0]))
+    assert rco == 0 and rcc == 0 and counts[0] == counts[1] == sto["n_steps"] == stc["n_steps"]
 
 
 def test_closed_forms_complete_timespan():

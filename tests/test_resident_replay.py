@@ -198,7 +198,7 @@ def test_warm_continuation_across_chunk_starts():
     tt, ut, rct, _ = hr.solve(kp(1e-2, abstol=1e-12, reltol=1e-10, dtmin=1e-30), u0, k0=k)
     assert rcc == 0 and rcw == 0 and rct == 0 and np.array_equal(tc, tw) and len(tw) == 11
     assert stw["n_chunks"] == 10 and stw["n_restarts"] == 10          # a segment start each, one of them cold
-    assert stw["n_steps"] < 0.85 * stc["n_steps"] and stw["n_factor"] < stc["n_factor"]
+    assert stw["n_steps"] < 0.9 * stc["n_steps"] and stw["n_factor"] < stc["n_factor"]   # (0.85 before the re-initialisations got CVODE's first-step rules: they cost less now)
     assert units(uw, ut) <= 100 and units(uw, ut) <= units(uc, ut) + 20
     # with rate updates inside the span the integrator re-initialises at each of them: warm mode changes nothing there
     hr.set_arrhenius(Ea, A, k_max=1e12)
