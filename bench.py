@@ -440,9 +440,19 @@ def main():
             ms_T = ev(lambda: hh.rhs_tiled_dev(Bb, uu.data_ptr(), dd.data_ptr(), d_T=TT.data_ptr(), stream=stream))
             alg_k = 20 * Rr + Bb * (8 * Rr + 16 * Nn)
             alg_T = 36 * Rr + Bb * (16 * Nn + 8)
-            del kl, dd
+            # the drop-in entry: states in the CALLER's species order (the reference's sol.u layout), rate constants in the slot order
+            # the library's own rate table writes (kin_rhs_batched_klib_dev); and the plain kin_rhs_batched_dev with the rate
+            # constants in the caller's REACTION order next to it (kin::sweep_big_kernel where the state does not fit LDS)
+            ms_d = ev(lambda: hh.rhs_batched_klib_dev(Bb, uu.data_ptr(), kl.data_ptr(), dd.data_ptr(), stream))
+            kc = torch.rand((Bb, Rr), dtype=torch.float64, device=dev, generator=g) + 0.5
+            ms_c = ev(lambda: hh.rhs_batched_dev(Bb, uu.data_ptr(), kc.data_ptr(), dd.data_ptr(), stream))
+            del kl, dd, kc
             return {"species": Nn, "reactions": Rr, "states": Bb, "hubs": lay["hubs"], "windows": lay["windows"],
                     "species_order_is_callers": lay["identity"],
+                    "dropin_callers_species_order_k_in_slot_order": {
+                        "entry": "kin_rhs_batched_klib_dev", "ms": ms_d, "evals_per_s": Bb / (ms_d * 1e-3), "frac_of_8TBps": alg_k / (ms_d * 1e-3) / 8e12,
+                        "hbm_bytes_expected_over_algorithmic": 1.0 if lay["identity"] else (alg_k + Bb * 32 * Nn) / alg_k},
+                    "callers_species_and_reaction_order": {"entry": "kin_rhs_batched_dev", "ms": ms_c, "frac_of_8TBps": alg_k / (ms_c * 1e-3) / 8e12},
                     "k_stream": {"ms": ms_k, "evals_per_s": Bb / (ms_k * 1e-3), "algorithmic_bytes_M2": alg_k,
                                  "GBps": alg_k / (ms_k * 1e-3) / 1e9, "frac_of_8TBps": alg_k / (ms_k * 1e-3) / 8e12, "bound": "hbm / LDS atomics"},
                     "temperature_form": {"ms": ms_T, "evals_per_s": Bb / (ms_T * 1e-3), "algorithmic_bytes_M1prime": alg_T,
@@ -494,12 +504,12 @@ def main():
                     return a.elapsed_time(b) / reps
                 ms_c = ev(lambda: hp.rhs_batched_dev(B, d_u.data_ptr(), k_p.data_ptr(), du_p.data_ptr(), stream))
                 # (the states in the library's species order: the caller's at this size)
-                ms_l = ev(lambda: hp.rhs_tiled_dev(B, d_u.data_ptr(), du_p.data_ptr(), d_k_lib=kl_p.data_ptr(), stream=stream))
+                ms_l = ev(lambda: hp.rhs_batched_klib_dev(B, d_u.data_ptr(), kl_p.data_ptr(), du_p.data_ptr(), stream))
                 del k_p, du_p, kl_p
                 return {"network": "C3 CRN minus a random 30 % of its reactions", "species": N, "reactions": Rp, "states": B,
                         "records": lay["records"], "k_len": lay["k_len"], "algorithmic_GB": alg / 1e9,
                         "callers_layouts": {"kernel": "kin::sweep_gen_kernel", "ms": ms_c, "frac_of_8TBps": alg / (ms_c * 1e-3) / 8e12},
-                        "library_order": {"kernel": "kin::tiled_sweep_kernel, one-slot records", "ms": ms_l,
+                        "library_order": {"kernel": "kin::tiled_sweep_kernel, one-slot records, through kin_rhs_batched_klib_dev (states in the caller's order, k in slot order)", "ms": ms_l,
                                           "frac_of_8TBps": alg / (ms_l * 1e-3) / 8e12}}
             finally:
                 hp.close()
@@ -514,6 +524,42 @@ def main():
         if rank == 0:
             out["single_trajectory_rhs_allreduce"] = dict(split, note="reaction blocks of one RHS over the ranks + SUM all-reduce of "
                                                           "du (RCCL) against the whole RHS on one rank: microseconds per evaluation")
+
+    # ---- an ensemble of ONE small network sharded by members over the ranks: 64 members per rank (weak scaling), each
+    # rank ONE kin_solve_ensemble launch on its GPU, then one row per member (the per-species maxima identify_next_seeds reads) and
+    # the return codes all-gathered in member order (RCCL on device tensors). No data-path collective during the solves.
+    if world > 1 and args.solve_chunks > 0:
+        def sharded_ensemble_leg():
+            from kinetica_jl_amd.distributed import solve_ensemble_sharded
+            net_e, Ea_e, A_e = synthetic_crn(300, 1500)
+            he = capi.HipNetwork.from_flat(net_e)
+            try:
+                he.set_arrhenius(Ea_e, A_e, k_max=1e12)
+                Ke = 64 * world
+                u0e = np.zeros((Ke, 300)); u0e[:, 0] = 1.0
+                Te = np.linspace(900.0, 1300.0, Ke)
+                pe = capi.KinParams(tspan0=0.0, tspan1=2e-3, abstol=1e-10, reltol=1e-8, adaptive_tols=1, update_tols=0, solve_chunks=1,
+                                    ban_negatives=0, solve_chunkstep=1e-3, maxiters=100000, save_interval=-1.0)
+                def local(h_, p_, u_, T_, k_):
+                    # a rank whose launch throws still takes part in the all-gather (retcode -1 for its members): the others
+                    # must not be left waiting in a collective
+                    try:
+                        return h_.solve_ensemble(p_, u_, T=T_, k=k_)
+                    except Exception:      # noqa: BLE001
+                        return None, np.zeros((len(u_), 1, 300)), np.ones(len(u_), np.int64), -np.ones(len(u_), np.int32), None
+                solve_ensemble_sharded(he, pe, u0e, T=Te, dist=dist, device=dev, solve_fn=local)       # warm-up (symbolic analysis, allocations)
+                dist.barrier()
+                t1 = time.perf_counter()
+                rows, rcs = solve_ensemble_sharded(he, pe, u0e, T=Te, dist=dist, device=dev, solve_fn=local)
+                w = max_over_ranks(time.perf_counter() - t1, dist, coll_dev)
+                return {"network": "300 species / 1500 reactions", "members": Ke, "members_per_rank": 64, "wall_s": w, "solves_per_s": Ke / w,
+                        "all_ok": bool((rcs == 0).all()), "rows_gathered": list(rows.shape),
+                        "note": "rank r integrates members [64 r, 64 r + 64) in one kin_solve_ensemble launch; maxima + return codes all-gathered"}
+            finally:
+                he.close()
+        leg = sharded_ensemble_leg()      # (not `guarded`: every rank must reach the same collectives)
+        if rank == 0:
+            out["ensemble_sharded_by_members"] = leg
 
     # ---- single-state RHS latency (what the integrator sees), rank 0 only
     if rank == 0:
@@ -958,11 +1004,13 @@ def main():
             c4 = sn.get("configs", {}).get("C4_prefix", {})
             if isinstance(c4, dict) and "wall_s" in c4:
                 brief_sn["C4_prefix_20_chunks_wall_s"] = c4["wall_s"]
-            out.setdefault("cpu_baseline", {"value": None, "unit": "RHS evals/s", "cores": 1, "kind": "port", "sample": "not run (--no-cpu or N > 1)"})
-            out["cpu_baseline"]["solve_network"] = brief_sn
-        for key in ("roofline", "cpu_baseline"):
+            if "cpu_baseline" in out:
+                out["cpu_baseline"]["solve_network"] = brief_sn
+            else:                              # (N > 1 or --no-cpu: no CPU baseline is taken; the summary still ends the line)
+                out["solve_network_summary"] = brief_sn
+        for key in ("solve_network_summary", "roofline", "cpu_baseline"):
             if key in out:
-                out[key] = out.pop(key)      # (dicts keep insertion order: these two end the line, inside the tail the driver keeps)
+                out[key] = out.pop(key)      # (dicts keep insertion order: these end the line, inside the tail the driver keeps)
         print(json.dumps(out), flush=True)      # the LAST line of rank 0's stdout (backends may print banners before it)
 
 

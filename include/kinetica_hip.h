@@ -153,6 +153,15 @@ int kin_rhs_tiled_dev(kin_network* h, int64_t B, const double* d_u_lib, const do
  * species order differs (species_identity == 0) the call converts the layout on the way in and out (16 N bytes per
  * state each way, workspace grown on demand). */
 int kin_rhs_batched_T_dev(kin_network* h, int64_t B, const double* d_u, const double* d_T, double* d_du, void* stream);
+/* The drop-in batched sweep for a caller whose RATE CONSTANTS come from this library (kin_rate_table_lib_dev, or converted once
+ * by kin_rates_to_lib_dev): states u[b][N] and du[b][N] in the CALLER's species order - the reference's own sol.u layout -,
+ * rate constants k_lib[b][k_len] in the slot order kin_lib_layout reports (16-byte aligned). The bandwidth-grade path at ANY
+ * size and after the low-k cutoff (apply_low_k_cutoff!, solve_utils.jl:213-245, leaves reactions without their reverse):
+ * hubs and windows in LDS, the k row streamed once; when the library species order differs from the caller's (N > ~10 000)
+ * the states are permuted through LDS on the way in and out, one coalesced pass each (HBM traffic per state: 8 k_len + 16 N for
+ * the sweep + 32 N for the two permutations). kin_rhs_batched_dev (rate constants in the caller's REACTION order) stays
+ * correct at every size but cannot stream k once when the state does not fit LDS. Enqueue only. */
+int kin_rhs_batched_klib_dev(kin_network* h, int64_t B, const double* d_u, const double* d_k_lib, double* d_du, void* stream);
 
 /* ---- A3: analytic sparse Jacobian ---------------------------------------------------- */
 /* Replaces ODEProblem(...; jac=true, sparse=true) (methods.jl:157-158): pattern (CSR,
@@ -311,8 +320,8 @@ const char* kin_version(void);
 /* Layout version of this header's structs and argument lists. A binding compares it (and, if it wants certainty, the
  * struct sizes) with the values it was written against before the first call: kin_params / kin_stats have grown between
  * versions (1: round 1; 2: + dtmin and the LU-cache counters; 3: + the library-order sweep entry points; 4: + kin_solve_ensemble,
- * kin_lu_analyze_host - structs unchanged). */
-#define KIN_ABI_VERSION 4
+ * kin_lu_analyze_host - structs unchanged; 5: + kin_rhs_batched_klib_dev - structs unchanged). */
+#define KIN_ABI_VERSION 5
 int kin_abi_version(void);
 int64_t kin_struct_size(int which); /* 0: sizeof(kin_params), 1: sizeof(kin_stats), else -1 */
 

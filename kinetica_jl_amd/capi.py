@@ -28,10 +28,10 @@ SYMBOLS = [
     "kin_newton_solve", "kin_device_count", "kin_set_device", "kin_version", "kin_solution_dot", "kin_rate_table_rows",
     "kin_solution_max_dev", "kin_rate_table_dev", "kin_rhs_block_dev",
     "kin_lib_layout", "kin_lib_layout_host", "kin_states_to_lib_dev", "kin_states_from_lib_dev", "kin_rates_to_lib_dev", "kin_rate_table_lib_dev",
-    "kin_rhs_tiled_dev", "kin_rhs_batched_T_dev", "kin_abi_version", "kin_struct_size",
+    "kin_rhs_tiled_dev", "kin_rhs_batched_T_dev", "kin_rhs_batched_klib_dev", "kin_abi_version", "kin_struct_size",
     "kin_solve_ensemble", "kin_lu_analyze_host",
 ]
-ABI_VERSION = 4   # include/kinetica_hip.h: KIN_ABI_VERSION this binding was written against
+ABI_VERSION = 5   # include/kinetica_hip.h: KIN_ABI_VERSION this binding was written against
 
 
 class KinParams(ctypes.Structure):
@@ -125,6 +125,7 @@ def lib():
         L.kin_rate_table_lib_dev.argtypes = [c_void_p, PD, c_int64, c_void_p]
         L.kin_rhs_tiled_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.kin_rhs_batched_T_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.kin_rhs_batched_klib_dev.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         L.kin_device_count.argtypes = [POINTER(c_int)]
         L.kin_set_device.argtypes = [c_int]
         _lib = L
@@ -322,6 +323,12 @@ class HipNetwork:
         """Batched RHS on caller-order states with rate constants formed in the sweep from T[b]; only enqueues."""
         self._chk(lib().kin_rhs_batched_T_dev(self._h, int(B), c_void_p(d_u), c_void_p(d_T), c_void_p(d_du),
                                               c_void_p(stream) if stream else None))
+
+    def rhs_batched_klib_dev(self, B, d_u, d_k_lib, d_du, stream=0):
+        """Batched RHS on caller-order states u[b][N] -> du[b][N] with rate constants in the library's slot order k_lib[b][k_len]
+        (from rate_table_lib_dev / rates_to_lib_dev); device pointers as ints; only enqueues."""
+        self._chk(lib().kin_rhs_batched_klib_dev(self._h, int(B), c_void_p(d_u), c_void_p(d_k_lib), c_void_p(d_du),
+                                                 c_void_p(stream) if stream else None))
 
     def jac_pattern(self, index_base=0):
         nnz = c_int64(0)

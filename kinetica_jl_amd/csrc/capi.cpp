@@ -81,7 +81,7 @@ static void require(bool c, int code, const char* msg) {
 
 extern "C" {
 
-const char* kin_version(void) { return "kinetica-hip 0.4 (gfx950)"; }
+const char* kin_version(void) { return "kinetica-hip 0.5 (gfx950)"; }
 
 int kin_abi_version(void) { return KIN_ABI_VERSION; }
 
@@ -370,7 +370,6 @@ kin_network* clone_for_solves(kin_network* h) {
 
 int replica_threads_max();
 int64_t replica_members_max() {
-  if (const char* e = getenv("KIN_ENSEMBLE_THREADS_K")) return std::max<int64_t>(0, atoll(e));
   return (int64_t)replica_threads_max();
 }
 int replica_threads_max() {

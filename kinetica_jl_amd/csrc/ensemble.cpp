@@ -33,7 +33,6 @@ struct Pending {
   int accept_order = 0;
   double pre_ru[36];
   // factor
-  int slot = 0; double c = 0.0; bool keep_diag = false;
   // drift
   double max_drift = 0.0;
   // results
@@ -114,7 +113,6 @@ struct EnsembleSolver {
   // KIN_ENSEMBLE_FACTOR_SYNC=1: factorisations stay IN the round (sparse parts on the pool's streams next to the round's other
   // launches, the dense inverses of all members that asked in this round as one batched chain behind them) instead of parking
   // their members: the members stay in step with each other, every launch of a round carries all of them
-  bool factor_sync = false;
   int g_min = 4, g_wait_us = 200;       // hold-off: a batch starts with 4 requests or 200 us after its first (KIN_ENSEMBLE_GJ_MIN / _WAIT_US)
   double t_enqueue = 0.0, t_sync = 0.0, t_round = 0.0;   // host seconds inside the rounds (KIN_TIMING=1)
   int64_t n_ops[16] = {};
@@ -175,7 +173,7 @@ struct EnsembleSolver {
       K = 0;
       KIN_HIP(hipHostMalloc((void**)&h_ctrl, (size_t)K_ * sizeof(BdfCtrl), hipHostMallocCoherent | hipHostMallocMapped));
       if (!h_seq) { KIN_HIP(hipHostMalloc((void**)&h_seq, sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped)); *h_seq = 0; }
-      fast_sync = !(getenv("KIN_ENSEMBLE_FAST_SYNC") && atoi(getenv("KIN_ENSEMBLE_FAST_SYNC")) == 0) && !getenv("KIN_NO_FAST_SYNC");
+      fast_sync = !getenv("KIN_NO_FAST_SYNC");
       if (hipHostGetDevicePointer((void**)&h_ctrl_dev, h_ctrl, 0) != hipSuccess || hipHostGetDevicePointer((void**)&h_seq_dev, h_seq, 0) != hipSuccess) {
         (void)hipGetLastError();
         fast_sync = false;
@@ -222,11 +220,8 @@ struct EnsembleSolver {
     g_enqueued.assign(K, 0);
     g_batched = !(getenv("KIN_ENSEMBLE_GJ_BATCHED") && atoi(getenv("KIN_ENSEMBLE_GJ_BATCHED")) == 0);
     g_batches = g_matrices = 0;
-    factor_sync = getenv("KIN_ENSEMBLE_FACTOR_SYNC") && atoi(getenv("KIN_ENSEMBLE_FACTOR_SYNC")) != 0;
     g_min = 4; g_wait_us = 200;
     g_min = std::min(g_min, std::max(1, K / 4));       // a small ensemble does not hold a lone request back for partners that rarely come
-    if (const char* e = getenv("KIN_ENSEMBLE_GJ_MIN")) g_min = std::max(1, atoi(e));
-    if (const char* e = getenv("KIN_ENSEMBLE_GJ_WAIT_US")) g_wait_us = std::max(0, atoi(e));
     while ((int)ms.size() < pool) {
       hipStream_t m_; KIN_HIP(hipStreamCreateWithFlags(&m_, hipStreamNonBlocking));
       ms.push_back(m_); mpinv.emplace_back(); mpinv.back().alloc(2 * 32 * 32); ms_lock.emplace_back(new std::mutex());
@@ -266,19 +261,6 @@ struct EnsembleSolver {
         for (int t = 0; t < K; t++) if (pend[t].kind == kind) { O[no] = pend[t].op; O[no].rep = t; no++; cnt[kind]++; }
       }
       auto count = [&](int kind) { return cnt[kind]; };
-      // 2a. factorisations of this round (factor_sync): the sparse parts go to the pool's streams now and run next to the rest
-      // of the round; their dense blocks are inverted together at the end of the round (below)
-      std::vector<int> fac;
-      for (int t = 0; t < K; t++) if (pend[t].kind == K_FACTOR) fac.push_back(t);
-      for (size_t i = 0; i < fac.size(); i++) {
-        const int t = fac[i];
-        hipStream_t f = ms[i % ms.size()];
-        SparseLU::Slot& q = slots[t][pend[t].slot];
-        if (!q.W.p) lu.alloc_slot(q, f);
-        lu.factor_sparse_into(pend[t].c, reps[t].jv, q, d_bad.p + t, f);
-        if (pend[t].keep_diag) { q.jd.alloc(N); launch_jac_diag(N, reps[t].jv, d_jdiag.p, q.jd.p, f); }
-        KIN_HIP(hipEventRecord(pre_evs[t], f));
-      }
       if (na + nc + no > 0) KIN_HIP(hipMemcpyAsync(d_ops.p, h_ops, (size_t)3 * K * sizeof(EnsOp), hipMemcpyHostToDevice, s));
       ens_accept(N, d_reps.p, d_ops.p, na, s);
       ens_change_D(N, d_reps.p, d_ops.p + K, nc, s);
@@ -295,26 +277,6 @@ struct EnsembleSolver {
         ens_iterations(T, d_reps.p, dO + first[K_CORRECTOR], ncorr, 0, BLIND_ITERS, s);
       }
       if (ncont > 0) ens_iterations(T, d_reps.p, dO + first[K_CORRECTOR_CONT], ncont, BLIND_ITERS, BDF_NEWTON_MAXITER - BLIND_ITERS, s);
-      // 2b. the dense inverses of this round's factorisations, GJ_BMAX matrices per chain
-      for (size_t i0 = 0; i0 < fac.size(); i0 += GJ_BMAX) {
-        const int n = (int)std::min<size_t>(GJ_BMAX, fac.size() - i0);
-        double* S[GJ_BMAX]; double* S2[GJ_BMAX]; int* badp[GJ_BMAX];
-        for (int i = 0; i < n; i++) {
-          const int t = fac[i0 + i];
-          SparseLU::Slot& q = slots[t][pend[t].slot];
-          KIN_HIP(hipStreamWaitEvent(s, pre_evs[t], 0));
-          S[i] = q.W.p + lu.off_S; S2[i] = q.S2.p; badp[i] = d_bad.p + t;
-        }
-        if (lu.m > 0) {
-          const int where = launch_gauss_jordan_batched(n, S, S2, lu.mpad, gpinv.p, badp, s);
-          for (int i = 0; i < n; i++) slots[fac[i0 + i]][pend[fac[i0 + i]].slot].sinv = where ? S2[i] : S[i];
-        }
-        g_batches++; g_matrices += n;
-      }
-      if (!fac.empty()) {
-        KIN_HIP(hipMemcpyAsync(h_bad, d_bad.p, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, s));
-        KIN_HIP(hipMemsetAsync(d_bad.p, 0, (size_t)K * sizeof(int), s));
-      }
       // 3. drift checks (one small launch per member at a restart)
       bool any_drift = false;
       for (int t = 0; t < K; t++) {
@@ -332,7 +294,7 @@ struct EnsembleSolver {
       // number to spin on (the host-driven integrator's scheme; ~5 us instead of the ~25 us of a copy + stream synchronisation),
       // unless other results come back by copy in this round (drift tests, factorisation flags) or the number does not arrive
       bool waited = false;
-      if (fast_sync && !any_drift && fac.empty()) {
+      if (fast_sync && !any_drift) {
         const unsigned long long want = ++seq_no;
         ens_publish(d_ctrl.p, h_ctrl_dev, K, h_seq_dev, want, s);
         tr1 = std::chrono::steady_clock::now();
@@ -357,7 +319,6 @@ struct EnsembleSolver {
           for (int i = 0; i < (int)slots[t].size(); i++)
             if (slots[t][i].valid && !(h_drift[(size_t)t * LU_MAX_SLOTS + i] <= p.max_drift)) { slots[t][i].valid = false; p.dropped++; }
         }
-        if (p.kind == K_FACTOR) p.bad = h_bad[t] != 0;
         ctrl_of[t] = h_ctrl[t];
         results[t] = p;
         done[t] = 1;
@@ -644,10 +605,7 @@ struct MemberBackend {
     return run(q).dropped;
   }
   bool factor(int slot, double c, bool keep_diag) {
-    if (!E.factor_sync) return E.factor_member(t, slot, c, keep_diag);
-    Pending q = make(K_FACTOR);
-    q.slot = slot; q.c = c; q.keep_diag = keep_diag;
-    return run(q).bad;
+    return E.factor_member(t, slot, c, keep_diag);   // leaves the round: own stream, dense block to the batching server
   }
   ResAttempt corrector(const ResCorrIn& in, const double*) {
     Pending q = make(K_CORRECTOR);

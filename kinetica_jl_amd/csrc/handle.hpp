@@ -58,7 +58,7 @@ struct kin_network {
   kin::TiledHost tiled;
   bool tiled_tried = false;
   kin::DevBuf<uint32_t> t_rec;
-  kin::DevBuf<int32_t> t_copy, t_kf, t_kr, t_rxn_of_slot, t_spec_of_lib, t_lib_of_spec, t_kslot;
+  kin::DevBuf<int32_t> t_copy, t_kf, t_kr, t_rxn_of_slot, t_spec_of_lib, t_lib_of_spec, t_kslot, t_stage_lib, t_stage_off;
   kin::DevBuf<double> t_par, t_T, t_u, t_du;   // Arrhenius parameters per record (4 doubles), temperatures, layout scratch
   bool t_par_valid = false;
 

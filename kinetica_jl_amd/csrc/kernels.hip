@@ -868,8 +868,7 @@ void launch_sweep(int n_cu, int64_t N, int64_t R, int64_t P, int64_t B, bool adj
   if ((size_t)(2 * N) * 8 <= lds_max) {
     const int tile = (int)((N + 1) / 2 * 2);
     const size_t smem = (size_t)(tile + N) * 8;
-    static int use_reg = -1;
-    if (use_reg < 0) { const char* e = getenv("KIN_SWEEP_REG"); use_reg = e ? atoi(e) : 8; }
+    constexpr int use_reg = 8;
     // register-resident path: both LDS arrays carry SWEEP_DUMMY extra entries (per-lane dummy species)
     // register-resident path: reactions paired as (2p, 2p+1) [adjacent] or (p, P+p) [block]
     if ((adj || block) && rec64 && use_reg >= 0 && ((((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && N % 2 == 0 &&

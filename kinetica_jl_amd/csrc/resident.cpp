@@ -40,10 +40,6 @@ struct ResidentSolver {
     hipStream_t s = h->stream;
     LUOptions opt;
     opt.min_round = 2;   // a round costs two barriers here, not two dependent launches
-    if (const char* e = getenv("KIN_LU_HUB_DEGREE")) opt.hub_degree = atoi(e);
-    if (const char* e = getenv("KIN_LU_MAX_ROUNDS")) opt.max_rounds = atoi(e);
-    if (const char* e = getenv("KIN_LU_MAX_TAIL_DEGREE")) opt.max_tail_degree = atoi(e);
-    if (const char* e = getenv("KIN_LU_MAX_DEGREE")) opt.max_degree = atoi(e);
     opt.max_rounds = std::min(opt.max_rounds, RES_MAX_ROUNDS);
     lu.analyze((int32_t)H.N, H.j_ptr, H.j_col, opt, s);
     if (lu.m > RES_MAX_DENSE) { why = "dense Schur block beyond the resident integrator's limit"; return; }
@@ -74,8 +70,7 @@ struct ResidentSolver {
       const size_t desc = resident_desc_bytes(hn.resid_plan, hn.stageA, hn.stageC);
       const size_t static_lds = resident_static_lds();
       const bool two_before = 2 * (dyn_lds + static_lds) <= (size_t)160 * 1024, two_after = 2 * (dyn_lds + desc + static_lds) <= (size_t)160 * 1024;
-      const bool off = getenv("KIN_RESIDENT_LDS_DESC") && atoi(getenv("KIN_RESIDENT_LDS_DESC")) == 0;
-      hn.desc_in_lds = (!off && lu.fused_tri && dyn_lds + desc <= RES_LDS_BUDGET && (two_after || !two_before)) ? 1 : 0;
+      hn.desc_in_lds = (lu.fused_tri && dyn_lds + desc <= RES_LDS_BUDGET && (two_after || !two_before)) ? 1 : 0;
       if (hn.desc_in_lds) dyn_lds += desc;
     }
     hn.fwdZ = lu.fwdZ.view(); hn.fwd_dense = lu.fwd_dense.view(); hn.bwdT = lu.bwdT.view(); hn.bwdV = lu.bwdV.view();
@@ -215,7 +210,6 @@ bool resident_eligible(kin_network* h, const kin_params& p, bool continuous, boo
   if (h->host.N > resident_max_n()) return false;
   if (!res_has_grid(p)) return false;
   if (getenv("KIN_TRACE_CHUNK") || getenv("KIN_INJECT_BAD_PIVOT")) return false;
-  if (getenv("KIN_WARM_RESTART") && atoi(getenv("KIN_WARM_RESTART")) != 0) return false;
   ResidentSolver* RS = get_resident(h);
   return RS->ok && RS->lu.m <= resident_max_dense_single();
 }
@@ -237,8 +231,7 @@ bool resident_fits(kin_network* h) { return resident_can_fit(h) && get_resident(
 // is 3-4x ahead, at <= 700 species at every K).
 bool resident_ensemble_route(kin_network* h, int64_t K) {
   if (!resident_can_fit(h)) return false;
-  static const int small_k = getenv("KIN_RESIDENT_ENSEMBLE_MIN_K") ? atoi(getenv("KIN_RESIDENT_ENSEMBLE_MIN_K")) : 32;
-  if (h->host.N > 700 && K < small_k) return false;
+  if (h->host.N > 700 && K < 32) return false;
   return get_resident(h)->ok;
 }
 

@@ -46,7 +46,7 @@ inline ResGrid make_res_grid(const kin_params& p) {
   return g;
 }
 
-// integrator settings: the defaults of solver.cpp (Solver) and the same environment switches
+// integrator settings: the constants of solver.cpp (Solver) and its two cache switches (KIN_LU_CACHE_SLOTS, KIN_LU_BAND)
 inline void res_default_settings(ResParams& P, int n_slots_max) {
   auto envd = [](const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; };
   auto envi = [](const char* n, long long d) { const char* e = getenv(n); return e ? atoll(e) : d; };
@@ -55,13 +55,14 @@ inline void res_default_settings(ResParams& P, int n_slots_max) {
   const double band = envd("KIN_LU_BAND", 0.35);
   P.n_slots = want;
   P.lu_band = want > 1 ? band : (getenv("KIN_LU_BAND") ? band : 0.0);
-  P.reuse_rate_max = envd("KIN_LU_RATE_MAX", 0.15);
-  P.crate_dy_max = envd("KIN_CRATE_DYMAX", 0.2);
-  P.lu_drift_max = envd("KIN_LU_DRIFT", 0.25);
-  P.newton_frac = envd("KIN_NEWTON_TOL", 0.03);
-  P.crate_max_age = envi("KIN_CRATE_AGE", 10);
-  P.lu_max_age = envi("KIN_LU_MAX_AGE", 50);
-  P.carry_rate = envi("KIN_CARRY_RATE", 1) != 0 ? 1 : 0;
+  // the constants of solver.cpp (Solver): reuse_rate_max, crate_dy_max, lu_drift_max, corrector tolerance, crate_max_age, lu_max_age
+  P.reuse_rate_max = 0.15;
+  P.crate_dy_max = 0.2;
+  P.lu_drift_max = 0.25;
+  P.newton_frac = 0.03;
+  P.crate_max_age = 10;
+  P.lu_max_age = 50;
+  P.carry_rate = 1;
 }
 
 inline void res_fill_params(ResParams& P, const kin_params& p, const ResGrid& g) {

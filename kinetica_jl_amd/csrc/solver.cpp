@@ -107,10 +107,6 @@ struct Solver {
     // 1173 -> 981, -10 %); small networks keep few rounds, their cost is the number of dependent launches
     // (C2: the loose setting is 15 % slower). Measured with tools/c5_lu_params.py and bench.py.
     if (N >= 4000) { opt.max_tail_degree = 32; opt.max_rounds = 16; opt.max_degree = 400; }
-    if (const char* e = getenv("KIN_LU_HUB_DEGREE")) opt.hub_degree = atoi(e);
-    if (const char* e = getenv("KIN_LU_MAX_ROUNDS")) opt.max_rounds = atoi(e);
-    if (const char* e = getenv("KIN_LU_MAX_TAIL_DEGREE")) opt.max_tail_degree = atoi(e);
-    if (const char* e = getenv("KIN_LU_MAX_DEGREE")) opt.max_degree = atoi(e);
     lu.analyze(N, H.j_ptr, H.j_col, opt, s);
     {
       // cache size: KIN_LU_CACHE_SLOTS (default 128), bounded by KIN_LU_CACHE_MB (default 32768) of device memory. A
@@ -121,27 +117,11 @@ struct Solver {
       double band = 0.35;
       size_t budget_mb = 32768;
       if (const char* e = getenv("KIN_INJECT_BAD_PIVOT")) inject_bad_pivot_at = atoll(e);
-      if (const char* e = getenv("KIN_LU_RATE_MAX")) reuse_rate_max = atof(e);
-      if (const char* e = getenv("KIN_CARRY_RATE")) carry_rate = atoi(e) != 0;
       if (const char* e = getenv("KIN_SPECULATE")) speculate = atoi(e) != 0;
       fuse_newton = lu.fused_tri && lu.m > 0 && lu.newton_grid() <= 10;
       if (const char* e = getenv("KIN_FUSE_NEWTON")) fuse_newton = atoi(e) != 0 && lu.fused_tri && lu.m > 0;
-      if (const char* e = getenv("KIN_ETACF")) cf_eta = atof(e);
-      if (const char* e = getenv("KIN_CF_RESET")) cf_resets = atoi(e) != 0;
-      if (const char* e = getenv("KIN_CF_GROWTH_CAP")) cf_growth_cap = atof(e);
-      if (const char* e = getenv("KIN_CF_SOFTCAP")) cf_softcap = atof(e);
-      if (const char* e = getenv("KIN_CF_RELAX")) cf_relax = atof(e);
-      if (const char* e = getenv("KIN_CRATE_AGE")) crate_max_age = atoll(e);
-      if (const char* e = getenv("KIN_CRATE_DYMAX")) crate_dy_max = atof(e);
-      if (const char* e = getenv("KIN_LU_MAX_AGE")) lu_max_age = atoll(e);
-      if (const char* e = getenv("KIN_LU_DRIFT")) lu_drift_max = atof(e);
       if (const char* e = getenv("KIN_LU_CACHE_SLOTS")) want = std::max(1, atoi(e));
       if (const char* e = getenv("KIN_LU_BAND")) band = atof(e);
-      if (const char* e = getenv("KIN_LU_ABSBAND")) lu_absband = atof(e);
-      if (const char* e = getenv("KIN_LU_PAIR")) lu_pair = atoi(e) != 0;
-      if (const char* e = getenv("KIN_LU_PAIR_MIN_M")) lu_pair_min_m = atoi(e);
-      if (const char* e = getenv("KIN_LU_PAIR_MAX_M")) lu_pair_max_m = atoi(e);
-      if (const char* e = getenv("KIN_LU_PAIR_FAST")) lu_pair_fast = std::max(1, std::min((int)GJ_BMAX, atoi(e)));
       if (const char* e = getenv("KIN_LU_CACHE_MB")) budget_mb = (size_t)std::max(1, atoi(e));
       if (h->lu_budget_mb > 0) budget_mb = std::min(budget_mb, h->lu_budget_mb);   // a replica's share (capi.cpp: replica_ensemble)
       const size_t fit = std::max<size_t>(1, budget_mb * 1024 * 1024 / std::max<size_t>(1, lu.slot_bytes()));
@@ -192,7 +172,7 @@ struct Solver {
     // 0.05 / 0.2 two of the 140 solves of tools/robustness_sweep.py collapsed their step size (DtLessThanMin at every retry
     // tolerance; the CPU mirror of the algorithm did the same) - iterates converged no further than asked leave enough
     // noise in the difference history for that. Measured: C3 0.434 -> 0.452 s, full C4 ramp 161 -> 163 s, sweep 140 / 140.
-    static const double frac = getenv("KIN_NEWTON_TOL") ? atof(getenv("KIN_NEWTON_TOL")) : 0.03;
+    constexpr double frac = 0.03;
     newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, frac);
   }
 
@@ -313,18 +293,12 @@ struct Solver {
         launch_slot_drift(N, n_checked, jv.p, d_jdiag.p, a, d_drift.p, s);
         KIN_HIP(hipMemcpyAsync(h_drift, d_drift.p, (size_t)n_checked * sizeof(double), hipMemcpyDeviceToHost, s));
       }
-      if (lu_band > 0.0 && lu_absband > 0.0) {   // the Jacobian's scale for the absolute reuse rule: rides on the same synchronisation
-        launch_jac_diag_absmax(N, jv.p, d_jdiag.p, d_drift.p + LU_MAX_SLOTS, s);
-        KIN_HIP(hipMemcpyAsync(h_drift + LU_MAX_SLOTS, d_drift.p + LU_MAX_SLOTS, sizeof(double), hipMemcpyDeviceToHost, s));
-        jnorm_pending = true;
-      }
     }
     rhs(y.p, f0.p);
     launch_bdf_norms(N, y.p, f0.p, nullptr, atol, rtol, ctrl.p, s);
     sync_ctrl();
     for (int i = 0; i < n_checked; i++)
       if (lu.slots[i].valid && !(h_drift[i] <= lu_drift_max)) { lu.slots[i].valid = false; st.n_lu_dropped++; }
-    if (jnorm_pending) { jnorm = 2.0 * h_drift[LU_MAX_SLOTS]; jnorm_pending = false; }
     if (hc->nonfinite) return false;
     const double interval = std::fabs(t_bound - t0);
     if (explicit_mode) {
@@ -382,8 +356,6 @@ struct Solver {
     order = 1;
     n_equal = 0;
     fail_score = 0.0;
-    cf_recent = false;
-    h_ceiling = INF;
     first_selection = true;
     return true;
   }
@@ -403,24 +375,6 @@ struct Solver {
     // three failed attempts in a row: nothing cached is trusted any more either
     for (auto& q : lu.slots) q.valid = false;
     force_jac_refresh = true;
-  }
-
-  // Warm continuation at a segment boundary (chunk start or rate update): the system is autonomous
-  // and segments run in local time, so the difference history, order and step size stay valid;
-  // only the Jacobian (and with it the iteration matrix) is refreshed when the rates changed.
-  // The reference re-initialises its integrator there (reinit!, methods.jl:260, 819 - order 1 and a
-  // ~1e-20 s first step, i.e. ~60 steps and ~20 factorisations per segment); results agree within
-  // the solver tolerance. Opt-in (KIN_WARM_RESTART=1); the default re-initialises like the reference.
-  void resume(bool rates_changed) {
-    spec = Spec{};
-    t = 0.0;
-    st.n_restarts++;
-    flush_accept();
-    if (rates_changed) {
-      KIN_HIP(hipMemcpyAsync(y.p, D.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
-      eval_jac(y.p);
-      jac_current = true;
-    }
   }
 
   // Warm continuation at a chunk start with unchanged rates (kin_params.solve_chunks == 2): history, order and step size are
@@ -445,9 +399,8 @@ struct Solver {
     }
   }
 
-  // CVODE's carried convergence rate (KIN_CARRY_RATE=0 switches it off): each factorisation remembers the contraction its
-  // corrector iterations have shown, and the first iteration of a step is judged with it (solver_kernels.hip)
-  bool carry_rate = true;
+  // CVODE's carried convergence rate: each factorisation remembers the contraction its corrector iterations have shown, and
+  // the first iteration of a step is judged with it (solver_kernels.hip)
   // The corrector update folded into the solve's last gather launch (stagec_newton_kernel). One launch less per iteration,
   // but every workgroup of the gather then takes part in the reduction hand-over (partial sums + arrival ticket), and that
   // costs ~0.3 us per workgroup: measured per 20-chunk solve, fused against separate: 300 species 0.101 / 0.110 s, 1 000
@@ -462,7 +415,7 @@ struct Solver {
   int64_t crate_max_age = 10;
   // is the slot's remembered rate fresh enough for the first-iteration test? (it keeps being carried and updated either way)
   bool crate_fresh(const SparseLU::Slot& q) const {
-    return carry_rate && q.crate < 1.0 && q.crate_restart == st.n_restarts && st.n_steps - q.crate_step <= crate_max_age;
+    return q.crate < 1.0 && q.crate_restart == st.n_restarts && st.n_steps - q.crate_step <= crate_max_age;
   }
   // KIN_CRATE_DYMAX: a first correction larger than this (in error-weight units) always gets a second iteration. If the true
   // contraction is worse than the remembered one - up to the 0.2 that a measurement would still accept - the error left behind is
@@ -511,8 +464,8 @@ struct Solver {
     // matrix is c J, and the absolute rule only admits slots whose matrix and this attempt's are both close to the identity)
     const double upd = (q.c_fact != c && std::fabs(c / q.c_fact - 1.0) <= lu_band) ? 2.0 / (1.0 + c / q.c_fact) : 1.0;
     const double rate_max = (lu_band > 0.0 && !cache_suspended && !slot_is_fresh) ? reuse_rate_max : 1.0;
-    const double crate0 = carry_rate ? q.crate : 1.0, tol_first = ((spec_it && carry_rate) || crate_fresh(q)) ? newton_tol : -1.0;
-    const bool from_ctrl = spec_it && carry_rate;
+    const double crate0 = q.crate, tol_first = (spec_it || crate_fresh(q)) ? newton_tol : -1.0;
+    const bool from_ctrl = spec_it;
     if (fuse_newton) {
       // the solve's last gather stage and the corrector update in one launch
       NewtonFuse f;
@@ -560,7 +513,7 @@ struct Solver {
     if (nearest_slot(c2) != cur_slot) return;          // (the slot can only drop out by the rule that also clears spec_go)
     const SparseLU::Slot& q = lu.slots[cur_slot];
     // the carried rate must count as fresh in the next step whether or not this one measures it anew
-    if (carry_rate && !(q.crate < 1.0 && q.crate_restart == st.n_restarts && (st.n_steps + 1) - q.crate_step <= crate_max_age)) return;
+    if (!(q.crate < 1.0 && q.crate_restart == st.n_restarts && (st.n_steps + 1) - q.crate_step <= crate_max_age)) return;
     spec.enq = true; spec.alive = false;
     spec.t_new = t2; spec.hh = hh2; spec.c = c2; spec.slot = cur_slot; spec.blind = blind; spec.order = order;
     spec.seq = ++seq_no;
@@ -591,10 +544,7 @@ struct Solver {
       // a slot may be at most 50 accepted steps old (CVODE's bound on the age of its Jacobian)
       if (pre_attempt && st.n_steps - q.step_stamp > 50) continue;
       const double r = std::fabs(std::log(c / q.c_fact));
-      // ... or - KIN_LU_ABSBAND - close to c in ABSOLUTE terms on the Jacobian's scale: the corrector with the matrix of c_fact
-      // contracts by about |c - c_fact| rho(J), whatever the ratio of the two (while c rho(J) << 1 the matrix is nearly the
-      // identity for every c: the first chunk of a solve from a pure initial state climbs through seven decades of such c)
-      const bool ok = std::fabs(c / q.c_fact - 1.0) <= lu_band || (lu_absband > 0.0 && jnorm > 0.0 && std::fabs(c - q.c_fact) * jnorm <= lu_absband);
+      const bool ok = std::fabs(c / q.c_fact - 1.0) <= lu_band;
       if (r < bd && ok) { bd = r; best = i; }
     }
     return best;
@@ -608,20 +558,13 @@ struct Solver {
     for (int i = 1; i < (int)lu.slots.size(); i++) if (lu.slots[i].last_use < lu.slots[v].last_use) v = i;
     return v;
   }
-  // ---- memory of a convergence failure (CVODE: cvHandleNFlag / cvSetEta). A failed corrector cuts the step by `cf_eta`
-  // (CVODE's ETACF = 0.25; 0.5 until round 3), does not count towards the history reset unless `cf_resets` (CVODE rebuilds its
-  // history only after repeated ERROR-TEST failures: after a reset the order-1 predictor is explicit Euler, which at the step
-  // sizes of a late, slowly varying solution is far outside the corrector's convergence region - the complete-timespan C3
-  // solve then halved its step ten more times, each with a factorisation of its own), and the first step-size
-  // selection after it may grow the step by `cf_growth_cap` at most (CVODE: no growth on the step after a failure).
-  double cf_eta = 0.25, cf_growth_cap = 0.0;
-  bool cf_resets = false, cf_recent = false;
-  // ... and a soft ceiling on the step size: a corrector that fails with a matrix made for this very step from a current
-  // Jacobian says the STEP is too long (late in a solve the error test allows steps at which the corrector stalls on the
-  // rounding floor of f). The ceiling is set to cf_softcap x that step, every later step-size selection stays below
-  // it, and each selection relaxes it by cf_relax - the step size then hovers below the corrector's limit instead of
-  // overshooting it by the error test's factor of 10 and falling back by orders of magnitude. Cleared by a restart.
-  double cf_softcap = 0.0, cf_relax = 1.3, h_ceiling = INF;   // (off by default: measured WORSE on the run it was built for - the failing step size is not a stable threshold: 3 400 - 4 900 steps against 1 930)
+  // ---- a convergence failure (CVODE: cvHandleNFlag / cvSetEta): a failed corrector cuts the step by ETACF = 0.25 (0.5 until round
+  // 3) and does not count towards the history reset (CVODE rebuilds its history only after repeated ERROR-TEST failures: after a
+  // reset the order-1 predictor is explicit Euler, which at the step sizes of a late, slowly varying solution is far outside the
+  // corrector's convergence region - the complete-timespan C3 solve then halved its step ten more times, each with a
+  // factorisation of its own; docs/DESIGN_HISTORY.md R4 has the A/B and the variants that were measured and dropped: a growth
+  // cap after a failure, a soft step-size ceiling)
+  static constexpr double cf_eta = 0.25;
   bool force_jac_refresh = false;   // a vanished pivot: the next attempt starts from a Jacobian at its own predictor
   // After an error-test rejection the retry gets a factorisation made for its own c (CVODE's rule: a failed error test
   // forces a linear-solver setup): a converged corrector whose matrix was reused carries an iteration error that the
@@ -634,86 +577,7 @@ struct Solver {
   // needs c J_ii ~ 1 on an autocatalytic species and practically never happens by itself)
   int64_t inject_bad_pivot_at = -1, attempt_no = 0;
   bool trace = false;   // KIN_TRACE_CHUNK=n: one line per corrector attempt of chunk n (diagnostic)
-  // ---- two step-size bands per factorisation (KIN_LU_PAIR=1; off by default, see the end of this comment). While the step size climbs - after every
-  // restart, i.e. at every chunk start, and through the first chunk's transient - the factorisation that follows this one is
-  // for a predictable c (10 x this one while the step size grows by its cap, else the neighbouring band) from almost the same
-  // Jacobian, and the dense inverses of two matrices are ONE chain of launches (280 us per matrix instead of 460,
-  // launch_gauss_jordan_batched): the second band's matrix is made now, into a slot of its own, whenever this factorisation
-  // was asked for because c grew. Dense blocks of lu_pair_min_m ... lu_pair_max_m only: below, the networks run in the resident
-  // kernel; above, the inverse is bandwidth-bound and a second matrix costs what it costs alone (C5, m = 3 126: the 5-chunk
-  // solve 0.85 -> 0.94 s with it). Measured (profiles/r04_lu_pair_absband_ab.txt): the 100-chunk C3 solve 0.443 ->
-  // 0.421 s, its first 5 chunks 0.169 -> 0.155 s, the 48 runs of the 10k robustness sweep 19.5 -> 17.6 s with no retry (2
-  // before) and 28 % more corrector failures (a predicted matrix that does not fit is refactorised like any other). A
-  // vanished pivot in the second matrix goes unnoticed until the slot is used (the corrector then fails and the slot is
-  // dropped like any other that does not converge). NOT the default: the runs stay within their tolerance and the deviations
-  // from the C3 truths are the same on average (30 chunks: max 170 -> 157 units, rms 7.6 -> 6.8), but their maxima at single
-  // save points move by factors (37 -> 53-88 units after 5 chunks, 58-81 -> 95-146 with warm chunk starts), past the bounds
-  // tests/test_gpu_configs.py asserts; a speed-up of 5 % does not buy a looser parity bound.
-  double lu_absband = 0.0, jnorm = 0.0;   // KIN_LU_ABSBAND: |c - c_fact| * (2 max |J_ii|) a slot may be away from c; jnorm = that scale, measured at restarts
-  bool jnorm_pending = false;
-  bool lu_pair = false;
-  int lu_pair_min_m = 400, lu_pair_max_m = 1536, lu_pair_fast = 2;   // matrices per chain while the step size climbs by its cap
-  double last_factor_c = 0.0;      // c of the last factorisation since the restart (0: none yet)
-  int64_t last_factor_restart = -1;
-  DevBuf<double> pair_pinv;
-  DevBuf<int> pair_bad;
-  int64_t n_paired = 0;
-  void stamp_slot(int slot) {
-    lu.slots[slot].last_use = ++use_clock;
-    lu.slots[slot].jac_stamp = jac_stamp_now;
-    lu.slots[slot].step_stamp = st.n_steps - steps_since_jac;
-    if (lu_band > 0.0) {
-      lu.slots[slot].jd.alloc(N);
-      launch_jac_diag(N, jv.p, d_jdiag.p, lu.slots[slot].jd.p, s);
-    }
-  }
-  bool factor_pair(int slot, double c) {
-    if (getenv("KIN_LU_PAIR_DEBUG")) fprintf(stderr, "[factor] restart %lld step %lld c %.4e ratio %.3f\n", (long long)st.n_restarts, (long long)st.n_steps, c, last_factor_c > 0 ? c / last_factor_c : 0.0);
-    const bool first = last_factor_restart != st.n_restarts;
-    const double ratio = (!first && last_factor_c > 0.0) ? c / last_factor_c : 0.0;
-    const bool climbing = first || ratio > 1.0;
-    last_factor_c = c; last_factor_restart = st.n_restarts;
-    if (!lu_pair || lu_band <= 0.0 || lu.m < lu_pair_min_m || lu.m > lu_pair_max_m || !climbing) return false;
-    // the c of the factorisations to come: after a restart the step size climbs by its cap of 10 per selection until the error
-    // test bites (a factorisation at every one of those steps), later by the width of a band per factorisation
-    const double next_band = (1.0 + lu_band) / (1.0 - lu_band) * 0.97;     // the band next to this one, with a little overlap
-    const bool fast = first || ratio >= 3.0;
-    const double step = fast ? std::min(10.0, first ? 10.0 : ratio) : next_band;
-    const int want = fast ? lu_pair_fast : 2;
-    int slots_[GJ_BMAX]; double cs[GJ_BMAX]; int n = 1;
-    slots_[0] = slot; cs[0] = c;
-    lu.factor_sparse_into(c, jv.p, lu.slots[slot], &ctrl.p->lu_bad, s);
-    lu.slots[slot].last_use = ++use_clock;                            // (victim_slot below must not pick it)
-    pair_pinv.alloc((size_t)GJ_BMAX * 2 * 32 * 32); pair_bad.alloc(1);
-    for (int g = 1; g < want && n < GJ_BMAX; g++) {
-      const double cg = cs[n - 1] * step;
-      if (nearest_slot(cg) >= 0) break;                               // already there
-      const int sg = victim_slot();
-      bool taken = false;
-      for (int i = 0; i < n; i++) taken = taken || slots_[i] == sg;
-      if (taken) break;
-      lu.factor_sparse_into(cg, jv.p, lu.slots[sg], pair_bad.p, s);
-      lu.slots[sg].last_use = ++use_clock;
-      slots_[n] = sg; cs[n] = cg; n++;
-    }
-    if (n == 1) {
-      lu.slots[slot].sinv = launch_gauss_jordan(lu.slots[slot].W.p + lu.off_S, lu.slots[slot].S2.p, lu.mpad, lu.pinv.p, &ctrl.p->lu_bad, s);
-      return true;
-    }
-    double* S[GJ_BMAX]; double* S2[GJ_BMAX]; int* bad[GJ_BMAX];
-    for (int i = 0; i < n; i++) { S[i] = lu.slots[slots_[i]].W.p + lu.off_S; S2[i] = lu.slots[slots_[i]].S2.p; bad[i] = i == 0 ? &ctrl.p->lu_bad : pair_bad.p; }
-    const int where = launch_gauss_jordan_batched(n, S, S2, lu.mpad, pair_pinv.p, bad, s);
-    for (int i = 0; i < n; i++) lu.slots[slots_[i]].sinv = where ? S2[i] : S[i];
-    for (int i = 1; i < n; i++) { stamp_slot(slots_[i]); st.n_factor++; n_paired++; }
-    return true;
-  }
   void factor_into(int slot, double c) {
-    if (factor_pair(slot, c)) {
-      stamp_slot(slot);
-      cur_slot = slot;
-      st.n_factor++;
-      return;
-    }
     lu.factor(c, jv.p, slot, &ctrl.p->lu_bad, s);
     lu.slots[slot].last_use = ++use_clock;
     lu.slots[slot].jac_stamp = jac_stamp_now;
@@ -948,15 +812,13 @@ struct Solver {
         // error-test failure
         const bool conv_failure = !converged;
         const double eta = conv_failure ? cf_eta : 0.5;
-        if (conv_failure && cf_softcap > 0.0 && !hc->lu_bad) h_ceiling = std::min(h_ceiling, cf_softcap * h_abs);
         h_abs *= eta;
         change_D(order, eta);
         n_equal = 0;
         lu_valid = false;
         st.n_rejected++;
         first_selection = false;   // (CVODE: any failed attempt sets etamax = 1, the first step's 1e4 is gone)
-        cf_recent = cf_recent || conv_failure;
-        if (!conv_failure || cf_resets) fail_score += 1.0;
+        if (!conv_failure) fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
         continue;
       }
@@ -1024,10 +886,6 @@ struct Solver {
     // growth cap 1e4 at the first selection after a (re)initialisation, 10 afterwards (CVODE: ETAMX1, ETAMX2 / ETAMX3)
     double factor = std::min(first_selection ? FIRST_MAX_FACTOR : MAX_FACTOR, safety_o * best);
     first_selection = false;
-    if (cf_recent && cf_growth_cap > 0.0) factor = std::min(factor, cf_growth_cap);
-    cf_recent = false;
-    if (h_abs * factor > h_ceiling) factor = std::max(h_ceiling / h_abs, MIN_FACTOR);   // (never a cut below what a rejection would make)
-    h_ceiling *= cf_relax;
     h_abs *= factor;
     change_D(order, factor);
     n_equal = 0;
@@ -1253,10 +1111,9 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
   chunk_start.alloc(N);
   bool have_history = false, rates_changed = false;
   int64_t rates_in_force = -1;
-  // default: re-initialise at every segment start like the reference; KIN_WARM_RESTART=1 opts in to
-  // the warm continuation (experimental: larger steps make tolerance-level negative undershoots of
-  // species with fast self-reactions more likely, and d/dt u = -2 k u^2 runs away once u < 0)
-  static const bool cold_restarts = !(getenv("KIN_WARM_RESTART") && atoi(getenv("KIN_WARM_RESTART")) != 0);
+  // every segment start re-initialises like the reference (reinit!, methods.jl:260, 819), except the chunk starts of
+  // kin_params.solve_chunks == 2 whose rates did not change (resume_chunk). Carrying the history across RATE UPDATES was built and
+  // measured in round 4 (3 180 rejected steps and 4x the time on the C4 prefix) and is gone (docs/DESIGN_HISTORY.md R4).
 
   // initial rates = calculator at the initial conditions (methods.jl:672, 734); a tstop at the
   // very start overrides it below
@@ -1340,7 +1197,6 @@ int solve_entry(kin_network* h, const kin_params& p, const double* u0, const dou
           // chunk boundaries; between the rate updates of a ramp the integrator is re-initialised as the reference does)
           const bool warm_chunk = p.solve_chunks == 2 && have_history && !rates_changed && !continuous && !S.explicit_mode;
           if (warm_chunk) S.resume_chunk();
-          else if (have_history && !cold_restarts) S.resume(rates_changed);
           else if (!S.restart(0.0, seg_len)) { retcode = KIN_RETCODE_UNSTABLE; failed = true; break; }
           have_history = true;
           rates_changed = false;

@@ -885,8 +885,7 @@ __global__ __launch_bounds__(SEG_WG) void stagec_newton_kernel(SegPlanView p, do
 }
 
 static bool stagec_big_wg(const SegPlanView& p) {
-  static const int force = getenv("KIN_FUSE_WG") ? atoi(getenv("KIN_FUSE_WG")) : 0;
-  return p.B > 0 || force == 1024;
+  return p.B > 0;
 }
 int stagec_newton_grid(const SegPlanView& p, int m) {
   const int tasks = p.G + p.S + (int)ceil_div(m, 64);

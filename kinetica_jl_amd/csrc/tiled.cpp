@@ -389,6 +389,24 @@ TiledHost build_tiled(const NetworkHost& H, int bs, int h_force) {
   }
   L.identity = true;
   for (int32_t i = 0; i < N; i++) if (L.species_of_lib[i] != i) { L.identity = false; break; }
+  if (!L.identity) {
+    // staging tables of the layout conversion (tiled.hpp): groups = hubs, then the windows; each is ascending in the caller's index
+    std::vector<int32_t> g_lo{0}, g_hi{h};
+    for (int t = 0; t < T; t++) { g_lo.push_back(L.win_off[t]); g_hi.push_back(L.win_off[t] + L.win_cnt[t]); }
+    L.stage_lib.clear(); L.stage_off.clear();
+    L.stage_lib.reserve(N); L.stage_off.reserve(N);
+    std::vector<int32_t> cur(g_lo);     // next library index of every group not yet emitted
+    for (int32_t p0 = 0; p0 < N; p0 += TILED_PIECE) {
+      const int32_t p1 = std::min<int32_t>(N, p0 + TILED_PIECE);
+      for (size_t g = 0; g < cur.size(); g++)
+        while (cur[g] < g_hi[g] && L.species_of_lib[cur[g]] < p1) {
+          L.stage_lib.push_back(cur[g]);
+          L.stage_off.push_back(L.species_of_lib[cur[g]] - p0);
+          cur[g]++;
+        }
+      if ((int32_t)L.stage_lib.size() != p1) { L.why = "internal: staging tables of the layout conversion do not cover a piece"; return L; }
+    }
+  }
   int32_t wmax = 0;
   for (int t = 0; t < T; t++) wmax = std::max(wmax, L.win_cnt[t]);
   L.E = L.wbase + wmax;

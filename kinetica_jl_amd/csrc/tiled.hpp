@@ -37,6 +37,7 @@ constexpr int TILED_MIN_ROWS = 2 * TILED_BATCH;   // iteration rows of a segment
 // touch hubs only go where they fill such a batch up (tiled.cpp).
 constexpr int TILED_MAX_SEG = 48;              // segments a layout may have (their descriptors travel in the kernel arguments)
 constexpr int TILED_EXP_TAB = 128;             // entries of the exp table the temperature form keeps in LDS (exp_tab.hpp)
+constexpr int TILED_PIECE = 8192;                // species per piece of the staged layout conversion (64 kB of LDS: two workgroups per CU)
 constexpr int TILED_LDS_ENTRIES = 10176;       // entries per LDS array (u, du): (2 x 10176 + 128) x 8 B = 160 kB exactly
 
 struct TiledHost {
@@ -52,6 +53,12 @@ struct TiledHost {
   int32_t row_quantum = TILED_BATCH;   // iteration rows of every segment are a multiple of this (2 or 4, see above)
   bool identity = true;            // library species order == caller's
   std::vector<int32_t> species_of_lib, lib_of_species;   // N each
+  // Layout conversion through LDS (tiled_kernels.hip: permute_staged_kernel; only when !identity). The caller's row is cut into
+  // pieces of TILED_PIECE species; hubs and windows are each sorted by the caller's species index, so the species of a piece
+  // that belong to one of them are a contiguous run of the library row. For the q-th element of that enumeration (piece after
+  // piece, inside a piece hubs then window after window): stage_lib[q] = its library index, stage_off[q] = its offset inside
+  // the piece. Piece c owns q in [c TILED_PIECE, min(N, (c + 1) TILED_PIECE)).
+  std::vector<int32_t> stage_lib, stage_off;             // N each
   std::vector<int32_t> win_off, win_cnt;                 // T each: window s = library species [win_off, win_off + win_cnt)
   std::vector<int32_t> copy_src;   // n_copy: library index (= LDS entry) of the species behind each copy entry
   std::vector<uint32_t> rec;       // 2 words per record: four 14-bit LDS labels with fixed roles + flags in bits 56.. (tiled_kernels.hip)

@@ -14,7 +14,6 @@ namespace {
 
 // workgroup size: 10 staged doubles per thread must cover the LDS entries (tiled_kernels.hip)
 int tiled_block_size(int64_t N) {
-  if (const char* e = getenv("KIN_TILED_BS")) { const int b = atoi(e); if (b == 256 || b == 512 || b == 1024) return b; }
   return N <= 2300 ? 256 : (N <= 4850 ? 512 : 1024);
 }
 
@@ -22,9 +21,7 @@ int tiled_block_size(int64_t N) {
 void ensure_tiled(kin_network* h) {
   if (!h->tiled_tried) {
     h->tiled_tried = true;
-    int force = 0;
-    if (const char* e = getenv("KIN_TILED_HUBS")) force = atoi(e);
-    h->tiled = build_tiled(h->host, tiled_block_size(h->host.N), force);
+    h->tiled = build_tiled(h->host, tiled_block_size(h->host.N), 0);
     const TiledHost& L = h->tiled;
     if (L.ok) {
       hipStream_t s = h->stream;
@@ -34,6 +31,7 @@ void ensure_tiled(kin_network* h) {
       h->t_copy.upload(L.copy_src, s);
       h->t_kf.upload(L.kf, s); h->t_kr.upload(L.kr, s); h->t_rxn_of_slot.upload(rxn_of_slot, s); h->t_kslot.upload(L.kslot, s);
       h->t_spec_of_lib.upload(L.species_of_lib, s); h->t_lib_of_spec.upload(L.lib_of_species, s);
+      if (!L.identity) { h->t_stage_lib.upload(L.stage_lib, s); h->t_stage_off.upload(L.stage_off, s); }
       KIN_HIP(hipStreamSynchronize(s));
     }
   }
@@ -77,6 +75,13 @@ TiledView view_of(kin_network* h) {
 
 void require(bool c, int code, const char* msg) {
   if (!c) throw KinError(code, msg);
+}
+
+// caller's species order <-> library order for B states (only called when the two differ or the caller asks for a copy)
+void states_convert(kin_network* h, int64_t B, bool to_lib, const double* d_in, double* d_out, hipStream_t s) {
+  const int64_t N = h->host.N;
+  if (h->tiled.identity) KIN_HIP(hipMemcpyAsync(d_out, d_in, (size_t)B * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+  else launch_permute_staged(N, B, to_lib, h->t_stage_lib.p, h->t_stage_off.p, d_in, d_out, s);
 }
 
 }  // namespace
@@ -142,7 +147,7 @@ int kin_states_to_lib_dev(kin_network* h, int64_t B, const double* d_in, double*
   KIN_TRY(h)
   require(B > 0 && d_in && d_out && d_in != d_out, ERR_INVALID_ARG, "bad arguments");
   ensure_tiled(h);
-  launch_gather_rows(h->host.N, h->host.N, B, h->t_spec_of_lib.p, d_in, d_out, stream ? (hipStream_t)stream : h->stream);
+  states_convert(h, B, true, d_in, d_out, stream ? (hipStream_t)stream : h->stream);
   KIN_CATCH(h)
 }
 
@@ -151,7 +156,7 @@ int kin_states_from_lib_dev(kin_network* h, int64_t B, const double* d_in, doubl
   KIN_TRY(h)
   require(B > 0 && d_in && d_out && d_in != d_out, ERR_INVALID_ARG, "bad arguments");
   ensure_tiled(h);
-  launch_gather_rows(h->host.N, h->host.N, B, h->t_lib_of_spec.p, d_in, d_out, stream ? (hipStream_t)stream : h->stream);
+  states_convert(h, B, false, d_in, d_out, stream ? (hipStream_t)stream : h->stream);
   KIN_CATCH(h)
 }
 
@@ -220,9 +225,34 @@ int kin_rhs_batched_T_dev(kin_network* h, int64_t B, const double* d_u, const do
     // caller's species order: two layout conversions around the sweep (16 N bytes per state each way; a caller that
     // keeps its states in library order calls kin_rhs_tiled_dev and pays neither)
     h->t_u.alloc((size_t)B * N); h->t_du.alloc((size_t)B * N);
-    launch_gather_rows(N, N, B, h->t_spec_of_lib.p, d_u, h->t_u.p, s);
+    states_convert(h, B, true, d_u, h->t_u.p, s);
     launch_tiled_sweep(view_of(h), h->tiled.BS, h->n_cu, B, h->t_u.p, nullptr, d_T, h->t_du.p, s);
-    launch_gather_rows(N, N, B, h->t_lib_of_spec.p, h->t_du.p, d_du, s);
+    states_convert(h, B, false, h->t_du.p, d_du, s);
+  }
+  KIN_CATCH(h)
+}
+
+int kin_rhs_batched_klib_dev(kin_network* h, int64_t B, const double* d_u, const double* d_k_lib, double* d_du, void* stream) {
+  if (!h) return KIN_ERR_INVALID_ARG;
+  KIN_TRY(h)
+  require(B > 0 && d_u && d_k_lib && d_du, ERR_INVALID_ARG, "bad arguments");
+  require((((uintptr_t)d_k_lib) & 15) == 0, ERR_INVALID_ARG, "d_k_lib must be 16-byte aligned");
+  ensure_tiled(h);
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const int64_t N = h->host.N;
+  if (h->tiled.P == 0) {
+    KIN_HIP(hipMemsetAsync(d_du, 0, (size_t)B * N * sizeof(double), s));
+    return KIN_OK;
+  }
+  if (h->tiled.identity) {
+    launch_tiled_sweep(view_of(h), h->tiled.BS, h->n_cu, B, d_u, d_k_lib, nullptr, d_du, s);
+  } else {
+    // the species permutation on the way in and out, each ONE coalesced pass through LDS (16 N bytes per state each way, next to
+    // the sweep's 8 k_len + 16 N): the workspace rows live on the handle
+    h->t_u.alloc((size_t)B * N); h->t_du.alloc((size_t)B * N);
+    states_convert(h, B, true, d_u, h->t_u.p, s);
+    launch_tiled_sweep(view_of(h), h->tiled.BS, h->n_cu, B, h->t_u.p, d_k_lib, nullptr, h->t_du.p, s);
+    states_convert(h, B, false, h->t_du.p, d_du, s);
   }
   KIN_CATCH(h)
 }

@@ -318,6 +318,67 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n_dst, int64_t
   for (int b = blockIdx.y; b < B; b += gridDim.y) dst[(size_t)b * n_dst + j] = m >= 0 ? src[(size_t)b * n_src + m] : 0.0;
 }
 
+// The species permutation of the layout conversion, staged through LDS (tiled.hpp). One workgroup = one piece of one state:
+//   TO_LIB   the piece of the caller's row comes in as one coalesced stream, goes into LDS, and leaves as the runs of the
+//            library row its species belong to (one run per hub / window range: hundreds of consecutive doubles each);
+//   else     the runs come in, the piece goes out.
+// 8 N bytes in and 8 N bytes out per state, nothing fetched twice: the plain gather above reads (or writes) 8-byte entries
+// scattered over the whole row, a 64-byte request each once the row has left the cache (C5, B = 1024: 0.35 / 0.21 ms for the
+// two directions; DESIGN 3.1b has this kernel's numbers). All loads of a thread are issued before its first LDS access:
+// 32 elements per thread = 64 kB in flight per workgroup.
+// VEC2: the rows are 16-byte aligned (N even, aligned bases) - the piece side moves 16 bytes per lane.
+template <bool TO_LIB, bool VEC2>
+__global__ __launch_bounds__(256) void permute_staged_kernel(int N, const int32_t* __restrict__ stage_lib, const int32_t* __restrict__ stage_off,
+                                                             const double* __restrict__ src, double* __restrict__ dst) {
+  __shared__ double2 buf2[TILED_PIECE / 2];
+  double* buf = (double*)buf2;
+  constexpr int PT = TILED_PIECE / 256;
+  const int p0 = blockIdx.x * TILED_PIECE;
+  const int cnt = min(N - p0, TILED_PIECE);
+  const double* s = src + (size_t)blockIdx.y * N;
+  double* d = dst + (size_t)blockIdx.y * N;
+  int32_t jl[PT], of[PT];
+#pragma unroll
+  for (int x = 0; x < PT; x++) {
+    const int q = threadIdx.x + 256 * x;
+    const bool ok = q < cnt;
+    jl[x] = ok ? stage_lib[p0 + q] : -1;
+    of[x] = ok ? stage_off[p0 + q] : 0;
+  }
+  if (TO_LIB) {
+    if (VEC2) {   // (cnt is even whenever N is: every piece but the last is whole)
+      double2 v2[PT / 2];
+#pragma unroll
+      for (int x = 0; x < PT / 2; x++) { const int q = threadIdx.x + 256 * x; v2[x] = 2 * q < cnt ? ((const double2*)(s + p0))[q] : make_double2(0.0, 0.0); }
+#pragma unroll
+      for (int x = 0; x < PT / 2; x++) { const int q = threadIdx.x + 256 * x; if (2 * q < cnt) buf2[q] = v2[x]; }
+    } else {
+      double v[PT];
+#pragma unroll
+      for (int x = 0; x < PT; x++) { const int q = threadIdx.x + 256 * x; v[x] = q < cnt ? s[p0 + q] : 0.0; }
+#pragma unroll
+      for (int x = 0; x < PT; x++) { const int q = threadIdx.x + 256 * x; if (q < cnt) buf[q] = v[x]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < PT; x++) if (jl[x] >= 0) d[jl[x]] = buf[of[x]];
+  } else {
+    double v[PT];
+#pragma unroll
+    for (int x = 0; x < PT; x++) v[x] = jl[x] >= 0 ? s[jl[x]] : 0.0;
+#pragma unroll
+    for (int x = 0; x < PT; x++) if (jl[x] >= 0) buf[of[x]] = v[x];
+    __syncthreads();
+    if (VEC2) {
+#pragma unroll
+      for (int x = 0; x < PT / 2; x++) { const int q = threadIdx.x + 256 * x; if (2 * q < cnt) ((double2*)(d + p0))[q] = buf2[q]; }
+    } else {
+#pragma unroll
+      for (int x = 0; x < PT; x++) { const int q = threadIdx.x + 256 * x; if (q < cnt) d[p0 + q] = buf[q]; }
+    }
+  }
+}
+
 // k_lib[b][2 p], k_lib[b][2 p + 1] = k[b][kf[p]], k[b][kr[p]] for a layout whose records all have two slots (k_lib row = 2 P):
 // one thread per record. Where the caller keeps a reaction and its reverse next to each other at an even position - the
 // usual case - the pair travels as ONE 16-byte load (swapped when the library made the reverse the record's forward
@@ -405,6 +466,24 @@ void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* 
   if (n_dst == 0 || B == 0) return;
   dim3 grid((unsigned)ceil_div(n_dst, 256), (unsigned)std::min<int64_t>(B, 1024));
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, s, n_dst, n_src, (int)B, map, src, dst);
+  KIN_HIP(hipGetLastError());
+}
+
+void launch_permute_staged(int64_t N, int64_t B, bool to_lib, const int32_t* stage_lib, const int32_t* stage_off, const double* src,
+                           double* dst, hipStream_t s) {
+  if (N == 0 || B == 0) return;
+  // (blockIdx.y carries the state: 65 535 states per launch)
+  for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+    const int64_t nb = std::min<int64_t>(65535, B - b0);
+    dim3 grid((unsigned)ceil_div(N, (int64_t)TILED_PIECE), (unsigned)nb);
+    const double* sp = src + (size_t)b0 * N;
+    double* dp = dst + (size_t)b0 * N;
+    const bool vec2 = N % 2 == 0 && ((((uintptr_t)sp) | ((uintptr_t)dp)) & 15) == 0;
+    if (to_lib && vec2) hipLaunchKernelGGL((permute_staged_kernel<true, true>), grid, dim3(256), 0, s, (int)N, stage_lib, stage_off, sp, dp);
+    else if (to_lib) hipLaunchKernelGGL((permute_staged_kernel<true, false>), grid, dim3(256), 0, s, (int)N, stage_lib, stage_off, sp, dp);
+    else if (vec2) hipLaunchKernelGGL((permute_staged_kernel<false, true>), grid, dim3(256), 0, s, (int)N, stage_lib, stage_off, sp, dp);
+    else hipLaunchKernelGGL((permute_staged_kernel<false, false>), grid, dim3(256), 0, s, (int)N, stage_lib, stage_off, sp, dp);
+  }
   KIN_HIP(hipGetLastError());
 }
 

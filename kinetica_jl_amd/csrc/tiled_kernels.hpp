@@ -28,6 +28,11 @@ void launch_tiled_sweep(const TiledView& v, int bs, int n_cu, int64_t B, const d
                         double* du, hipStream_t s);
 // dst[b][j] = map[j] >= 0 ? src[b][map[j]] : 0 for b < B (rows of n_dst / n_src doubles): the layout conversions
 void launch_gather_rows(int64_t n_dst, int64_t n_src, int64_t B, const int32_t* map, const double* src, double* dst, hipStream_t s);
+// The species permutation through LDS (tiled.hpp: stage_lib / stage_off): every global access is part of a coalesced stream -
+// the caller's row piece by piece, the library row in runs of one hub / window range per piece. to_lib: dst (library order) from
+// src (caller's order); else the reverse. B x N doubles each way.
+void launch_permute_staged(int64_t N, int64_t B, bool to_lib, const int32_t* stage_lib, const int32_t* stage_off, const double* src,
+                           double* dst, hipStream_t s);
 // k_lib[b][2 p .. 2 p + 1] = k[b][kf[p]], k[b][kr[p]] (0 without a reverse): layouts whose records all have two slots; src rows of R
 // doubles, R even and src 16-byte aligned
 void launch_rates_to_lib_pairs(int P, int64_t R, int64_t B, const int32_t* kf, const int32_t* kr, const double* src, double* dst,

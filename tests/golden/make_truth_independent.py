@@ -206,6 +206,22 @@ def c5():
            independent_method=f"scipy Radau (SuperLU, MMD ordering) over the first rate interval, rtol {RELTOL * TIGHT:g}, atol {ABSTOL * TIGHT:g}")
 
 
+def c3_long():
+    """truth_c3_long.npz (100 chunks at x1e-2 tolerances) is the same trajectory as truth_c3_mid.npz (30 chunks at x1e-3), which
+    c3_mid() checks against Radau at 5 and 10 ms: stored here are its deviation from the mid truth at their common save points
+    (10, 20, 30 ms) and, at 10 ms, the bound on its deviation from the Radau state that the triangle inequality gives
+    (|long - mid| + |mid - Radau|, maxima over the species). No integration is run."""
+    path = os.path.join(HERE, "truth_c3_long.npz")
+    lg, md = np.load(path), np.load(os.path.join(HERE, "truth_c3_mid.npz"))
+    assert "self_check_independent" in md.files, "run c3_mid first"
+    common = [t for t in lg["t"] if t > 0 and np.abs(md["t"] - t).min() < 1e-12]
+    dev = [float(units(lg["u"][int(np.argmin(np.abs(lg["t"] - t)))], md["u"][int(np.argmin(np.abs(md["t"] - t)))]).max()) for t in common]
+    at10 = dev[0] + float(md["self_check_independent"])
+    print(f"c3_long: against truth_c3_mid at t = {common}: {dev} units; at 10 ms at most {at10:.2f} units from the Radau state", flush=True)
+    update(path, self_check_vs_c3_mid=np.asarray(dev), self_check_vs_c3_mid_points=np.asarray(common), self_check_independent=at10,
+           independent_method="bound at t = 10 ms: |truth_c3_long - truth_c3_mid| + |truth_c3_mid - scipy Radau| (make_truth_independent.py c3_mid), maxima over the species")
+
+
 if __name__ == "__main__":
     for name in sys.argv[1:] or ["c3", "c4"]:
-        {"c3": c3, "c4": c4, "c3_mid": c3_mid, "c4_long": c4_long, "c5": c5}[name]()
+        {"c3": c3, "c4": c4, "c3_mid": c3_mid, "c4_long": c4_long, "c5": c5, "c3_long": c3_long}[name]()

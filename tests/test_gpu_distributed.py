@@ -117,6 +117,8 @@ def test_bench_two_ranks_on_one_card_end_to_end():
     assert rec["value"] > 0 and rec["unit"] == "RHS evals/s" and rec["dtype"] == "f64"
     assert rec["solve_network"]["replicas"] == 2 and rec["solve_network"]["retcode"] == 0
     assert rec["single_trajectory_rhs_allreduce"]["ranks"] == 2
+    ens = rec["ensemble_sharded_by_members"]       # 64 members per rank, one kin_solve_ensemble launch each, rows all-gathered
+    assert ens["members"] == 128 and ens["all_ok"] and ens["rows_gathered"] == [128, 300] and ens["solves_per_s"] > 0
     # a world size that contradicts --gpus is refused before any GPU work
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-pmc"],
                          env=dict(os.environ, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
@@ -143,3 +145,26 @@ def test_bench_four_ranks_rehearsal_reports_who_took_part():
     assert who["backend"] == "gloo" and who["world_size"] == 4 and sorted(m["rank"] for m in who["members"]) == [0, 1, 2, 3]
     assert rec["solve_network"]["replicas"] == 4 and rec["solve_network"]["retcode"] == 0
     assert rec["single_trajectory_rhs_allreduce"]["ranks"] == 4
+    assert rec["ensemble_sharded_by_members"]["members"] == 256 and rec["ensemble_sharded_by_members"]["all_ok"]
+    assert list(rec)[-1] == "roofline" and list(rec)[-2] == "solve_network_summary"      # what the driver keeps ends the line
+    assert rec["solve_network_summary"]["gpu_wall_s"] > 0
+
+
+def test_bench_six_ranks_rehearsal():
+    """As many ranks as the test box allows on its one card (six GPU processes; the driver's N = 8 run needs a node): the same
+    checks at world size 6."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SINGLE_DEVICE="1", BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "6", "--species", "1000", "--reactions", "5000",
+                        "--batch", "64", "--steps", "3", "--warmup", "1", "--solve-chunks", "2", "--no-cpu", "--no-pmc", "--no-tiled",
+                        "--sustain-seconds", "0", "--spinup-seconds", "0", "--replicas", ""], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 6 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["ranks"]["world_size"] == 6 and sorted(m["rank"] for m in rec["ranks"]["members"]) == list(range(6))
+    assert rec["solve_network"]["replicas"] == 6 and rec["solve_network"]["retcode"] == 0
+    assert rec["ensemble_sharded_by_members"]["members"] == 384 and rec["ensemble_sharded_by_members"]["all_ok"]

@@ -41,11 +41,16 @@ def _tiled_k(h, U, K):
     _sync()
     h.rhs_tiled_dev(B, d_ul.data_ptr(), d_dul.data_ptr(), d_k_lib=d_kl.data_ptr())
     h.states_from_lib_dev(B, d_dul.data_ptr(), d_du.data_ptr())
+    # the same through the drop-in entry: states in the caller's order, rate constants in slot order (kin_rhs_batched_klib_dev)
+    d_du2 = torch.full_like(d_u, float("nan"))
+    _sync()
+    h.rhs_batched_klib_dev(B, d_u.data_ptr(), d_kl.data_ptr(), d_du2.data_ptr())
     torch.cuda.synchronize()
     # the conversions are permutations: checked against the layout the library reports
     assert np.array_equal(d_ul.cpu().numpy(), U[:, lay["species_of_lib"]])
     kl = np.zeros((B, lay["k_len"])); kl[:, lay["slot_of_reaction"]] = K
     assert np.array_equal(d_kl.cpu().numpy(), kl)
+    lay["du_klib"] = d_du2.cpu().numpy()
     return d_du.cpu().numpy(), lay
 
 
@@ -71,6 +76,7 @@ def test_k_stream_form_matches_oracle(n, r, B):
     du, lay = _tiled_k(h, U, K)
     assert lay["identity"] and lay["windows"] == 1
     _check_against_oracle(net, du, U, K, range(B))
+    _check_against_oracle(net, lay["du_klib"], U, K, range(B))      # kin_rhs_batched_klib_dev
     h.close()
 
 
@@ -84,6 +90,7 @@ def test_windows_on_a_small_network(monkeypatch):
     du, lay = _tiled_k(h, U, K)
     assert lay["windows"] > 1 and not lay["identity"]
     _check_against_oracle(net, du, U, K, [0, 1, 17, 255, 256, 299])
+    _check_against_oracle(net, lay["du_klib"], U, K, [0, 1, 17, 255, 256, 299])      # kin_rhs_batched_klib_dev
     # temperature form on the same layout, caller-order entry point (converts on the way in and out)
     h.set_arrhenius(Ea, A, k_max=1e12)
     T = np.linspace(500.0, 1200.0, B)
@@ -111,6 +118,7 @@ def test_special_stoichiometries_and_unpaired_reactions():
     du, lay = _tiled_k(h, U, K)
     assert lay["records"] == 7
     _check_against_oracle(net, du, U, K, range(5))
+    _check_against_oracle(net, lay["du_klib"], U, K, range(5))      # kin_rhs_batched_klib_dev
     h.close()
 
 
@@ -244,6 +252,18 @@ def test_full_size_c3_elementwise_and_c5_tiled_sweep():
             assert np.all(err <= tol), (n, b, err.max())
             # mass conservation (the synthetic CRN conserves sum m_i u_i)
             assert abs(du[b] @ net.mass) <= 1e-12 * (on.abs_rhs(k, U[b]) @ net.mass)
+        # the drop-in entry on the same states in the CALLER's species order (kin_rhs_batched_klib_dev: at C5 the species permutation
+        # goes through LDS on the way in and out), against the library-order call
+        d_uc, d_duc = _dev(U), torch.full((B, n), float("nan"), dtype=torch.float64, device="cuda")
+        _sync()
+        h.rhs_batched_klib_dev(B, d_uc.data_ptr(), d_kl.data_ptr(), d_duc.data_ptr())
+        torch.cuda.synchronize()
+        duc = d_duc.cpu().numpy()
+        assert np.all(np.isfinite(duc))
+        for b in sample:
+            k = kl[b][lay["slot_of_reaction"]]
+            assert np.all(np.abs(duc[b] - du[b]) <= 4e-13 * on.abs_rhs(k, U[b]) + 1e-300), (n, b)
+        del d_uc, d_duc
         # linearity in k: doubling k doubles du exactly (power of two)
         d_k2 = d_kl * 2.0
         d_du2 = torch.empty_like(d_dul)
@@ -289,6 +309,7 @@ def test_one_slot_records_after_the_low_k_cutoff(monkeypatch, n, entries):
     assert R2 <= lay["k_len"] < R2 + 130 * lay["windows"] and lay["k_len"] < 2 * lay["records"]
     assert (lay["windows"] > 1) == bool(entries)
     _check_against_oracle(net, du, U, K, range(B))
+    _check_against_oracle(net, lay["du_klib"], U, K, range(B))      # kin_rhs_batched_klib_dev
     # rate table in library order = the plain table, permuted; the sweep fed with it against the temperature form
     h.set_arrhenius(Ea, A, k_max=1e12)
     T = np.linspace(600.0, 1400.0, B)

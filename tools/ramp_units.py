@@ -1,5 +1,5 @@
 """Deviation of the C4 / C5 ramp prefixes from their committed truths, in tolerance units (what tests/test_gpu_configs.py bounds).
-Usage: [KIN_WARM_RESTART=1] python tools/ramp_units.py [c4] [c5]"""
+Usage: python tools/ramp_units.py [c4] [c5]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,7 +24,7 @@ for name in (sys.argv[1:] or ["c4", "c5"]):
     t, u, rc, st, _ = h.solve(p, u0, tstops=z["tstops"], T_stops=z["T_stops"])
     sel = np.searchsorted(t, z["t"])
     e = units(u[sel], z["u"])
-    print(json.dumps({"config": name, "warm": os.environ.get("KIN_WARM_RESTART"), "rc": rc, "max_units": float(e.max()),
+    print(json.dumps({"config": name, "rc": rc, "max_units": float(e.max()),
                       "rms_units": float(np.sqrt((e ** 2).mean(axis=1)).max()), "steps": st["n_steps"], "factor": st["n_factor"],
                       "retries": st["n_retries"], "wall_s": st["wall_seconds"]}), flush=True)
     h.close()

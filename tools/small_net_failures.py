@@ -11,7 +11,7 @@ from kinetica_jl_amd.synth import synthetic_crn
 VARIANTS = (("resident", {"KIN_RESIDENT": "1"}), ("host", {"KIN_RESIDENT": "0"}), ("host, update not fused", {"KIN_RESIDENT": "0", "KIN_FUSE_NEWTON": "0"}),
             ("host, no speculation", {"KIN_RESIDENT": "0", "KIN_SPECULATE": "0"}), ("host, neither", {"KIN_RESIDENT": "0", "KIN_SPECULATE": "0", "KIN_FUSE_NEWTON": "0"}),
             ("host, no fast sync", {"KIN_RESIDENT": "0", "KIN_NO_FAST_SYNC": "1"}), ("host, no LU cache", {"KIN_RESIDENT": "0", "KIN_LU_BAND": "0"}),
-            ("host, no carried rate", {"KIN_RESIDENT": "0", "KIN_CARRY_RATE": "0"}), ("host, plain substitution", {"KIN_RESIDENT": "0", "KIN_LU_EXPLICIT": "0"}))
+            ("host, plain substitution", {"KIN_RESIDENT": "0", "KIN_LU_EXPLICIT": "0"}))
 if len(sys.argv) == 1:          # the switches are read once per process: one child per variant
     for name, env in VARIANTS:
         subprocess.run([sys.executable, os.path.abspath(__file__), name], env=dict(os.environ, **env), check=False)
