@@ -242,7 +242,8 @@ int kin_solve(kin_network* h, const kin_params* params, const double* u0,
  *   (the handle's current rates for all); discrete rate updates (tstops / T_stops / k_table as in kin_solve) are shared
  *   by all members and exclude k / T. `params` needs a save grid (solve_chunks or save_interval).
  * Outputs (any may be NULL): *n_rows = rows of the save grid; out_t[n_rows]; out_u[K][n_rows][N]; n_saved[K] rows a member
- * actually wrote; retcodes[K] (KIN_RETCODE_*); stats[K]. A call with out_u == NULL and n_saved == NULL only reports *n_rows.
+ * actually wrote (the rows of out_u beyond them - a member that failed early - are zero); retcodes[K] (KIN_RETCODE_*); stats[K].
+ * A call with out_u == NULL and n_saved == NULL only reports *n_rows.
  * Returns KIN_OK when the call ran, whatever the members' retcodes; KIN_ERR_UNSUPPORTED for a network that fits neither
  * path (too large for the resident kernel and without a dense Schur block): solve those member by member with kin_solve. */
 int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, const double* u0, const double* k, const double* T,

@@ -447,6 +447,7 @@ void replica_ensemble(kin_network* h, const kin_params& p, int64_t K, const doub
           const int64_t ns = std::min<int64_t>(c->n_saved, cap);
           if (n_saved) n_saved[m] = ns;
           if (out_u && ns > 0) c->d_sol_u.download(out_u + (size_t)m * cap * N, (size_t)ns * N, s);
+          if (out_u && ns < cap) std::memset(out_u + ((size_t)m * cap + (size_t)ns) * N, 0, (size_t)(cap - ns) * N * sizeof(double));   // rows a failed member never wrote
           KIN_HIP(hipStreamSynchronize(s));
           if (out_t) {
             std::lock_guard<std::mutex> lock(grid_mu);

@@ -101,7 +101,11 @@ struct ResidentSolver {
       K_cap = K; n_slots = slots;
     }
     d_solt.alloc((size_t)K * (size_t)sol_rows);
-    if (own_sol) d_sol.alloc((size_t)K * (size_t)sol_rows * N);
+    if (own_sol) {
+      d_sol.alloc((size_t)K * (size_t)sol_rows * N);
+      // rows beyond a member's n_saved (a member that failed early) read as zeros in out_u
+      KIN_HIP(hipMemsetAsync(d_sol.p, 0, (size_t)K * (size_t)sol_rows * N * sizeof(double), s));
+    }
     h_traj.assign(K, ResTrajDev{});
     for (int t = 0; t < K; t++) {
       ResTrajDev& q = h_traj[t];

@@ -1,7 +1,9 @@
 """Writes the "Numbers" block of DESIGN.md (between the numbers:begin / numbers:end markers) from the files under profiles/.
 Every row names the file (and key) it comes from; tests/test_docs_numbers.py runs this script in check mode and fails when the
 block in DESIGN.md differs from what the files give.
-Usage: python tools/design_numbers.py [--check] [--round r04]"""
+A file is taken from the current round (`r05_<name>`) when it exists, else from the last round that measured it (`r04_<name>`:
+kernels and probes this round did not touch); the source column names the file that was read.
+Usage: python tools/design_numbers.py [--check] [--round r05]"""
 import csv
 import json
 import os
@@ -9,10 +11,19 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r04"
+TAG = "r05"
+PREV = "r04"
 if "--round" in sys.argv:
     TAG = sys.argv[sys.argv.index("--round") + 1]
 P = os.path.join(ROOT, "profiles")
+
+
+def pick(name):
+    """file name under profiles/ for `name`: this round's if it exists, else the previous round's"""
+    for tag in (TAG, PREV):
+        if os.path.exists(os.path.join(P, f"{tag}_{name}")):
+            return f"{tag}_{name}"
+    raise FileNotFoundError(name)
 
 
 def load(name):
@@ -36,20 +47,20 @@ def build():
     def add(group, what, value, source):
         rows.append((group, what, value, source))
 
-    b = load(f"{TAG}_bench_default.json")
-    src_b = f"{TAG}_bench_default.json"
+    b = load(pick("bench_default.json"))
+    src_b = pick("bench_default.json")
     rf = b["roofline"]
     add("headline sweep", "`sweep_reg_kernel`, B = 4096, 10k / 50k: launch (bench HIP events, after 1 s spin-up)",
         f"{rf['avg_launch_ms']:.4f} ms = {rf['achieved']:.0f} GB/s = **{rf['frac']:.3f} of 8 TB/s**", f"{src_b} `roofline`")
     add("headline sweep", "RHS evaluations per second (`value`)", f"{b['value'] / 1e6:.2f} M/s", f"{src_b} `value`")
     add("headline sweep", "HBM traffic (PMC, same run) / algorithmic bytes", f"{rf['traffic_over_algorithmic']:.3f}", f"{src_b} `roofline.traffic_over_algorithmic`")
-    pm = load(f"{TAG}_sweep_pmc.json")
+    pm = load(pick("sweep_pmc.json"))
     add("headline sweep", f"rocprofv3 average over {pm['calls']} launches (spin-up + timed + sustained)",
-        f"{pm['avg_ns_rocprof'] / 1e3:.1f} µs (bench events in that run {pm['avg_launch_ms_bench_events'] * 1e3:.1f} µs)", f"{TAG}_sweep_pmc.json")
+        f"{pm['avg_ns_rocprof'] / 1e3:.1f} µs (bench events in that run {pm['avg_launch_ms_bench_events'] * 1e3:.1f} µs)", pick("sweep_pmc.json"))
     tl = pm["timed_launches_only"]
     add("headline sweep", f"cold clocks: rocprofv3 average over the {tl['calls']} warm-up + timed launches, no spin-up",
-        f"{tl['avg_ns_rocprof'] / 1e3:.1f} µs = {pm['algorithmic_bytes_per_launch'] / tl['avg_ns_rocprof'] / 8000:.3f}", f"{TAG}_sweep_pmc.json `timed_launches_only`")
-    add("headline sweep", "PMC: (2 × FETCH_SIZE + WRITE_SIZE) KiB / algorithmic", f"{pm['traffic_over_algorithmic']:.3f}", f"{TAG}_sweep_pmc.json")
+        f"{tl['avg_ns_rocprof'] / 1e3:.1f} µs = {pm['algorithmic_bytes_per_launch'] / tl['avg_ns_rocprof'] / 8000:.3f}", pick("sweep_pmc.json") + " `timed_launches_only`")
+    add("headline sweep", "PMC: (2 × FETCH_SIZE + WRITE_SIZE) KiB / algorithmic", f"{pm['traffic_over_algorithmic']:.3f}", pick("sweep_pmc.json"))
     add("headline sweep", "CPU port, oracle RHS, 1 core", f"{b['cpu_baseline']['value']:.0f} evals/s", f"{src_b} `cpu_baseline`")
 
     ts = b["tiled_sweep"]
@@ -64,18 +75,18 @@ def build():
             f"{pc['callers_layouts']['ms']:.3f} ms = {pc['callers_layouts']['frac_of_8TBps']:.3f} / {pc['library_order']['ms']:.3f} ms = {pc['library_order']['frac_of_8TBps']:.3f} of 8 TB/s",
             f"{src_b} `post_cutoff_sweep`")
     for cfg in ("c3", "c5"):
-        dv = load(f"{TAG}_{cfg}_tiled_pmc.json")["derived"]
+        dv = load(pick(f"{cfg}_tiled_pmc.json"))["derived"]
         bc, ac = dv["lds_bank_conflict_cycles"], dv["lds_active_cycles"]
         add("tiled sweep", f"{cfg.upper()} k-stream under rocprofv3: PMC traffic / algorithmic; LDS bank-conflict cycles per launch, plain order → bank-aware inside chunks of 64 records (default) → from a reservoir of 256; LDS-active cycles",
             f"{dv['k_stream_traffic_over_algorithmic']:.3f}; {bc[0] / 1e6:.0f} M → {bc[1] / 1e6:.0f} M → {bc[2] / 1e6:.0f} M; "
-            f"{ac[0] / 1e6:.0f} M → {ac[1] / 1e6:.0f} M → {ac[2] / 1e6:.0f} M", f"{TAG}_{cfg}_tiled_pmc.json `derived`")
+            f"{ac[0] / 1e6:.0f} M → {ac[1] / 1e6:.0f} M → {ac[2] / 1e6:.0f} M", pick(f"{cfg}_tiled_pmc.json") + " `derived`")
 
-    ct = load(f"{TAG}_c5_table_pmc.json")
+    ct = load(pick("c5_table_pmc.json"))
     for kr in ct["kernels"]:
         name = kr["kernel"].split("::")[-1]
         add("rate table" if "rate_table" in name else "caller's-layout sweep at C5", f"`{name}`: rocprofv3 average over {kr['calls']} launches",
             f"{kr['avg_ns_rocprof'] / 1e6:.3f} ms = {kr['achieved_GBps']:.0f} GB/s = {kr['frac_of_8TBps']:.3f}, traffic {kr['traffic_over_algorithmic']:.2f}× algorithmic",
-            f"{TAG}_c5_table_pmc.json")
+            pick("c5_table_pmc.json"))
 
     sn = b["solve_network"]
     add("C3 solve", "100 chunks (0, 0.1) s: warm / cold (handle creation + analysis + first solve)",
@@ -119,11 +130,11 @@ def build():
     v = c4["vs_truth_in_tolerance_units"]
     add("C4 prefix", "first 20 chunks (200 restarts): wall, steps, factorisations", f"{c4['wall_s']:.2f} s, {c4['stats']['n_steps']}, {c4['stats']['n_factor']}", f"{src_b} `configs.C4_prefix`")
     add("C4 prefix", "... against `truth_c4_long.npz`: max / rms / p99.9 units (truth self-check)", f"{v['max']:.0f} / {v['rms']:.1f} / {v['p99.9']:.1f} ({v['truth_self_check']:.1f})", src_b)
-    pth = os.path.join(P, f"{TAG}_c4_full_run.json")
-    if os.path.exists(pth):
+    pth = os.path.join(P, pick("c4_full_run.json"))
+    if True:
         c4f = json.load(open(pth))
         add("C4 prefix", "the whole 14 s ramp (tools/run_configs.py c4, C4_TEND=14): wall, steps, factorisations, restarts, retries",
-            f"{c4f['wall_s']:.1f} s, {c4f['stats']['n_steps']}, {c4f['stats']['n_factor']}, {c4f['stats']['n_restarts']}, {c4f['stats']['n_retries']} (retcode {c4f['retcode']})", f"{TAG}_c4_full_run.json")
+            f"{c4f['wall_s']:.1f} s, {c4f['stats']['n_steps']}, {c4f['stats']['n_factor']}, {c4f['stats']['n_restarts']}, {c4f['stats']['n_retries']} (retcode {c4f['retcode']})", pick("c4_full_run.json"))
     c5 = cf["C5_static"]
     add("configurations", "C5 static, 5 chunks: warm / cold, dense block", f"{c5['wall_s']:.2f} s / {c5['cold_wall_s_incl_create_and_analysis']:.2f} s, {c5['dense_block']}", f"{src_b} `configs.C5_static`")
 
@@ -144,68 +155,83 @@ def build():
         if isinstance(e, dict) and "solves_per_s" in e:
             add("ensemble, lockstep", f"for comparison, round 3's K handles on K host threads, K = {k_} (2 chunks of C3)", f"{e['solves_per_s']:.1f} solves/s", f"{src_b} `concurrent_replicas`")
 
-    path = os.path.join(P, f"{TAG}_ensemble_resident_scaling.jsonl")
+    path = os.path.join(P, pick("ensemble_resident_scaling.jsonl"))
     if os.path.exists(path):
-        for r in jsonl(f"{TAG}_ensemble_resident_scaling.jsonl"):
+        for r in jsonl(pick("ensemble_resident_scaling.jsonl")):
             if r["species"] == 1000 or r["K"] == 1024:
                 add("ensemble, one launch", f"scaling probe: {r['species']} species, K = {r['K']}, members at {r['T']}",
                     f"{r['solves_per_s']:.0f} solves/s (steps mean {r['steps_mean']:.0f} / slowest {r['steps_max']}, {r['slots']} cache slots per member)",
-                    f"{TAG}_ensemble_resident_scaling.jsonl")
-    path = os.path.join(P, f"{TAG}_resident_vs_host.jsonl")
+                    pick("ensemble_resident_scaling.jsonl"))
+    path = os.path.join(P, pick("resident_vs_host.jsonl"))
     if os.path.exists(path):
-        for r in jsonl(f"{TAG}_resident_vs_host.jsonl"):
+        for r in jsonl(pick("resident_vs_host.jsonl")):
             add("resident vs host-driven", f"{r['species']} species (dense block {r['dense_block']}), 20 chunks: resident / host-driven",
-                f"{r['resident_s']:.3f} s / {r['host_driven_s']:.3f} s = {r['host_over_resident']:.2f}×", f"{TAG}_resident_vs_host.jsonl")
+                f"{r['resident_s']:.3f} s / {r['host_driven_s']:.3f} s = {r['host_over_resident']:.2f}×", pick("resident_vs_host.jsonl"))
 
-    calls, avg, pct = kernel_row(f"{TAG}_solve_kernel_stats.csv", "gj_update_kernel")
-    add("solve kernel time", "C3 20 chunks: `gj_update_kernel` share of kernel time, average launch", f"{pct:.1f} %, {avg:.2f} µs × {calls}", f"{TAG}_solve_kernel_stats.csv")
+    calls, avg, pct = kernel_row(pick("solve_kernel_stats.csv"), "gj_update_kernel")
+    add("solve kernel time", "C3 20 chunks: `gj_update_kernel` share of kernel time, average launch", f"{pct:.1f} %, {avg:.2f} µs × {calls}", pick("solve_kernel_stats.csv"))
     for needle, label in (("bdf_newton_kernel", "corrector update + decision"), ("segsum_kernel<4, 1024>", "solve stage A gather"), ("segsum_kernel<2, 1024>", "Newton residual gather"),
                           ("segsum_kernel<5, 256>", "solve stage C gather"), ("gemv_kernel", "dense GEMV"), ("rates_skip_kernel", "rates")):
         try:
-            calls, avg, pct = kernel_row(f"{TAG}_solve_kernel_stats.csv", needle)
-            add("solve kernel time", f"... {label} (`{needle}`)", f"{pct:.1f} %, {avg:.2f} µs", f"{TAG}_solve_kernel_stats.csv")
+            calls, avg, pct = kernel_row(pick("solve_kernel_stats.csv"), needle)
+            add("solve kernel time", f"... {label} (`{needle}`)", f"{pct:.1f} %, {avg:.2f} µs", pick("solve_kernel_stats.csv"))
         except IndexError:
             pass
-    gj = open(os.path.join(P, f"{TAG}_gj_probe_batched.txt")).read()
+    gj = open(os.path.join(P, pick("gj_probe_batched.txt"))).read()
     m = re.search(r"m=(\d+)\s+GJ mean ([\d.]+) us\s+best ([\d.]+) us\s+\((\d+) launches\)", gj)
-    add("Gauss-Jordan", f"dense inverse alone, m = {m.group(1)} ({m.group(4)} launches), HIP events", f"{m.group(2)} µs mean, {m.group(3)} µs best", f"{TAG}_gj_probe_batched.txt")
+    add("Gauss-Jordan", f"dense inverse alone, m = {m.group(1)} ({m.group(4)} launches), HIP events", f"{m.group(2)} µs mean, {m.group(3)} µs best", pick("gj_probe_batched.txt"))
     for mm in re.finditer(r"batched n=\s*(\d+): mean ([\d.]+) us\s+best ([\d.]+) us\s+= ([\d.]+) us per matrix, results (.*)", gj):
         if mm.group(1) in ("4", "8", "16"):
-            add("Gauss-Jordan", f"batched chain, {mm.group(1)} matrices per launch", f"{mm.group(4)} µs per matrix ({mm.group(5).strip()})", f"{TAG}_gj_probe_batched.txt")
-    db = load(f"{TAG}_dense_block_options.json")["rows"]
+            add("Gauss-Jordan", f"batched chain, {mm.group(1)} matrices per launch", f"{mm.group(4)} µs per matrix ({mm.group(5).strip()})", pick("gj_probe_batched.txt"))
+    db = load(pick("dense_block_options.json"))["rows"]
     ms = [r["dense_block"] for r in db if "dense_block" in r]
-    add("Gauss-Jordan", f"dense block at C3 over {len(ms)} elimination option sets (configured: {db[0]['dense_block']})", f"{min(ms)} ... {max(ms)}", f"{TAG}_dense_block_options.json")
+    add("Gauss-Jordan", f"dense block at C3 over {len(ms)} elimination option sets (configured: {db[0]['dense_block']})", f"{min(ms)} ... {max(ms)}", pick("dense_block_options.json"))
 
-    ph = open(os.path.join(P, f"{TAG}_resident_phase_300.txt")).read()
+    ph = open(os.path.join(P, pick("resident_phase_300.txt"))).read()
     head = re.search(r"N=(\d+) m=(\d+) slots=\d+ steps=(\d+) factor=(\d+) linsolve=(\d+) wall ([\d.]+) s", ph)
 
     def phase(label):
         return float(re.search(re.escape(label) + r"\s+([\d.]+) ms", ph).group(1))
     add("resident phases", f"{head.group(1)} species, 20 chunks: {head.group(3)} steps, {head.group(4)} factorisations, {head.group(5)} solves",
-        f"kernel {phase('kernel'):.1f} ms = {1e3 * phase('kernel') / int(head.group(3)):.0f} µs per step", f"{TAG}_resident_phase_300.txt")
+        f"kernel {phase('kernel'):.1f} ms = {1e3 * phase('kernel') / int(head.group(3)):.0f} µs per step", pick("resident_phase_300.txt"))
     add("resident phases", "... factorisations (of which dense inverse) / corrector attempts (of which solves)",
-        f"{phase('factor'):.1f} ({phase('(of which dense inverse)'):.1f}) / {phase('corrector attempts'):.1f} ({phase('(solve)'):.1f}) ms", f"{TAG}_resident_phase_300.txt")
-    wl = open(os.path.join(P, f"{TAG}_wg_latency_probe.txt")).read().split("grid = 256")[0]
-    pick = {}
+        f"{phase('factor'):.1f} ({phase('(of which dense inverse)'):.1f}) / {phase('corrector attempts'):.1f} ({phase('(solve)'):.1f}) ms", pick("resident_phase_300.txt"))
+    wl = open(os.path.join(P, pick("wg_latency_probe.txt"))).read().split("grid = 256")[0]
+    lat = {}
     for l in wl.splitlines():
         mm = re.match(r"\s+(.*?)\s{2,}([\d.]+) ns", l)
         if mm:
-            pick[mm.group(1)] = float(mm.group(2))
+            lat[mm.group(1)] = float(mm.group(2))
     add("resident phases", "in-workgroup latencies: barrier / dependent global load / LDS read / 5 wave sums DPP (bpermute) / hand-over LDS (global)",
-        f"{pick['barrier']:.0f} / {pick['dependent global load (idx chase)']:.0f} / {pick['dependent LDS read']:.0f} / {pick['5 wave sums (DPP)']:.0f} ({pick['5 wave sums (ds_bpermute)']:.0f}) / "
-        f"{pick['stage hand-over through LDS']:.0f} ({pick['stage hand-over through global memory (store, barrier, load, barrier)']:.0f}) ns", f"{TAG}_wg_latency_probe.txt")
+        f"{lat['barrier']:.0f} / {lat['dependent global load (idx chase)']:.0f} / {lat['dependent LDS read']:.0f} / {lat['5 wave sums (DPP)']:.0f} ({lat['5 wave sums (ds_bpermute)']:.0f}) / "
+        f"{lat['stage hand-over through LDS']:.0f} ({lat['stage hand-over through global memory (store, barrier, load, barrier)']:.0f}) ns", pick("wg_latency_probe.txt"))
 
-    cfab = open(os.path.join(P, f"{TAG}_cf_rules_ab.txt")).read()
-    for tag, label in (("KIN_ETACF=0.5 KIN_CF_RESET=1 KIN_CF_GROWTH_CAP=0", "round 3's rules"), ("KIN_ETACF=0.25 KIN_CF_RESET=0 KIN_CF_GROWTH_CAP=0", "adopted (ETACF 0.25, no reset on corrector failures)")):
-        blk = cfab.split("=== " + tag)[-1].split("===")[0]          # the last run with these settings
-        mm = re.search(r"wall ([\d.]+) rc 0 \{'n_steps': (\d+), 'n_rejected': (\d+), 'n_factor': (\d+), 'n_newton_fail': (\d+)\}", blk)
-        sw = re.findall(r"sweep (wide2?): (\d+) solves, failures (\d+) retries (\d+)", blk)
-        sws = "; sweeps " + ", ".join(f"{a}: {c} failures / {d} retries of {b_}" for a, b_, c, d in sw) if sw else ""
-        add("convergence-failure rules", f"C3 over (0, 1) s as one integration, {label}", f"{mm.group(1)} s, {mm.group(2)} steps, {mm.group(5)} corrector failures, {mm.group(4)} factorisations{sws}", f"{TAG}_cf_rules_ab.txt")
-
-    rd = jsonl(f"{TAG}_ramp_diag.jsonl")
-    lo, hi = min(r["max_units"] for r in rd), max(r["max_units"] for r in rd)
-    add("C4 prefix", f"3-chunk prefix under {len(rd)} solver-switch variants (tools/ramp_diag.py): max units", f"{lo:.0f} ... {hi:.0f} (default {rd[0]['max_units']:.0f}, p99.9 {rd[0]['p999']:.1f})", f"{TAG}_ramp_diag.jsonl")
+    # ---- round 5
+    dc5, dcut = load(pick("c5_dropin_pmc.json")), load(pick("cut_dropin_pmc.json"))
+    for d, label, src in ((dc5, "C5 (50000 / 250000, B = 1024)", pick("c5_dropin_pmc.json")), (dcut, "post-cutoff C3 network (35000 reactions, B = 4096)", pick("cut_dropin_pmc.json"))):
+        t = d["timing_hip_events"]
+        add("drop-in sweep", f"`kin_rhs_batched_klib_dev` (caller's species order, k in slot order), {label}: call (HIP events); HBM traffic (PMC) / algorithmic",
+            f"{t['ms_per_call']:.3f} ms = {t['frac_of_8TBps']:.3f} of 8 TB/s; {d['traffic_over_algorithmic']:.2f}", src)
+    ks = dc5["kernel_stats"]
+    perm = [v["avg_ns"] / 1e3 for k_, v in ks.items() if "permute_staged_kernel" in k_]
+    tile = [v["avg_ns"] / 1e3 for k_, v in ks.items() if "tiled_sweep_kernel" in k_]
+    add("drop-in sweep", "... its kernels at C5 under rocprofv3: species permutation in / tiled sweep / permutation out", f"{max(perm):.0f} / {tile[0]:.0f} / {min(perm):.0f} µs", pick("c5_dropin_pmc.json") + " `kernel_stats`")
+    cs = jsonl(pick("config_stats.jsonl"))
+    for case, label in (("c3_long_chunkwise", "C3 100 chunks as the reference runs them"), ("c3_long_complete", "... as ONE integration"), ("c3_long_warm", "... warm chunk starts (extension)"),
+                        ("c3_long_x0.1", "... 10× tighter tolerances (default units)"), ("c4_long_default", "C4 ramp, 20 chunks"), ("c5_default", "C5 ramp, 2 chunks")):
+        rr = [r for r in cs if r["case"] == case]
+        f3 = lambda key: " / ".join(f"{r[key]:g}" for r in rr)
+        add("parity statistics", f"{label}: rms; p99.9; 50 major species; max over all (reuse band 0.32 / 0.35 / 0.38)", f"{f3('rms')}; {f3('p999')}; {f3('major')}; {f3('max')}", pick("config_stats.jsonl"))
+    tt = jsonl(pick("tight_tol_truth.jsonl"))[-1]
+    add("tight tolerances", "200 species at rtol 1e-10 against a Radau truth, tight units rms / max (steps, corrector failures): CPU port; resident; host-driven",
+        "; ".join(f"{tt[k_]['rms_units']:.0f} / {tt[k_]['max_units']:.0f} ({tt[k_]['steps']}, {tt[k_]['fail']})" for k_ in ("cpu_port_tight", "resident_tight", "host_driven_tight")), pick("tight_tol_truth.jsonl"))
+    g2 = open(os.path.join(P, pick("gj_two_step_probe.txt"))).read()
+    m1 = re.search(r"one-step chain: mean ([\d.]+) us.*\n.*two-step chain: mean ([\d.]+) us", g2)
+    add("Gauss-Jordan", "two block steps per launch (round 5, not adopted; bit-identical inverse), m = 1024: one-step / two-step chain", f"{m1.group(1)} / {m1.group(2)} µs", pick("gj_two_step_probe.txt"))
+    sm = open(os.path.join(P, pick("switch_matrix.txt"))).read()
+    runs = re.findall(r"^== (\S+): (.*)$", sm, flags=re.M)
+    clean = sum(1 for _, r_ in runs if "failed" not in r_)
+    add("switches", f"solve tests (46) under each of {len(runs)} non-default switch values: values with every test green / with tests that assert default-route properties failing", f"{clean} / {len(runs) - clean}", pick("switch_matrix.txt"))
 
     rk = b.get("ranks", {})
     add("multi-GPU", "ranks that took part in the committed bench line", f"world size {rk.get('world_size')}, backend {rk.get('backend')}; no scaling curve measured", f"{src_b} `ranks`")
