@@ -222,6 +222,31 @@ def c3_long():
            independent_method="bound at t = 10 ms: |truth_c3_long - truth_c3_mid| + |truth_c3_mid - scipy Radau| (make_truth_independent.py c3_mid), maxima over the species")
 
 
+def c3_long_direct():
+    """truth_c3_long.npz against ONE Radau integration from t = 0 to 0.1 s (tolerances x1e-2, corrector tolerance 0.03: see c3()),
+    at every stored chunk end - the direct form of what c3_long() bounds through truth_c3_mid. Hours on one core."""
+    path = os.path.join(HERE, "truth_c3_long.npz")
+    tr = np.load(path)
+    global TIGHT
+    TIGHT = float(os.environ.get("INDEP_TIGHT", "1e-2"))
+    net, Ea, A = synthetic_crn(10000, 50000)
+    on = orc.OracleNetwork.from_flat(net)
+    k = orc.arrhenius(Ea, A, float(tr["T"]), k_max=1e12)
+    u0 = np.zeros(10000); u0[0] = 1.0
+    t0 = time.time()
+    t_eval = tr["t"][1:]
+    u, nfev, njev, nlu = radau(on, k, u0, 0.0, float(t_eval[-1]), t_eval, newton_tol=0.03)
+    dev = units(u, tr["u"][1:])
+    per = [float(x) for x in dev.max(axis=1)]
+    print(f"c3_long: Radau {nfev} rhs, {njev} jac, {nlu} lu, {time.time() - t0:.0f} s; deviation from the stored truth per chunk end {per}, rms {np.sqrt((dev ** 2).mean()):.4f}", flush=True)
+    if os.environ.get("INDEP_DUMP"):
+        np.savez_compressed(os.environ["INDEP_DUMP"], t=t_eval, u=u)
+    update(path, self_check_independent=float(dev.max()), self_check_independent_rms=float(np.sqrt((dev ** 2).mean())),
+           self_check_independent_per_point=np.asarray(per), independent_points=np.asarray(t_eval),
+           independent_method=f"scipy Radau (SuperLU, MMD ordering), oracle rhs + analytic sparse Jacobian, rtol {RELTOL * TIGHT:g}, "
+                              f"atol {ABSTOL * TIGHT:g}, corrector tolerance 0.03, one integration from t = 0 over all 100 ms")
+
+
 if __name__ == "__main__":
     for name in sys.argv[1:] or ["c3", "c4"]:
-        {"c3": c3, "c4": c4, "c3_mid": c3_mid, "c4_long": c4_long, "c5": c5, "c3_long": c3_long}[name]()
+        {"c3": c3, "c4": c4, "c3_mid": c3_mid, "c4_long": c4_long, "c5": c5, "c3_long": c3_long, "c3_long_direct": c3_long_direct}[name]()
