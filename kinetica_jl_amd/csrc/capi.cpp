@@ -492,9 +492,7 @@ int kin_solve_ensemble(kin_network* h, const kin_params* params, int64_t K, cons
     else if (!force_batched && resident_ensemble_route(h, K))
       resident_ensemble(h, *params, K, u0, k, T, tstops, T_stops, k_table, n_stops, n_rows, out_t, out_u, n_saved, retcodes, stats);
     // few members of a network too large for a compute unit: kin_solve calls on host threads, one member per thread up to the
-    // thread limit (KIN_ENSEMBLE_THREADS_K raises the member count that takes this route: the threads then take several
-    // members each - measured, profiles/r04_ensemble_route_crossover.jsonl: from 16 members on the lockstep rounds are ahead
-    // at 3 000 and 10 000 species)
+    // thread limit (beyond it the lockstep rounds are ahead at 3 000 and 10 000 species: profiles/r04_ensemble_route_crossover.jsonl)
     // ... and ANY number of members when the lockstep form does not take the network's factorisation (it needs the fused solve
     // with a dense Schur block; KIN_LU_FUSED=0 or a network without hubs has none): the threads then take several members each
     else if (!force_batched && (K <= replica_members_max() || !ensemble_batched_supported(h, nullptr)))

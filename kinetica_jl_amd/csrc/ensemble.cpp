@@ -110,10 +110,9 @@ struct EnsembleSolver {
   DevBuf<double> gpinv;
   std::vector<hipEvent_t> pre_evs;      // per member: end of the sparse part
   int64_t g_batches = 0, g_matrices = 0;
-  // KIN_ENSEMBLE_FACTOR_SYNC=1: factorisations stay IN the round (sparse parts on the pool's streams next to the round's other
-  // launches, the dense inverses of all members that asked in this round as one batched chain behind them) instead of parking
-  // their members: the members stay in step with each other, every launch of a round carries all of them
-  int g_min = 4, g_wait_us = 200;       // hold-off: a batch starts with 4 requests or 200 us after its first (KIN_ENSEMBLE_GJ_MIN / _WAIT_US)
+  // (factorisations kept INSIDE the rounds - every launch of a round then carries all members - were built in round 4 and measured
+  // slower, profiles/r04_ensemble_factor_sync_ab.txt; that path is gone)
+  int g_min = 4, g_wait_us = 200;       // hold-off: a batch starts with 4 requests or 200 us after its first
   double t_enqueue = 0.0, t_sync = 0.0, t_round = 0.0;   // host seconds inside the rounds (KIN_TIMING=1)
   int64_t n_ops[16] = {};
 

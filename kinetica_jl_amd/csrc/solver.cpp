@@ -318,7 +318,7 @@ struct Solver {
       // CVODE's initial step (cvode.c: cvHin / cvUpperBoundH0 / cvYddNorm; resident_core.hpp restart() has the description),
       // rounded down to a power of ten: every restart's climb passes through the same step sizes, so the matrices of the
       // previous segment's climb are found in the LU cache again (C3, 100 chunks: 363 -> 269 factorisations in round 4's A/B,
-      // profiles/r04_h0_decade_ab.txt; the rms deviations from the truths do not move)
+      // profiles/r04_h0_decade_ab.txt - round 4's A/B of the grid as an opt-in; the rms deviations from the truths do not move)
       const double hlb = 100.0 * std::numeric_limits<double>::epsilon() * std::max(std::fabs(t0), std::fabs(t_bound));
       double hub = 0.1 * interval;
       if (hub * hc->scratch[3] > 1.0) hub = 1.0 / hc->scratch[3];
