@@ -557,7 +557,12 @@ def main():
                         "note": "rank r integrates members [64 r, 64 r + 64) in one kin_solve_ensemble launch; maxima + return codes all-gathered"}
             finally:
                 he.close()
-        leg = sharded_ensemble_leg()      # (not `guarded`: every rank must reach the same collectives)
+        # (every rank must reach the same collectives: a member launch that throws is absorbed inside `local` above; what is caught
+        # here is a failure every rank meets alike - a refused allocation, a shape the gather rejects - so that the line is still printed)
+        try:
+            leg = sharded_ensemble_leg()
+        except Exception as e:      # noqa: BLE001
+            leg = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["ensemble_sharded_by_members"] = leg
 
