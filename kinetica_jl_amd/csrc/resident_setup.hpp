@@ -58,7 +58,7 @@ inline void res_default_settings(ResParams& P, int n_slots_max) {
   // the constants of solver.cpp (Solver): reuse_rate_max, crate_dy_max, lu_drift_max, corrector tolerance, crate_max_age, lu_max_age
   P.reuse_rate_max = 0.15;
   P.crate_dy_max = 0.2;
-  P.lu_drift_max = 0.25;
+  P.lu_drift_max = 1.0;
   P.newton_frac = 0.03;
   P.crate_max_age = 10;
   P.lu_max_age = 50;

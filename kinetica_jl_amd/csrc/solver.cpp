@@ -432,12 +432,16 @@ struct Solver {
   // predictor; the full C4 ramp then ran into DtLessThanMin a few hundred restarts later (with 5 restarts it runs
   // through). CVODE bounds the same staleness by re-evaluating J at least every 50 steps.
   int64_t lu_max_age = 50;
-  // Drift guard (KIN_LU_DRIFT, default 0.25): at every restart the Jacobian is fresh; one kernel compares, for every slot,
-  // diag(I - c_s J) as it was when the slot was made with what today's Jacobian gives at the same c_s, and slots whose
-  // diagonal moved by more than 25 % (either way) are dropped. For mass-action kinetics a column's off-diagonal entries
-  // are bounded by its diagonal (a reactant's loss terms), so the diagonal is a sound proxy for "a direction that was
-  // stiff in the slot and is not any more" - the unsafe case described above.
-  double lu_drift_max = 0.25;
+  // Drift guard: at every restart the Jacobian is fresh; one kernel compares, for every slot, diag(I - c_s J) as it was when
+  // the slot was made with what today's Jacobian gives at the same c_s, and slots whose diagonal moved by more than a factor
+  // of 1 + lu_drift_max (either way) are dropped. For mass-action kinetics a column's off-diagonal entries are bounded by its
+  // diagonal (a reactant's loss terms), so the diagonal is a sound proxy for "a direction that was stiff in the slot and is not
+  // any more" - the unsafe case described above, which is a change by ORDERS of magnitude. Rounds 2-4 dropped at 25 %; round 5
+  // measured what that costs (profiles/r05_lu_drift_ab.txt: 157 of the 307 factorisations of the 100-chunk C3 solve re-made
+  // matrices the guard had dropped although the corrector - whose contraction is watched anyway, reuse_rate_max - converged
+  // with them): a factor of 2 keeps the protection and takes 307 -> 242 factorisations, 0.388 -> 0.346 s, C4's 20 chunks
+  // 516 -> 291 and 1.51 -> 1.39 s, deviations from the truths inside the spread of the reuse-band study.
+  double lu_drift_max = 1.0;
   DevBuf<int32_t> d_jdiag;
   DevBuf<double> d_drift;
   double* h_drift = nullptr;     // pinned

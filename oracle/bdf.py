@@ -86,7 +86,7 @@ class OracleBDF:
         # new Jacobian if the old one is more than 20 steps old); a reused slot that needed every allowed iteration is dropped
         self.lu_rate_max = 0.15
         self.lu_max_age = 50             # restarts a slot stays on offer after its Jacobian was evaluated
-        self.lu_drift_max = 0.25         # drift guard: see Solver::restart (solver.cpp)
+        self.lu_drift_max = 1.0          # drift guard: see Solver::restart (solver.cpp); 0.25 until round 4
         self.jac_stamp_now = 0
         self.cache_suspended = False     # a tolerance retry runs its chunk without the cache
         self.force_fresh_lu = False

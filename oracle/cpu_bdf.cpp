@@ -422,7 +422,7 @@ struct Bdf {
   int lu_cache = 0;
   struct Slot { double c_fact = 0.0, crate = 1.0; int64_t crate_step = 0, crate_restart = -1; int64_t last_use = 0, jac_stamp = 0; std::vector<double> Lx, Ux, Udiag, jd; };
   int64_t lu_max_age = 50, jac_stamp_now = 0;
-  double lu_drift_max = 0.25;                   // drift guard: see Solver::restart (solver.cpp)   // restarts a slot stays on offer after its Jacobian was evaluated
+  double lu_drift_max = 1.0;                    // drift guard: see Solver::restart (solver.cpp); 0.25 until round 4   // restarts a slot stays on offer after its Jacobian was evaluated
   bool cache_suspended = false;                // a tolerance retry runs its chunk without the cache
   std::vector<Slot> slots;          // the value arrays of the ACTIVE slot live in `lu` (swapped in)
   int active_slot = -1;

@@ -237,7 +237,7 @@ def test_warm_chunk_continuation_in_all_three_drivers(monkeypatch):
     tc, uc, rcc, stc, _ = h.solve(cold, u0)
     tw, uw, rcw, stw, _ = h.solve(warm, u0)
     assert rcc == 0 and rcw == 0 and np.array_equal(tc, tw) and stw["n_restarts"] == 10
-    assert stw["n_steps"] < 0.9 * stc["n_steps"] and units(uw, uc) < 150          # measured 970 against 1 129
+    assert stw["n_steps"] < 0.95 * stc["n_steps"] and units(uw, uc) < 150         # 987 against 1 091 (970 / 1 129 before the re-initialisations got cheaper in round 5)
     monkeypatch.setenv("KIN_RESIDENT", "0")
     th, uh, rch, sth, _ = h.solve(warm, u0)
     monkeypatch.delenv("KIN_RESIDENT")
