@@ -12,9 +12,9 @@
 // same constants. At the default tolerances (1e-10 / 1e-8) their trajectories agree within the step-sequence
 // tolerance (<= 124 units over the 312 solves of profiles/r04_robustness_resident.jsonl), not bit for bit. At rtol = 1e-10 every
 // implementation runs on the rounding floor of the right-hand side and they differ by the accuracy of their LINEAR ALGEBRA: against
-// a Radau truth (tests/golden/truth_tight_200.npz) the CPU port's pivoted LU lands at rms 88 / max 1 240 tight units in 6 429
-// steps, this controller over the in-workgroup factorisation at 362 / 5 126 in 9 442, the host-driven path's explicit inverses at
-// 872 / 12 333 in 17 474 with 15 294 corrector failures (profiles/r05_tight_tol_truth.jsonl; tests/test_gpu_resident.py bounds both).
+// a Radau truth (tests/golden/truth_tight_200.npz) the CPU port's pivoted LU lands at rms 153 / max 2 149 tight units in 6 692
+// steps, this controller over the in-workgroup factorisation at 385 / 5 442 in 9 531, the host-driven path's explicit inverses at
+// 885 / 12 511 in 17 618 with 15 641 corrector failures (profiles/r05_tight_tol_truth.jsonl; tests/test_gpu_resident.py bounds both).
 #pragma once
 #include <cmath>
 #include <cstdint>
