@@ -692,7 +692,9 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
                                                          int crate_from_ctrl, int ban_negatives) {
   __shared__ double sh[20];
   __shared__ int last;
-  if (ctrl->newton_done) return;
+  // the "already decided" flag travels with the first round of loads instead of in front of it (a dependent load of its own is
+  // ~1.5 us of every launch, segsum_dev.hpp): a launch behind the decision ends after ONE round of loads
+  const int decided = __hip_atomic_load(&ctrl->newton_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int G = gridDim.x;
   // A non-finite update makes the sum of squares non-finite: one reduction carries both the norm and the flag.
   double s = 0.0, se = 0.0, sm = 0.0, sp = 0.0, neg = 0.0;
@@ -707,6 +709,7 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     dm[x] = (ok && order > 1) ? D[(size_t)order * N + i] : 0.0;
     dp[x] = (ok && order < 5) ? D[(size_t)(order + 1) * N + i] : 0.0;
   }
+  if (decided) return;
 #pragma unroll
   for (int x = 0; x < RED_PT; x++) dy[x] = xl[x] >= 0 ? upd * W[xl[x]] : 0.0;   // upd = 2 / (1 + c / c_fact): reused factorisation
 #pragma unroll
