@@ -168,11 +168,11 @@ struct Solver {
   void set_tols(double a, double r) {
     atol = a; rtol = r;
     // corrector tolerance in the style of ode15s / CVODE: a fixed fraction of the error weight, not RADAU5's sqrt(rtol); see
-    // oracle/bdf.py (set_tols). ode15s uses 0.05; here 0.03 (KIN_NEWTON_TOL), together with reuse_rate_max = 0.15: with
-    // 0.05 / 0.2 two of the 140 solves of tools/robustness_sweep.py collapsed their step size (DtLessThanMin at every retry
-    // tolerance; the CPU mirror of the algorithm did the same) - iterates converged no further than asked leave enough
-    // noise in the difference history for that. Measured: C3 0.434 -> 0.452 s, full C4 ramp 161 -> 163 s, sweep 140 / 140.
-    constexpr double frac = 0.03;
+    // oracle/bdf.py (set_tols). ode15s uses 0.05, CVODE 0.1 (nlscoef); here 0.1 since round 5. Rounds 2-4 ran 0.03: with
+    // 0.05 two of the 140 solves of tools/robustness_sweep.py collapsed their step size then - that was before CVODE's
+    // failure and restart rules came in; with them every sweep ends as it does at 0.03 (profiles/r05_newton_tol_ab.txt),
+    // C3 takes 0.325 s instead of 0.350 s and at 1e-13 / 1e-11 the solve is 2-7 x closer to the Radau truth in half the steps.
+    constexpr double frac = 0.1;
     newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, frac);
   }
 
