@@ -10,11 +10,11 @@
 //     controller's logic is checked without a GPU (test infrastructure, not a product path).
 // The host-driven integrator of solver.cpp stays the path for large networks; both implement the same algorithm with the
 // same constants. At the default tolerances (1e-10 / 1e-8) their trajectories agree within the step-sequence
-// tolerance (<= 124 units over the 312 solves of profiles/r04_robustness_resident.jsonl), not bit for bit. At rtol = 1e-10 every
+// tolerance (<= 190 units over the 312 solves of profiles/r05_robustness_resident.jsonl), not bit for bit. At rtol = 1e-10 every
 // implementation runs on the rounding floor of the right-hand side and they differ by the accuracy of their LINEAR ALGEBRA: against
-// a Radau truth (tests/golden/truth_tight_200.npz) the CPU port's pivoted LU lands at rms 153 / max 2 149 tight units in 6 692
-// steps, this controller over the in-workgroup factorisation at 385 / 5 442 in 9 531, the host-driven path's explicit inverses at
-// 885 / 12 511 in 17 618 with 15 641 corrector failures (profiles/r05_tight_tol_truth.jsonl; tests/test_gpu_resident.py bounds both).
+// a Radau truth (tests/golden/truth_tight_200.npz) the CPU port's pivoted LU lands at rms 61 / max 378 tight units in 4 073
+// steps, this controller over the in-workgroup factorisation at 55 / 757 in 5 656, the host-driven path's explicit inverses at
+// 394 / 5 572 in 9 785 with 6 172 corrector failures (profiles/r05_tight_tol_truth.jsonl; tests/test_gpu_resident.py bounds both).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -33,6 +33,9 @@ constexpr int RES_D_ROWS = RES_MAX_ORDER + 3;
 constexpr int RES_MAX_SLOTS = 64;   // one LU-cache slot per lane of a wavefront (resident.hip keeps the slot table in registers)
 
 enum : int { RES_RET_SUCCESS = 0, RES_RET_MAXITERS = 1, RES_RET_DTLESSTHANMIN = 2, RES_RET_UNSTABLE = 3 };   // = KIN_RETCODE_*
+
+// corrector tolerance as a fraction of the error weight: solver_kernels.hpp bdf_newton_frac has the rule and its measurements
+KIN_HD inline double res_newton_frac(double rtol) { return fmin(0.1, fmax(0.03, 1e-10 / rtol)); }
 
 // what a solve needs besides the network (plain data; pointers are device pointers in the product, host pointers in the test)
 // largest power of ten <= h by exact IEEE operations only (solver.cpp: decade_floor)
@@ -159,7 +162,8 @@ struct ResidentBdf {
   KIN_HD void set_tols(double a, double r) {
     atol = a; rtol = r;
     const double lo = 10.0 * 2.220446049250313e-16 / r;
-    newton_tol = lo > P.newton_frac ? lo : P.newton_frac;
+    const double frac = P.newton_frac > 0.0 ? P.newton_frac : res_newton_frac(r);
+    newton_tol = lo > frac ? lo : frac;
   }
 
   // work matrices of change_D: MEMBERS, not locals - on the device the controller object lives in LDS, dynamically indexed

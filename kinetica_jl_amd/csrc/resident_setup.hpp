@@ -59,7 +59,7 @@ inline void res_default_settings(ResParams& P, int n_slots_max) {
   P.reuse_rate_max = 0.15;
   P.crate_dy_max = 0.2;
   P.lu_drift_max = 1.0;
-  P.newton_frac = 0.1;
+  P.newton_frac = -1.0;   // < 0: bdf_newton_frac(rtol), the rule of solver_kernels.hpp (a test may pin a value here)
   P.crate_max_age = 10;
   P.lu_max_age = 50;
   P.carry_rate = 1;

@@ -168,12 +168,9 @@ struct Solver {
   void set_tols(double a, double r) {
     atol = a; rtol = r;
     // corrector tolerance in the style of ode15s / CVODE: a fixed fraction of the error weight, not RADAU5's sqrt(rtol); see
-    // oracle/bdf.py (set_tols). ode15s uses 0.05, CVODE 0.1 (nlscoef); here 0.1 since round 5. Rounds 2-4 ran 0.03: with
-    // 0.05 two of the 140 solves of tools/robustness_sweep.py collapsed their step size then - that was before CVODE's
-    // failure and restart rules came in; with them every sweep ends as it does at 0.03 (profiles/r05_newton_tol_ab.txt),
-    // C3 takes 0.325 s instead of 0.350 s and at 1e-13 / 1e-11 the solve is 2-7 x closer to the Radau truth in half the steps.
-    constexpr double frac = 0.1;
-    newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, frac);
+    // oracle/bdf.py (set_tols). ode15s uses 0.05, CVODE 0.1 (nlscoef). Here 0.03 at the default tolerances, rising to 0.1
+    // where the relative tolerance goes below 3e-9 - bdf_newton_frac() in solver_kernels.hpp has the rule and what it rests on.
+    newton_tol = std::max(10.0 * std::numeric_limits<double>::epsilon() / rtol, bdf_newton_frac(rtol));
   }
 
   // step-end hand-over without a stream synchronisation: the corrector launch that decides the attempt publishes the

@@ -1,5 +1,7 @@
 // Kernel launchers and device-visible structs of the BDF integrator (solver_kernels.hip).
 #pragma once
+#include <cmath>
+
 #include "common.hpp"
 
 namespace kin {
@@ -7,6 +9,20 @@ namespace kin {
 constexpr int BDF_MAX_ORDER = 5;
 constexpr int BDF_NEWTON_MAXITER = 4;
 constexpr int BDF_D_ROWS = BDF_MAX_ORDER + 3;
+
+// Corrector tolerance as a fraction of the error weight atol + rtol |y| (the estimated iteration error must get below it):
+// 0.03 at the default relative tolerance 1e-8 and looser ones, 0.1 (CVODE's nlscoef) from 1e-9 down, 1e-10 / rtol between.
+// What it rests on (profiles/r05_newton_tol_ab.txt, one MI355X):
+//  * at rtol <= 1e-9 an iteration asked to converge to 0.03 of the weight asks for less than the rounding of the right-hand
+//    side's sums leaves (~1e-10 relative on these networks): it fails, and every failure restarts the step at a quarter. With 0.1
+//    the 200-species solve at 1e-12 / 1e-10 ends 2-7 x closer to its Radau truth in half the steps (resident kernel rms 385 -> 55
+//    tight units, host-driven 885 -> 394, CPU port 153 -> 61), C3 at 1e-11 / 1e-9 takes 0.60 s instead of 0.90 s;
+//  * at 1e-8 a flat 0.1 is 7 % faster on C3 (0.350 -> 0.325 s) and passes every sweep with the default switches, but over the 140
+//    solves of tools/robustness_sweep.py wide under four perturbed configurations (corrector fused, reuse band 0.3, 8 and 1
+//    factorisation slots) 10 of 560 needed a tolerance retry after a step-size collapse, against 3 of 560 at 0.03 and 5 at 0.05
+//    (ode15s) - all on 1 000-species networks, the ones that collapsed under 0.05 in round 2: not adopted there.
+// Same rule: resident_core.hpp res_newton_frac, oracle/bdf.py, oracle/cpu_bdf.cpp.
+inline double bdf_newton_frac(double rtol) { return std::fmin(0.1, std::fmax(0.03, 1e-10 / rtol)); }
 
 struct BdfCoef {  // passed to kernels by value
   double gamma[BDF_MAX_ORDER + 1];

@@ -120,10 +120,10 @@ class OracleBDF:
             # relative norm, i.e. 0.05 in units of the error weights atol + rtol*|y| used here (Shampine &
             # Reichelt 1997, sec. 2.3); CVODE uses 0.1 of its error-test constant. Both accept on the first
             # iteration when the correction is already that small.
-            # Rounds 2-4 ran 0.03 (0.05 collapsed the step size in two of 140 sweep solves then); with CVODE's failure and
-            # restart rules in place (round 5) CVODE's own 0.1 passes every sweep and is the value used by all four
-            # implementations (kinetica_jl_amd/csrc/solver.cpp set_tols has the measurements)
-            self.newton_tol = max(10 * EPS / rtol, 0.1)
+            # 0.03 at rtol >= 3.3e-9 (rounds 2-4: 0.05 collapsed the step size in two of 140 sweep solves), rising to CVODE's
+            # 0.1 at rtol <= 1e-9, where 0.03 asks for less than the rounding of the right-hand side leaves
+            # (kinetica_jl_amd/csrc/solver_kernels.hpp bdf_newton_frac has the rule and its measurements)
+            self.newton_tol = max(10 * EPS / rtol, min(0.1, max(0.03, 1e-10 / rtol)))
 
     def _f(self, y):
         self.stats["n_rhs"] += 1

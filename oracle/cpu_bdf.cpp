@@ -517,7 +517,7 @@ struct Bdf {
     lu.analyze((int32_t)N, net.jcp, net.jri);
   }
   double* Drow(int j) { return D.data() + (size_t)j * N; }
-  void set_tols(double a, double r) { atol = a; rtol = r; newton_tol = std::max(10.0 * EPS / r, 0.1); }   // oracle/bdf.py set_tols
+  void set_tols(double a, double r) { atol = a; rtol = r; newton_tol = std::max(10.0 * EPS / r, std::min(0.1, std::max(0.03, 1e-10 / r))); }   // oracle/bdf.py set_tols
   void fun(const double* u, double* out) { const double t0 = now_s(); net.rhs(k, u, out); st.n_rhs++; st.t_rhs += now_s() - t0; }
   void eval_jac(const double* u) { const double t0 = now_s(); net.jac(k, u, J.data()); st.n_jac++; lu_valid = false; steps_since_jac = 0; jac_stamp_now = st.n_restarts; st.t_jac += now_s() - t0; }
   double rms_scaled(const double* v, const double* sc) const {
