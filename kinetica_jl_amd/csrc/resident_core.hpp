@@ -10,7 +10,7 @@
 //     controller's logic is checked without a GPU (test infrastructure, not a product path).
 // The host-driven integrator of solver.cpp stays the path for large networks; both implement the same algorithm with the
 // same constants. At the default tolerances (1e-10 / 1e-8) their trajectories agree within the step-sequence
-// tolerance (<= 190 units over the 312 solves of profiles/r05_robustness_resident.jsonl), not bit for bit. At rtol = 1e-10 every
+// tolerance (<= 201 units over the 312 solves of profiles/r05_robustness_resident.jsonl), not bit for bit. At rtol = 1e-10 every
 // implementation runs on the rounding floor of the right-hand side and they differ by the accuracy of their LINEAR ALGEBRA: against
 // a Radau truth (tests/golden/truth_tight_200.npz) the CPU port's pivoted LU lands at rms 61 / max 378 tight units in 4 073
 // steps, this controller over the in-workgroup factorisation at 55 / 757 in 5 656, the host-driven path's explicit inverses at
