@@ -44,7 +44,9 @@ enum {
   KIN_RETCODE_SUCCESS = 0,
   KIN_RETCODE_MAXITERS = 1,
   KIN_RETCODE_DTLESSTHANMIN = 2,
-  KIN_RETCODE_UNSTABLE = 3
+  KIN_RETCODE_UNSTABLE = 3     /* a non-finite state at (re)initialisation, or an accepted step that leaves a species below -1e3
+                                * error weights (the blow-up of a negative concentration, given up before the step size has followed
+                                * it down to dtmin; the tolerance retry of adaptive_tols treats it like any other failure) */
 };
 
 typedef struct kin_network kin_network; /* opaque */

@@ -620,6 +620,7 @@ struct MemberBackend {
     const BdfCtrl& c = E.ctrl_of[t];
     ResAttempt a{};
     a.done = c.newton_done != 0; a.converged = c.converged != 0; a.nonfinite = c.nonfinite != 0; a.any_negative = c.any_negative != 0;
+    a.deep_negative = (c.any_negative & 2) != 0;
     a.n_iter = c.n_iter; a.err = c.err_norm; a.err_m = c.err_m_norm; a.err_p = c.err_p_norm; a.crate = c.crate;
     return a;
   }

@@ -845,8 +845,8 @@ __device__ __forceinline__ ResSums newton_body(int slot, double c, double upd, i
     const double q = dy / scale[i];
     v[0] += q * q;
     const double yy = y[i] + dy, dd = d[i] + dy;
-    if (yy < 0.0) v[4] = 1.0;
     const double sce = atol + rtol * fabs(yy);
+    if (yy < 0.0) v[4] = fmax(v[4], yy < -RES_NEG_DEEP * sce ? RES_NEG_MARK : 1.0);
     const double e = ec * dd / sce;
     v[1] += e * e + (isfinite(yy) ? 0.0 : INFINITY);
     if (order > 1) { const double em = ec_m * (D[(size_t)order * N + i] + dd) / sce; v[2] += em * em; }

@@ -89,14 +89,16 @@ struct ResCorrIn {
   int32_t slot, order;
   double c, upd, rate_max, crate0, tol_first, newton_tol, dy_first_max, ec, ec_m, ec_p, atol, rtol, alpha_o;
 };
-struct ResAttempt { bool done, converged, nonfinite, any_negative; int n_iter; double err, err_m, err_p, crate; };
+struct ResAttempt { bool done, converged, nonfinite, any_negative, deep_negative; int n_iter; double err, err_m, err_p, crate; };
+// solver_kernels.hpp BDF_NEG_DEEP / BDF_NEG_MARK: an accepted step with a species below -1e3 error weights ends the segment
+constexpr double RES_NEG_DEEP = 1e3, RES_NEG_MARK = 4294967296.0;
 
 // Predictor + corrector iterations until decided: the decisions of newton_decide (solver_kernels.hip), taken in sequence.
 // `I` supplies predict_inner / newton_iter_inner (the CPU replay: the backend itself; the device: the phase's own inlined
 // operations, run by all wavefronts).
 template <class I>
 KIN_HD ResAttempt res_corrector_loop(I& b, const ResCorrIn& in, const double* gamma, int n_species) {
-  ResAttempt a{false, false, false, false, 0, 0.0, 0.0, 0.0, 1.0};
+  ResAttempt a{false, false, false, false, false, 0, 0.0, 0.0, 0.0, 1.0};
   b.predict_inner(in.order, gamma, in.alpha_o, in.atol, in.rtol);
   const double N = (double)n_species;
   double crate = in.crate0, dy_old = 0.0;
@@ -127,6 +129,7 @@ KIN_HD ResAttempt res_corrector_loop(I& b, const ResCorrIn& in, const double* ga
     if (a.converged) {
       a.err = sqrt(q.se / N); a.err_m = sqrt(q.sm / N); a.err_p = sqrt(q.sp / N);
       a.any_negative = q.neg > 0.0;
+      a.deep_negative = q.neg >= RES_NEG_MARK;
       if (!(fabs(q.se) <= 1.79769313486231570815e308)) a.nonfinite = true;
     }
   }
@@ -301,7 +304,7 @@ struct ResidentBdf {
     return b.corrector(in, gamma);
   }
 
-  enum StepStatus { STEP_OK = 0, STEP_DT_MIN = 1 };
+  enum StepStatus { STEP_OK = 0, STEP_DT_MIN = 1, STEP_UNSTABLE = 2 };
 
   // one accepted step towards t_bound (Solver::step without the asynchronous machinery)
   KIN_HD StepStatus step(double t_bound) {
@@ -402,6 +405,7 @@ struct ResidentBdf {
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
+        if (a.deep_negative) return STEP_UNSTABLE;   // solver_kernels.hpp BDF_NEG_DEEP: the negative excursion, given up early
         accepted = true;
       }
     }
@@ -517,6 +521,7 @@ struct ResidentBdf {
               const StepStatus ss = step(seg_len);
               if (iters_left < 0) { retcode = RES_RET_MAXITERS; failed = true; break; }
               if (ss == STEP_DT_MIN) { retcode = RES_RET_DTLESSTHANMIN; failed = true; break; }
+              if (ss == STEP_UNSTABLE) { retcode = RES_RET_UNSTABLE; failed = true; break; }
               const double t_abs = t >= seg_len ? seg_end : t_seg + t;
               const int last = (chunks && !(nc == P.n_chunks - 1 && !P.save_hits_end)) ? L - 1 : L;
               while (save_i < last && P.save_local[save_i] <= t_abs) {

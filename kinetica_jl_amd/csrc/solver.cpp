@@ -841,6 +841,7 @@ struct Solver {
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
+        if (hc->any_negative & 2) return STEP_UNSTABLE;   // solver_kernels.hpp BDF_NEG_DEEP: the negative excursion, given up early
         accepted = true;
       }
     }

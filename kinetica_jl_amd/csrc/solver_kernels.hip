@@ -657,14 +657,14 @@ __device__ __forceinline__ void newton_decide(const NewtonDecide& a) {
       ctrl->err_norm = sqrt(te / (double)N);
       ctrl->err_m_norm = sqrt(a.tot[2] / (double)N);
       ctrl->err_p_norm = sqrt(a.tot[3] / (double)N);
-      ctrl->any_negative = a.tot[4] > 0.0;
+      ctrl->any_negative = a.tot[4] > 0.0 ? (a.tot[4] >= BDF_NEG_MARK ? 3 : 1) : 0;   // bit 1: a species below -BDF_NEG_DEEP weights
       if (!isfinite(te)) ctrl->nonfinite = 1;
     }
     ctrl->converged = converged ? 1 : 0;
     ctrl->newton_done = done ? 1 : 0;
     // the verdict the host will reach from the same numbers (solver.cpp, step()): an accepted step with nothing that makes
     // the next one more than a continuation (every allowed iteration used = the host may drop the factorisation)
-    ctrl->spec_go = (done && converged && !ctrl->nonfinite && !ctrl->lu_bad && !(a.ban_negatives && ctrl->any_negative) &&
+    ctrl->spec_go = (done && converged && !ctrl->nonfinite && !ctrl->lu_bad && !(a.ban_negatives && ctrl->any_negative) && !(ctrl->any_negative & 2) &&
                      !(ctrl->err_norm > 1.0) && iter + 1 < maxit) ? 1 : 0;
     if ((done || publish_always) && host_ctrl) {
       *host_ctrl = *ctrl;
@@ -719,8 +719,8 @@ __global__ __launch_bounds__(256) void bdf_newton_kernel(int N, int iter, int ma
     yy[x] += dy[x]; dd[x] += dy[x];
     if (i0 + 256 * x >= N) continue;
     // error test of the state after this iteration (a non-finite state makes the sum non-finite)
-    if (yy[x] < 0.0) neg = 1.0;
     const double sce = atol + rtol * fabs(yy[x]);
+    if (yy[x] < 0.0) neg = fmax(neg, yy[x] < -BDF_NEG_DEEP * sce ? BDF_NEG_MARK : 1.0);
     const double e = cf.error_const[order] * dd[x] / sce;
     se += e * e + (isfinite(yy[x]) ? 0.0 : INFINITY);
     if (order > 1) { const double em = cf.error_const[order - 1] * (dm[x] + dd[x]) / sce; sm += em * em; }
@@ -781,8 +781,8 @@ __device__ __forceinline__ void newton_apply(const NewtonFuse& f, int32_t sp, do
   const double q = dy / e.sc;
   t.s += q * q;
   e.yy += dy; e.dd += dy;
-  if (e.yy < 0.0) t.neg = 1.0;
   const double sce = f.atol + f.rtol * fabs(e.yy);
+  if (e.yy < 0.0) t.neg = fmax(t.neg, e.yy < -BDF_NEG_DEEP * sce ? BDF_NEG_MARK : 1.0);
   const double er = f.ec * e.dd / sce;
   t.se += er * er + (isfinite(e.yy) ? 0.0 : INFINITY);
   if (f.order > 1) { const double em = f.ec_m * (e.dm + e.dd) / sce; t.sm += em * em; }

@@ -22,6 +22,14 @@ constexpr int BDF_D_ROWS = BDF_MAX_ORDER + 3;
 //    factorisation slots) 10 of 560 needed a tolerance retry after a step-size collapse, against 3 of 560 at 0.03 and 5 at 0.05
 //    (ode15s) - all on 1 000-species networks, the ones that collapsed under 0.05 in round 2: not adopted there.
 // Same rule: resident_core.hpp res_newton_frac, oracle/bdf.py, oracle/cpu_bdf.cpp.
+// An ACCEPTED step (corrector converged, error test passed) that leaves a species below -BDF_NEG_DEEP error weights ends the
+// segment as Unstable: no single step makes that (the error test bounds a step's own error), it is the negative excursion of
+// DESIGN 4 - below zero some species are unstable under mass-action kinetics, |u| grows with an e-folding time of ~0.1 ms and h
+// follows it down for 500-1 400 more steps until dtmin or a non-finite state ends the attempt anyway; the chunk's tolerance retry
+// (negative entries of its start state zeroed) is what carries the solve in either case, so results are unchanged. The flag
+// rides in the sum that counts negative entries: a thread contributes 1 for a negative entry, BDF_NEG_MARK for a deep one.
+constexpr double BDF_NEG_DEEP = 1e3;
+constexpr double BDF_NEG_MARK = 4294967296.0;   // 2^32 > any count of species
 inline double bdf_newton_frac(double rtol) { return std::fmin(0.1, std::fmax(0.03, 1e-10 / rtol)); }
 
 struct BdfCoef {  // passed to kernels by value

@@ -46,6 +46,7 @@ ALPHA = (1 - KAPPA) * GAMMA
 ERROR_CONST = KAPPA * GAMMA + 1 / np.arange(1, MAX_ORDER + 2)
 
 RET_SUCCESS, RET_MAXITERS, RET_DTMIN, RET_UNSTABLE = 0, 1, 2, 3
+NEG_DEEP = 1e3
 
 
 def rms(x):
@@ -423,6 +424,10 @@ class OracleBDF:
                     self._reset_history()
                     order = self.order
             else:
+                # an accepted step that leaves a species below -NEG_DEEP error weights ends the segment as Unstable: the negative
+                # excursion, given up early (kinetica_jl_amd/csrc/solver_kernels.hpp BDF_NEG_DEEP has the reasoning)
+                if np.any(y_new < -NEG_DEEP * scale):
+                    return "unstable"
                 accepted = True
         self.stats["n_steps"] += 1
         self.steps_since_jac += 1
@@ -680,6 +685,9 @@ def solve_network_oracle(fun_of_k, jac_of_k, n, params, u0, k0=None, tstops=None
                             break
                         if status == "dtmin":
                             retcode, failed = RET_DTMIN, True
+                            break
+                        if status == "unstable":
+                            retcode, failed = RET_UNSTABLE, True
                             break
                         t_abs = seg_end if bdf.t >= seg_len else t_seg + bdf.t
                         if L > 0:

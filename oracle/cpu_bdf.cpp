@@ -727,7 +727,8 @@ struct Bdf {
     if (!converged) st.n_newton_fail++;
     return converged;
   }
-  enum Status { OK = 0, DTMIN = 1, MAXITERS = 2 };
+  enum Status { OK = 0, DTMIN = 1, MAXITERS = 2, UNSTABLE = 3 };
+  static constexpr double NEG_DEEP = 1e3;   // kinetica_jl_amd/csrc/solver_kernels.hpp BDF_NEG_DEEP
   Status step(double t_bound) {
     bool accepted = false, first_attempt = true;
     double safety = 0.9, err_norm = 0.0, t_new = t;
@@ -811,6 +812,8 @@ struct Bdf {
         fail_score += 1.0;
         if (fail_score >= 3.0 && order > 1) reset_history();
       } else {
+        // an accepted step with a species below -NEG_DEEP error weights: the negative excursion, given up early
+        for (int64_t i = 0; i < N; i++) if (y[i] < -NEG_DEEP * scale[i]) return UNSTABLE;
         accepted = true;
       }
     }
@@ -977,6 +980,7 @@ int solve(Handle& H, const CpuParams& p, const double* u0, const double* k0, con
             const Bdf::Status ss = B.step(seg_len);
             if (ss == Bdf::MAXITERS) { retcode = RET_MAXITERS; failed = true; break; }
             if (ss == Bdf::DTMIN) { retcode = RET_DTMIN; failed = true; break; }
+            if (ss == Bdf::UNSTABLE) { retcode = RET_UNSTABLE; failed = true; break; }
             const double t_abs = B.t >= seg_len ? seg_end : t_seg + B.t;
             if (L > 0) {
               const int64_t last_i = (chunks && !(nc == n_chunks - 1 && !save_hits_end)) ? L - 1 : L;

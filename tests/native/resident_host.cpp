@@ -333,8 +333,8 @@ struct HostBackend {
       const double s = dy / scale[i];
       q.s += s * s;
       const double yy = y[i] + dy, dd = d[i] + dy;
-      if (yy < 0.0) q.neg = 1.0;
       const double sce = atol + rtol * std::fabs(yy);
+      if (yy < 0.0) q.neg = std::fmax(q.neg, yy < -RES_NEG_DEEP * sce ? RES_NEG_MARK : 1.0);
       const double e = ec * dd / sce;
       q.se += e * e + (std::isfinite(yy) ? 0.0 : INFINITY);
       if (order > 1) { const double em = ec_m * (D[(size_t)order * N + i] + dd) / sce; q.sm += em * em; }

@@ -79,6 +79,23 @@ def test_restart_rules_take_the_same_steps_in_every_implementation(monkeypatch):
     assert rco == 0 and rcc == 0 and counts[0] == counts[1] == sto["n_steps"] == stc["n_steps"]
 
 
+def test_a_species_deep_below_zero_ends_the_segment_as_unstable(monkeypatch):
+    """2A -> B with A(0) = -1e-3 (blow-up at 0.5 ms): an accepted step that leaves a species below -1e3 error weights ends the
+    segment as Unstable (solver_kernels.hpp BDF_NEG_DEEP) - resident kernel and host-driven integrator, same retcode and step
+    count as the CPU implementations (tests/test_resident_replay.py has those); with `adaptive_tols` the chunk's retry zeroes the
+    negative entry and the solve ends with Success."""
+    net = from_lists(2, [[(0, 2)]], [[(1, 1)]])
+    for resident in ("1", "0"):
+        monkeypatch.setenv("KIN_RESIDENT", resident)
+        h = capi.HipNetwork.from_flat(net); h.set_rates([1e6])
+        t, u, rc, st, status = h.solve(kp((0.0, 1e-3), adaptive=False), [-1e-3, 1.0])
+        # (a solve that ends without Success is the reference's ErrorException("ODE solution failed."): KIN_ERR_SOLVE_FAILED)
+        assert status == capi.KIN_ERR_SOLVE_FAILED and capi.RETCODE_NAMES[rc] == "Unstable" and st["n_steps"] == 0, (resident, status, rc, st)
+        t, u, rc, st, status = h.solve(kp((0.0, 1e-3)), [-1e-3, 1.0])
+        assert status == capi.KIN_OK and rc == 0 and st["n_retries"] == 1 and u[-1, 0] == 0.0, (resident, rc, st)
+        h.close()
+
+
 def test_closed_forms_complete_timespan():
     pars = kp((0.0, 2.0), chunks=False, save=0.25)
     # A <-> B

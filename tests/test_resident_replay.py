@@ -171,6 +171,30 @@ def test_robertson_and_failure_semantics(golden_dir):
     hr.close()
 
 
+def test_a_species_deep_below_zero_ends_the_segment_as_unstable():
+    """2A -> B with A(0) = -1e-3 runs to -infinity in finite time (1 / (2 k |A0|) = 0.5 ms): the negative excursion of DESIGN 4 in
+    two species. An ACCEPTED step that leaves a species below -1e3 error weights ends the segment as Unstable in every
+    implementation (kinetica_jl_amd/csrc/solver_kernels.hpp BDF_NEG_DEEP) instead of following the blow-up down to dtmin: same
+    retcode and the same handful of steps from the resident controller's CPU replay, oracle/cpu_bdf.cpp and oracle/bdf.py; with
+    `adaptive_tols` the retry zeroes the negative entry of the chunk's start state and the solve ends with Success."""
+    from oracle import bdf as obdf
+    net = from_lists(2, [[(0, 2)]], [[(1, 1)]])
+    k = np.array([1e6]); u0 = np.array([-1e-3, 1.0])
+    hr = HostResident(net)
+    cs = cpu_bdf.CpuSolver(net)
+    on = orc.OracleNetwork.from_flat(net)
+    t, u, rc, st = hr.solve(kp(1e-3, adaptive_tols=0), u0, k0=k)
+    tc, uc, rcc, stc = cs.solve(dict(tspan=(0.0, 1e-3), adaptive_tols=False), u0, k0=k)
+    to, uo, rco, sto = obdf.solve_network_oracle(lambda kk: (lambda y: on.rhs(kk, y)), lambda kk: (lambda y: on.jac(kk, y)), 2,
+                                                 dict(tspan=(0.0, 1e-3), adaptive_tols=False), u0, k0=k)
+    assert rc == rcc == rco == 3                                   # Unstable
+    assert st["n_steps"] == stc["n_steps"] == sto["n_steps"] == 0  # the first step is never accepted
+    t, u, rc, st = hr.solve(kp(1e-3), u0, k0=k)
+    tc, uc, rcc, stc = cs.solve(dict(tspan=(0.0, 1e-3)), u0, k0=k)
+    assert rc == 0 and rcc == 0 and st["n_retries"] == stc["n_retries"] == 1 and u[-1, 0] == 0.0 and uc[-1, 0] == 0.0
+    hr.close()
+
+
 def test_ban_negatives_rejects_steps_like_the_cpu_implementation():
     net, Ea, A = synthetic_crn(300, 1500)
     k = orc.arrhenius(Ea, A, 1400.0, k_max=1e12)
