@@ -231,7 +231,7 @@ def build():
     sm = open(os.path.join(P, pick("switch_matrix.txt"))).read()
     runs = re.findall(r"^== (\S+): (.*)$", sm, flags=re.M)
     clean = sum(1 for _, r_ in runs if "failed" not in r_)
-    add("switches", f"solve tests (47) under each of {len(runs)} non-default switch values: values with every test green / with tests that assert default-route properties failing", f"{clean} / {len(runs) - clean}", pick("switch_matrix.txt"))
+    add("switches", f"solve tests (48) under each of {len(runs)} non-default switch values: values with every test green / with tests that assert default-route properties failing", f"{clean} / {len(runs) - clean}", pick("switch_matrix.txt"))
 
     rk = b.get("ranks", {})
     add("multi-GPU", "ranks that took part in the committed bench line", f"world size {rk.get('world_size')}, backend {rk.get('backend')}; no scaling curve measured", f"{src_b} `ranks`")
