@@ -23,10 +23,12 @@ constexpr int BDF_D_ROWS = BDF_MAX_ORDER + 3;
 //    (ode15s) - all on 1 000-species networks, the ones that collapsed under 0.05 in round 2: not adopted there.
 // Same rule: resident_core.hpp res_newton_frac, oracle/bdf.py, oracle/cpu_bdf.cpp.
 // An ACCEPTED step (corrector converged, error test passed) that leaves a species below -BDF_NEG_DEEP error weights ends the
-// segment as Unstable: no single step makes that (the error test bounds a step's own error), it is the negative excursion of
-// DESIGN 4 - below zero some species are unstable under mass-action kinetics, |u| grows with an e-folding time of ~0.1 ms and h
-// follows it down for 500-1 400 more steps until dtmin or a non-finite state ends the attempt anyway; the chunk's tolerance retry
-// (negative entries of its start state zeroed) is what carries the solve in either case, so results are unchanged. The flag
+// segment as Unstable. The error test bounds what ONE step can do to one species at sqrt(N) / error constant weights in the worst
+// case (~300 at 1 000 species; more only if a step's whole error sat on a single species of a larger network), so such a state
+// has been growing over many accepted steps: it is the negative excursion of DESIGN 4 - below zero some species are unstable
+// under mass-action kinetics, |u| grows with an e-folding time of ~0.1 ms and h follows it down for 500-1 400 more steps until
+// dtmin or a non-finite state ends the attempt anyway. The chunk's tolerance retry (negative entries of its start state zeroed)
+// carries the solve in either case; a false alarm costs one such retry (docs/DESIGN_HISTORY.md R5.12 has the measurements). The flag
 // rides in the sum that counts negative entries: a thread contributes 1 for a negative entry, BDF_NEG_MARK for a deep one.
 constexpr double BDF_NEG_DEEP = 1e3;
 constexpr double BDF_NEG_MARK = 4294967296.0;   // 2^32 > any count of species
