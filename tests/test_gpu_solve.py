@@ -64,19 +64,21 @@ def test_restart_rules_take_the_same_steps_in_every_implementation(monkeypatch):
     problem, same step counts."""
     from oracle import cpu_bdf
     net = from_lists(2, [[(0, 1)]], [[(1, 1)]])
-    pars = kp((0.0, 1.0), True, 0.1, 0.05)
-    odict = dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.1, save_interval=0.05)
-    counts = []
-    for resident in ("1", "0"):
-        monkeypatch.setenv("KIN_RESIDENT", resident)
-        h = capi.HipNetwork.from_flat(net); h.set_rates([3.0])
-        t, u, rc, st, status = h.solve(pars, [1.0, 0.0])
-        assert status == capi.KIN_OK and rc == 0 and errscale(u[:, 0], np.exp(-3.0 * t)) < 100
-        counts.append(st["n_steps"])
-        h.close()
-    to, uo, rco, sto = oracle_solve(net, odict, [1.0, 0.0], k0=np.array([3.0]))
-    tc, uc, rcc, stc = cpu_bdf.CpuSolver(net).solve(odict, np.array([1.0, 0.0]), k0=np.array([3.0]))
-    assert rco == 0 and rcc == 0 and counts[0] == counts[1] == sto["n_steps"] == stc["n_steps"]
+    # ... and so is the corrector tolerance, which depends on rtol (bdf_newton_frac: 0.03 at 1e-8, 0.1 from 1e-9 down)
+    for atol, rtol in ((1e-10, 1e-8), (1e-11, 1e-9), (1e-12, 1e-10)):
+        pars = kp((0.0, 1.0), True, 0.1, 0.05, abstol=atol, reltol=rtol)
+        odict = dict(tspan=(0.0, 1.0), solve_chunks=True, solve_chunkstep=0.1, save_interval=0.05, abstol=atol, reltol=rtol)
+        counts = []
+        for resident in ("1", "0"):
+            monkeypatch.setenv("KIN_RESIDENT", resident)
+            h = capi.HipNetwork.from_flat(net); h.set_rates([3.0])
+            t, u, rc, st, status = h.solve(pars, [1.0, 0.0])
+            assert status == capi.KIN_OK and rc == 0 and errscale(u[:, 0], np.exp(-3.0 * t)) < 100
+            counts.append(st["n_steps"])
+            h.close()
+        to, uo, rco, sto = oracle_solve(net, odict, [1.0, 0.0], k0=np.array([3.0]))
+        tc, uc, rcc, stc = cpu_bdf.CpuSolver(net).solve(odict, np.array([1.0, 0.0]), k0=np.array([3.0]))
+        assert rco == 0 and rcc == 0 and counts[0] == counts[1] == sto["n_steps"] == stc["n_steps"], (rtol, counts, sto["n_steps"], stc["n_steps"])
 
 
 def test_a_species_deep_below_zero_ends_the_segment_as_unstable(monkeypatch):

@@ -113,6 +113,27 @@ def test_controller_takes_the_steps_of_the_independent_cpu_implementation():
     hr.close()
 
 
+def test_corrector_tolerance_rule_is_the_same_in_every_implementation():
+    """The corrector tolerance is 0.03 of the error weight down to rtol = 3.3e-9 and rises to 0.1 at 1e-9 (bdf_newton_frac,
+    solver_kernels.hpp): A -> B at 1e-11 / 1e-9 and at 1e-12 / 1e-10 takes the same number of steps in the replayed resident
+    controller, oracle/cpu_bdf.cpp and oracle/bdf.py (at the default tolerances tests/test_gpu_solve.py compares all four)."""
+    from oracle import bdf as obdf
+    net = from_lists(2, [[(0, 1)]], [[(1, 1)]])
+    on = orc.OracleNetwork.from_flat(net)
+    k = np.array([3.0]); u0 = np.array([1.0, 0.0])
+    hr = HostResident(net)
+    cs = cpu_bdf.CpuSolver(net)
+    for atol, rtol, frac in ((1e-10, 1e-8, 0.03), (1e-10, 5e-9, 0.03), (1e-11, 2e-9, 0.05), (1e-11, 1e-9, 0.1), (1e-12, 1e-10, 0.1)):
+        ob = obdf.OracleBDF(lambda y: y, lambda y: None, 2, atol, rtol)
+        assert ob.newton_tol == pytest.approx(frac)
+        pars = dict(tspan=(0.0, 1.0), solve_chunkstep=0.1, save_interval=0.05, abstol=atol, reltol=rtol, dtmin=1e-30)
+        t, u, rc, st = hr.solve(kp(1.0, chunk=0.1, save=0.05, abstol=atol, reltol=rtol, dtmin=1e-30), u0, k0=k)
+        tc, uc, rcc, stc = cs.solve(pars, u0, k0=k)
+        to, uo, rco, sto = obdf.solve_network_oracle(lambda kk: (lambda y: on.rhs(kk, y)), lambda kk: (lambda y: on.jac(kk, y)), 2, pars, u0, k0=k)
+        assert rc == rcc == rco == 0 and st["n_steps"] == stc["n_steps"] == sto["n_steps"], (rtol, st["n_steps"], stc["n_steps"], sto["n_steps"])
+    hr.close()
+
+
 def test_discrete_rate_updates_save_grid_and_truth(golden_dir):
     """60-species network under a temperature ramp (zero-order hold, restart at every stop, save grid finer than the stops)
     against the committed Radau truth, and against cpu_bdf on a finer grid with chunk stitching."""
