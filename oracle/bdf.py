@@ -111,6 +111,10 @@ class OracleBDF:
         self.iters_left = 0
         self.first_selection = False
         self.pre_attempt = None   # continuous rates: called with the local time of every step attempt
+        # EXPERIMENT HOOK (tools/err_cap_experiment.py; None = the algorithm as built, everywhere else): a cap on the error
+        # estimate of the WORST species, in error weights - a step whose rms error test passes but whose worst species is above
+        # the cap is treated as an error-test failure of size worst / cap (docs/DESIGN_HISTORY.md R5.13)
+        self.err_cap = None
 
     def set_tols(self, atol, rtol):
         self.atol, self.rtol = atol, rtol
@@ -410,6 +414,10 @@ class OracleBDF:
             safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2 * NEWTON_MAXITER + n_iter)
             scale = self.atol + self.rtol * np.abs(y_new)
             err_norm = rms(ERROR_CONST[order] * d / scale)
+            if self.err_cap is not None and err_norm <= 1:
+                worst = float(np.max(np.abs(ERROR_CONST[order] * d / scale)))
+                if worst > self.err_cap:
+                    err_norm = max(1.0001, worst / self.err_cap)
             if err_norm > 1:
                 factor = max(MIN_FACTOR, safety * err_norm ** (-1 / (order + 1)))
                 self.h_abs *= factor
